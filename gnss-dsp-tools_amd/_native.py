@@ -1,0 +1,107 @@
+"""ctypes binding of libgacq.so (the C ABI declared in include/gacq.h).
+
+The library is built in-tree by __graft_entry__.build() / `make -C gnss-dsp-tools_amd/csrc`.
+There is NO Python/CPU fallback for the engine: if the shared object is missing this module
+raises at import, and the engine entry points raise when no GPU is visible.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgacq.so")
+
+# One HIP runtime per process: when torch is (or will be) in the process its bundled
+# libamdhip64/librocfft (same SONAMEs as /opt/rocm's) must be the ones that get bound, so it
+# is imported before libgacq.so is dlopen'ed.  Device buffers are torch tensors anyway.
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - torch is part of the image; C-only users do not need it
+    torch = None
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libgacq.so not built: %s is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+        "or `make -C gnss-dsp-tools_amd/csrc` (needs hipcc). There is no CPU fallback." % LIB_PATH)
+
+lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+
+c_int_p = ctypes.POINTER(ctypes.c_int)
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_uint8_p = ctypes.POINTER(ctypes.c_uint8)
+
+
+class SigDesc(ctypes.Structure):
+    _fields_ = [("code_length", ctypes.c_int), ("n", ctypes.c_int), ("pad", ctypes.c_int),
+                ("boc", ctypes.c_int), ("metric_mode", ctypes.c_int), ("fold_code", ctypes.c_int),
+                ("fs", ctypes.c_double)]
+
+
+class Result(ctypes.Structure):
+    _fields_ = [("metric", ctypes.c_double), ("code_chips", ctypes.c_double),
+                ("doppler_hz", ctypes.c_double), ("idx", ctypes.c_int), ("d_index", ctypes.c_int)]
+
+
+class Peak(ctypes.Structure):
+    _fields_ = [("metric", ctypes.c_double), ("idx", ctypes.c_int), ("d_index", ctypes.c_int)]
+
+
+ERRORS = {0: "GACQ_OK", -1: "GACQ_ERR_BAD_ARG", -2: "GACQ_ERR_UNKNOWN_CODE", -3: "GACQ_ERR_BAD_PRN",
+          -4: "GACQ_ERR_HIP", -5: "GACQ_ERR_ROCFFT", -6: "GACQ_ERR_SHORT_INPUT", -7: "GACQ_ERR_NO_DEVICE",
+          -8: "GACQ_ERR_INTERNAL", -9: "GACQ_ERR_UNSUPPORTED"}
+
+# name -> (restype, argtypes): every symbol include/gacq.h declares
+SYMBOLS = {
+    "gacq_code_count": (ctypes.c_int, []),
+    "gacq_code_name": (ctypes.c_char_p, [ctypes.c_int]),
+    "gacq_code_length": (ctypes.c_int, [ctypes.c_char_p]),
+    "gacq_code_chip_rate": (ctypes.c_double, [ctypes.c_char_p]),
+    "gacq_code_prns": (ctypes.c_int, [ctypes.c_char_p, c_int_p, ctypes.c_int]),
+    "gacq_code_chips": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, c_uint8_p, ctypes.c_int]),
+    "gacq_code_replica": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_float_p]),
+    "gacq_device_count": (ctypes.c_int, []),
+    "gacq_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "gacq_destroy": (None, [ctypes.c_void_p]),
+    "gacq_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "gacq_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "gacq_set_engine": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "gacq_set_workspace_limit": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]),
+    "gacq_signal_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(SigDesc), ctypes.c_char_p,
+                                          c_int_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "gacq_signal_create_chips": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(SigDesc), c_uint8_p,
+                                                ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "gacq_signal_destroy": (None, [ctypes.c_void_p]),
+    "gacq_signal_fft_length": (ctypes.c_int, [ctypes.c_void_p]),
+    "gacq_signal_spectrum": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_float_p]),
+    "gacq_search": (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_size_t, c_int_p, ctypes.c_int,
+                                   c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.POINTER(Result)]),
+    "gacq_search_batch_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                             c_int_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p,
+                                             ctypes.c_int, ctypes.c_void_p]),
+    "gacq_finalize": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Peak), ctypes.c_int, c_int_p, ctypes.c_int,
+                                     c_double_p, ctypes.c_int, ctypes.POINTER(Result)]),
+    "gacq_set_profiling": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "gacq_get_stage_time": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, ctypes.POINTER(ctypes.c_long)]),
+    "gacq_reset_stage_times": (ctypes.c_int, [ctypes.c_void_p]),
+    "gacq_stage_name": (ctypes.c_char_p, [ctypes.c_int]),
+    "gacq_debug_row": (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_double,
+                                      ctypes.c_double, ctypes.c_int, c_float_p]),
+}
+
+for _name, (_res, _args) in SYMBOLS.items():
+    _fn = getattr(lib, _name)          # AttributeError here == the .so does not export a declared symbol
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+class GacqError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("%s (%d): %s" % (ERRORS.get(code, "GACQ_ERR_?"), code, message))
+        self.code = code
+
+
+def check(rc, ctx=None):
+    if rc < 0:
+        msg = lib.gacq_last_error(ctx)
+        raise GacqError(rc, msg.decode() if msg else "")
+    return rc

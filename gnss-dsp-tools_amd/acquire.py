@@ -1,0 +1,279 @@
+"""Host-side mirror of the reference's acquisition entry point.
+
+The reference defines, inline in every acquire-*.py,
+
+    search(x, prn, doppler_search, ms) -> (m_metric, m_code, m_doppler)      acquire-gps-l1.py:18-40
+
+and maps it over PRNs with multiprocessing.Pool (acquire-gps-l1.py:100-108).  Here the same call
+surface is kept (``make_search(name)`` returns a function with exactly that signature and return
+tuple) but every PRN / Doppler bin / block of the search runs on the GPU through libgacq.so.
+``search_all`` replaces the Pool.map: all items in one launch sequence, forward FFTs shared.
+
+No CPU fallback: constructing an Engine without a visible GPU raises.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _native as nat
+from . import signals as _signals
+
+PEAK_DTYPE = np.dtype([("metric", "<f8"), ("idx", "<i4"), ("d_index", "<i4")])
+
+
+def parse_list_ranges(s, sep='-'):
+    """'1,3,7-14' -> [1,3,7,...,14]   (option syntax of gnsstools/util.py:1-10)."""
+    out = []
+    for tok in s.split(','):
+        ends = tok.split(sep)
+        if len(ends) == 1:
+            out.append(int(ends[0]))
+        else:
+            out.extend(range(int(ends[0]), int(ends[1]) + 1))
+    return out
+
+
+def parse_list_floats(s):
+    """'-7000,7000,200' -> [-7000.0, 7000.0, 200.0]   (gnsstools/util.py:12-14)."""
+    return [float(v) for v in s.split(',')]
+
+
+def doppler_grid(doppler_search):
+    """The half-open grid the reference iterates: np.arange(min,max,incr) (acquire-gps-l1.py:26)."""
+    lo, hi, step = doppler_search
+    return np.ascontiguousarray(np.arange(lo, hi, step), dtype=np.float64)
+
+
+class AcqSignal:
+    """Code spectra of one signal for a fixed item list, resident on the device."""
+
+    def __init__(self, engine, sig, prns):
+        self.engine = engine
+        self.sig = sig
+        self.prns = list(prns)
+        L = nat.check(nat.lib.gacq_code_length(sig.code.encode()))
+        self.code_length = L
+        self.desc = nat.SigDesc(L, sig.n, int(sig.pad), int(sig.boc), int(sig.normalised), int(sig.fold), sig.fs)
+        arr = (ctypes.c_int * len(self.prns))(*self.prns)
+        h = ctypes.c_void_p()
+        nat.check(nat.lib.gacq_signal_create(engine._ctx, ctypes.byref(self.desc), sig.code.encode(), arr,
+                                             len(self.prns), ctypes.byref(h)), engine._ctx)
+        self._h = h
+        self._index = {p: i for i, p in enumerate(self.prns)}
+
+    def close(self):
+        if self._h:
+            nat.lib.gacq_signal_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def spectrum(self, prn):
+        out = np.empty(self.sig.nfft, dtype=np.complex64)
+        nat.check(nat.lib.gacq_signal_spectrum(self._h, self._index[prn], out.ctypes.data_as(nat.c_float_p)), self.engine._ctx)
+        return out
+
+
+class Engine:
+    """One acquisition context bound to one GPU (one process per GPU)."""
+
+    def __init__(self, device=0, engine=0, workspace_bytes=None):
+        h = ctypes.c_void_p()
+        nat.check(nat.lib.gacq_create(int(device), ctypes.byref(h)))
+        self._ctx = h
+        self.device = int(device)
+        self._signals = {}
+        if engine:
+            self.set_engine(engine)
+        if workspace_bytes:
+            nat.check(nat.lib.gacq_set_workspace_limit(self._ctx, int(workspace_bytes)), self._ctx)
+
+    # -- configuration -----------------------------------------------------------------------
+    def set_engine(self, engine):
+        """0 auto, 1 rocFFT pipeline, 2 LDS-resident FFT kernels."""
+        nat.check(nat.lib.gacq_set_engine(self._ctx, int(engine)), self._ctx)
+
+    def set_stream(self, stream_handle):
+        """Launch on the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream); 0/None = own stream."""
+        nat.check(nat.lib.gacq_set_stream(self._ctx, ctypes.c_void_p(stream_handle or None)), self._ctx)
+
+    def set_profiling(self, on):
+        nat.check(nat.lib.gacq_set_profiling(self._ctx, int(bool(on))), self._ctx)
+
+    def reset_stage_times(self):
+        nat.check(nat.lib.gacq_reset_stage_times(self._ctx), self._ctx)
+
+    def stage_times(self):
+        """{stage name: (total_ms, launches)} from HIP events on the launch stream."""
+        out = {}
+        for s in range(7):
+            ms, n = ctypes.c_double(), ctypes.c_long()
+            nat.check(nat.lib.gacq_get_stage_time(self._ctx, s, ctypes.byref(ms), ctypes.byref(n)), self._ctx)
+            out[nat.lib.gacq_stage_name(s).decode()] = (ms.value, n.value)
+        return out
+
+    def close(self):
+        for s in self._signals.values():
+            s.close()
+        self._signals.clear()
+        if self._ctx:
+            nat.lib.gacq_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- signals -----------------------------------------------------------------------------
+    def signal(self, name, prns):
+        sig = _signals.get(name) if isinstance(name, str) else name
+        key = (sig.name, tuple(prns))
+        if key not in self._signals:
+            self._signals[key] = AcqSignal(self, sig, prns)
+        return self._signals[key]
+
+    def _plan(self, name, items):
+        """Map reference 'items' (PRNs, or GLONASS channels) to (AcqSignal, item indices, per-item bias)."""
+        sig = _signals.get(name) if isinstance(name, str) else name
+        items = [int(i) for i in items]
+        if sig.bias_hz:
+            s = self.signal(sig, [0])                                  # one shared code (glonass/ca.py:27)
+            idx = np.zeros(len(items), dtype=np.int32)
+            bias = np.array([sig.bias_hz * c for c in items], dtype=np.float64)   # 562500*chan
+            return s, idx, bias
+        uniq = sorted(set(items))
+        s = self.signal(sig, uniq)
+        idx = np.array([s._index[p] for p in items], dtype=np.int32)
+        return s, idx, None
+
+    # -- the reference call surface ------------------------------------------------------------
+    def search_all(self, name, x, items, doppler_search, ms):
+        """[search(x, item, doppler_search, ms) for item in items] of acquire-<name>.py, one GPU pass."""
+        sig = _signals.get(name) if isinstance(name, str) else name
+        return self.search_blocks(sig, x, items, doppler_grid(doppler_search), sig.blocks(int(ms)))
+
+    def search(self, name, x, item, doppler_search, ms):
+        """search(x, prn, doppler_search, ms) -> (metric, code, doppler)   acquire-gps-l1.py:18-40."""
+        return self.search_all(name, x, [item], doppler_search, ms)[0]
+
+    def search_blocks(self, name, x, items, dopplers, blocks):
+        """Engine-level form: explicit Doppler values and block count B."""
+        sig = _signals.get(name) if isinstance(name, str) else name
+        s, idx, bias = self._plan(sig, items)
+        dopplers = np.ascontiguousarray(dopplers, dtype=np.float64)
+        blocks = max(int(blocks), 0)                    # range(negative) is empty in the reference
+        need = sig.samples_needed(blocks)
+        x = np.asarray(x)
+        if x.ndim != 1:
+            raise ValueError("x must be a 1-D complex array")
+        if len(x) < need:
+            # the reference fails here with numpy's broadcast ValueError (short last block * w)
+            raise ValueError("operands could not be broadcast together: search needs %d samples "
+                             "(%d block(s) of n=%d%s), x has %d" % (need, blocks, sig.n, ", padded" if sig.pad else "", len(x)))
+        xc = np.ascontiguousarray(x[:max(need, 1)], dtype=np.complex64)
+        res = (nat.Result * len(idx))()
+        nat.check(nat.lib.gacq_search(
+            s._h, xc.ctypes.data_as(nat.c_float_p), len(xc), idx.ctypes.data_as(nat.c_int_p), len(idx),
+            dopplers.ctypes.data_as(nat.c_double_p), len(dopplers),
+            bias.ctypes.data_as(nat.c_double_p) if bias is not None else None, blocks, res), self._ctx)
+        return [_as_tuple(r) for r in res]
+
+    def debug_row(self, name, x, item, doppler, blocks):
+        """Accumulated magnitude row q[0:N] of one (item, doppler) via the rocFFT pipeline."""
+        sig = _signals.get(name) if isinstance(name, str) else name
+        s, idx, bias = self._plan(sig, [item])
+        need = sig.samples_needed(blocks)
+        xc = np.ascontiguousarray(np.asarray(x)[:need], dtype=np.complex64)
+        if len(xc) < need:
+            raise ValueError("x too short: %d < %d" % (len(xc), need))
+        q = np.empty(sig.nfft, dtype=np.float32)
+        nat.check(nat.lib.gacq_debug_row(s._h, xc.ctypes.data_as(nat.c_float_p), len(xc), int(idx[0]), float(doppler),
+                                         float(bias[0]) if bias is not None else 0.0, int(blocks),
+                                         q.ctypes.data_as(nat.c_float_p)), self._ctx)
+        return q
+
+    # -- device-resident batched form (bench / sharded path) --------------------------------------
+    def search_batch_dev(self, name, x_dev, items, dopplers, blocks, out=None):
+        """x_dev: torch complex64 CUDA tensor [nepoch, nsamp]; returns a torch tensor [nepoch, nitems, 2]
+        of float64 whose 16-byte rows are gacq_peak records (view with PEAK_DTYPE on the host).
+        Asynchronous on the engine's stream."""
+        import torch
+        sig = _signals.get(name) if isinstance(name, str) else name
+        s, idx, bias = self._plan(sig, items)
+        dopplers = np.ascontiguousarray(dopplers, dtype=np.float64)
+        if not (x_dev.is_cuda and x_dev.dtype == torch.complex64 and x_dev.dim() == 2 and x_dev.is_contiguous()):
+            raise ValueError("x_dev must be a contiguous 2-D complex64 CUDA tensor")
+        nepoch, nsamp = x_dev.shape
+        if out is None:
+            out = torch.empty((nepoch, len(idx), 2), dtype=torch.float64, device=x_dev.device)
+        nat.check(nat.lib.gacq_search_batch_dev(
+            s._h, ctypes.c_void_p(x_dev.data_ptr()), nsamp, nepoch, idx.ctypes.data_as(nat.c_int_p), len(idx),
+            dopplers.ctypes.data_as(nat.c_double_p), len(dopplers),
+            bias.ctypes.data_as(nat.c_double_p) if bias is not None else None, int(blocks),
+            ctypes.c_void_p(out.data_ptr())), self._ctx)
+        return out
+
+    def finalize(self, name, items, peaks, dopplers, shard_d0=None):
+        """Host-side last step: peaks [nshard, nitems] (PEAK_DTYPE) -> list of (metric, code, doppler)."""
+        sig = _signals.get(name) if isinstance(name, str) else name
+        s, idx, _ = self._plan(sig, items)
+        peaks = np.ascontiguousarray(peaks).view(PEAK_DTYPE).reshape(-1, len(idx))
+        nshard = peaks.shape[0]
+        dopplers = np.ascontiguousarray(dopplers, dtype=np.float64)
+        d0 = np.ascontiguousarray(shard_d0 if shard_d0 is not None else np.zeros(nshard), dtype=np.int32)
+        res = (nat.Result * len(idx))()
+        nat.check(nat.lib.gacq_finalize(s._h, peaks.ctypes.data_as(ctypes.POINTER(nat.Peak)), nshard,
+                                        d0.ctypes.data_as(nat.c_int_p), len(idx),
+                                        dopplers.ctypes.data_as(nat.c_double_p), len(dopplers), res), self._ctx)
+        return [_as_tuple(r) for r in res]
+
+
+def _as_tuple(r):
+    if r.d_index < 0:
+        return 0, 0, 0                  # the reference's untouched initial values (acquire-gps-l1.py:25)
+    return np.float64(r.metric), float(r.code_chips), np.float64(r.doppler_hz)
+
+
+def format_result(name, item, result):
+    """The worker() output line of acquire-<name>.py (e.g. acquire-gps-l1.py:103)."""
+    sig = _signals.get(name) if isinstance(name, str) else name
+    metric, code, doppler = result
+    return sig.fmt % (item, doppler, metric, code)
+
+
+_default_engine = None
+
+
+def default_engine():
+    global _default_engine
+    if _default_engine is None:
+        _default_engine = Engine(0)
+    return _default_engine
+
+
+def make_search(name, engine=None):
+    """Return ``search(x, prn, doppler_search, ms)`` with the reference's signature and return tuple,
+    bound to acquire-<name>.py's hard-coded fs/n/variant."""
+    sig = _signals.get(name)
+
+    def search(x, prn, doppler_search, ms):
+        return (engine or default_engine()).search(sig, x, prn, doppler_search, ms)
+
+    search.__doc__ = "GPU search() of acquire-%s.py: (metric, code, doppler)" % sig.name
+    return search
+
+
+def search_north_star(prn, samples, fs, doppler_range, name="gps-l1", ms=1, engine=None):
+    """BASELINE.json's argument order: search(prn, samples, fs, doppler_range) -> (code_phase, doppler, metric).
+    `fs` must equal the signal's internal rate (the reference hard-codes it, acquire-gps-l1.py:19)."""
+    sig = _signals.get(name)
+    if float(fs) != sig.fs:
+        raise ValueError("%s search runs at fs=%.0f Hz (hard-coded in the reference), got %r" % (sig.name, sig.fs, fs))
+    metric, code, doppler = (engine or default_engine()).search(sig, samples, prn, doppler_range, ms)
+    return code, doppler, metric

@@ -1,0 +1,99 @@
+// Internal declarations shared by the engine translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/gacq.h"
+
+namespace gacq {
+
+constexpr int kNcoTableSize = 1024;        // gnsstools/nco.py:3
+constexpr int kBlock = 256;                // 4 wave64 per workgroup
+
+// Per-(epoch, item, doppler) reduction record written by the magnitude/peak stage.
+struct RowRec {
+  float peak;    // max_k q[k]
+  int idx;       // first k attaining it (np.argmax semantics)
+  double sum;    // sum_k q[k]  (for the max/mean metric)
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct FftPlan {
+  rocfft_plan plan = nullptr;
+  rocfft_execution_info info = nullptr;
+  void* work = nullptr;
+  size_t work_size = 0;
+};
+
+struct StageEvent { int stage; hipEvent_t a, b; };
+
+}  // namespace gacq
+
+struct gacq_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int engine = 0;
+  size_t ws_limit = (size_t)4 << 30;
+  std::map<std::pair<long, long>, gacq::FftPlan> plans;   // (N * 2 + inverse, batch)
+  gacq::DevBuf tab, xstage, X, Y, rows, freq, fset, items, out_peaks;
+  bool profiling = false;
+  double stage_ms[GACQ_NSTAGES] = {0};
+  long stage_n[GACQ_NSTAGES] = {0};
+  std::vector<gacq::StageEvent> pending;
+};
+
+struct gacq_sig {
+  gacq_ctx* ctx = nullptr;
+  gacq_sigdesc desc{};
+  int nprn = 0;
+  int N = 0;                 // FFT length: n or 2n
+  float2* spectra = nullptr; // [nprn][N] code spectra C_p = fft(replica), complex64
+};
+
+namespace gacq {
+
+int set_error(gacq_ctx* ctx, int code, const char* fmt, ...);
+int ensure(gacq_ctx* ctx, DevBuf& b, size_t bytes);
+int fft_exec(gacq_ctx* ctx, int N, long batch, bool inverse, void* data);
+void stage_begin(gacq_ctx* ctx, int stage);
+void stage_end(gacq_ctx* ctx);
+
+// LDS-resident FFT engine (gacq_ldsfft.hip): supported lengths and the two launches.
+bool lds_supported(int N);
+// X[row][k] = conj(FFT_N(x_window * nco))   rows = ((e*F + f)*D + d)*B + b
+int lds_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n, int N, const double* d_freq,
+                int FD, int B, const float2* tab, float2* X);
+// rows[(e*P + p)*D + d] = reduce_k sum_b | IFFT_N(C_p * X[e,f(p),d,b]) | / N
+int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const int* d_items, const int* d_fset,
+                  int nepoch, int nitems, int F, int D, int B, int N, RowRec* rows);
+
+#define GACQ_HIP(ctx, call)                                                                         \
+  do {                                                                                              \
+    hipError_t e_ = (call);                                                                         \
+    if (e_ != hipSuccess)                                                                           \
+      return gacq::set_error((ctx), GACQ_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                             __FILE__, __LINE__);                                                   \
+  } while (0)
+
+#define GACQ_FFT(ctx, call)                                                                         \
+  do {                                                                                              \
+    rocfft_status s_ = (call);                                                                      \
+    if (s_ != rocfft_status_success)                                                                \
+      return gacq::set_error((ctx), GACQ_ERR_ROCFFT, "%s failed: rocfft_status %d (%s:%d)", #call, (int)s_, \
+                             __FILE__, __LINE__);                                                   \
+  } while (0)
+
+}  // namespace gacq

@@ -1,0 +1,710 @@
+// MI355X (gfx950) acquisition engine: C ABI + the rocFFT pipeline (any FFT length).
+//
+// Pipeline per batch of epochs (kernels K1..K4 around rocFFT):
+//   K1 mix_nco_kernel      y[e,f,d,b,i] = x[e][b*n+i] * tab[floor(f_d*i*1024) & 1023]   acquire-gps-l1.py:28,30-31
+//   F1 rocFFT forward      batched, in place                                             acquire-gps-l1.py:32 (fft.fft)
+//   K2 conj_mul_kernel     Y[e,p,d,b,k] = C_p[k] * conj(X[e,f(p),d,b,k])                 acquire-gps-l1.py:32
+//   F2 rocFFT inverse      batched, in place, unnormalised (1/N folded into K3)          acquire-gps-l1.py:32 (fft.ifft)
+//   K3 mag_peak_kernel     q[k] = sum_b |r_b[k]|/N ; (max, first argmax, sum) per row    acquire-gps-l1.py:33-35
+//   K4 best_doppler_kernel strict-'>' scan over Doppler bins in order                    acquire-gps-l1.py:36-39
+// For power-of-two lengths that fit in LDS the K1+F1 and K2+F2+K3 groups are replaced by the two
+// fused LDS-resident FFT kernels in gacq_ldsfft.hip (engine 2).
+#include "gacq_common.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <mutex>
+
+using namespace gacq;
+
+namespace {
+std::string g_last_error;
+std::once_flag g_rocfft_once;
+const char* kStageNames[GACQ_NSTAGES] = {"mix_nco", "rocfft_forward", "conj_mul", "rocfft_inverse",
+                                         "mag_peak", "best_doppler", "lds_correlate"};
+}  // namespace
+
+namespace gacq {
+
+int set_error(gacq_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+int ensure(gacq_ctx* ctx, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return GACQ_OK;
+  if (b.p) {
+    GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GACQ_HIP(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  size_t want = bytes + bytes / 8;
+  if (hipMalloc(&b.p, want) != hipSuccess) {
+    (void)hipGetLastError();
+    want = bytes;
+    GACQ_HIP(ctx, hipMalloc(&b.p, want));
+  }
+  b.cap = want;
+  return GACQ_OK;
+}
+
+int fft_exec(gacq_ctx* ctx, int N, long batch, bool inverse, void* data) {
+  auto key = std::make_pair((long)N * 2 + (inverse ? 1 : 0), batch);
+  auto it = ctx->plans.find(key);
+  if (it == ctx->plans.end()) {
+    FftPlan p;
+    size_t len[1] = {(size_t)N};
+    GACQ_FFT(ctx, rocfft_plan_create(&p.plan, rocfft_placement_inplace,
+                                     inverse ? rocfft_transform_type_complex_inverse : rocfft_transform_type_complex_forward,
+                                     rocfft_precision_single, 1, len, (size_t)batch, nullptr));
+    GACQ_FFT(ctx, rocfft_execution_info_create(&p.info));
+    GACQ_FFT(ctx, rocfft_plan_get_work_buffer_size(p.plan, &p.work_size));
+    if (p.work_size) {
+      GACQ_HIP(ctx, hipMalloc(&p.work, p.work_size));
+      GACQ_FFT(ctx, rocfft_execution_info_set_work_buffer(p.info, p.work, p.work_size));
+    }
+    it = ctx->plans.emplace(key, p).first;
+  }
+  FftPlan& p = it->second;
+  GACQ_FFT(ctx, rocfft_execution_info_set_stream(p.info, ctx->stream));
+  void* bufs[1] = {data};
+  GACQ_FFT(ctx, rocfft_execute(p.plan, bufs, nullptr, p.info));
+  return GACQ_OK;
+}
+
+void stage_begin(gacq_ctx* ctx, int stage) {
+  if (!ctx->profiling) return;
+  StageEvent ev;
+  ev.stage = stage;
+  if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) return;
+  (void)hipEventRecord(ev.a, ctx->stream);
+  ctx->pending.push_back(ev);
+}
+
+void stage_end(gacq_ctx* ctx) {
+  if (!ctx->profiling || ctx->pending.empty()) return;
+  (void)hipEventRecord(ctx->pending.back().b, ctx->stream);
+}
+
+}  // namespace gacq
+
+// ------------------------------------------------------------------------------------------------
+// Kernels of the rocFFT pipeline.  All are pure streaming kernels (HBM-bound): 16 B per lane,
+// 256-thread workgroups, one flattened 1-D grid (row-major over rows x chunks).
+// ------------------------------------------------------------------------------------------------
+
+// K1: carrier wipe-off with the reference's 10-bit phase-quantised table NCO.
+// The table index is computed in fp64 exactly like numpy does: floor((0 + f*i) * 1024) mod 1024
+// (gnsstools/nco.py:6-9); one v_mul_f64 per sample is noise next to the HBM traffic.
+__global__ __launch_bounds__(kBlock) void mix_nco_kernel(const float2* __restrict__ x, size_t epoch_stride,
+                                                          float2* __restrict__ y, const double* __restrict__ freq,
+                                                          const float2* __restrict__ tab, int n, int span, int FD, int B,
+                                                          int chunks) {
+  __shared__ float2 s_tab[kNcoTableSize];
+  for (int i = threadIdx.x; i < kNcoTableSize; i += kBlock) s_tab[i] = tab[i];
+  __syncthreads();
+  const long blk = blockIdx.x;
+  const int chunk = (int)(blk % chunks);
+  const long row = blk / chunks;            // ((e*FD + fd)*B + b)
+  const int b = (int)(row % B);
+  const long t = row / B;
+  const int fd = (int)(t % FD);
+  const long e = t / FD;
+  const double f = freq[fd];
+  const float2* src = x + e * epoch_stride + (size_t)b * n;
+  float2* dst = y + row * (long)span;
+  // each thread: 8 samples as 4 x (2 complex = 16 B)
+  const int base = chunk * (kBlock * 8);
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int i0 = base + (j * kBlock + threadIdx.x) * 2;
+    if (i0 + 1 < span) {
+      const float4 s = *reinterpret_cast<const float4*>(src + i0);
+      const long k0 = (long)floor(__dmul_rn(__dmul_rn(f, (double)i0), 1024.0)) & (kNcoTableSize - 1);
+      const long k1 = (long)floor(__dmul_rn(__dmul_rn(f, (double)(i0 + 1)), 1024.0)) & (kNcoTableSize - 1);
+      const float2 w0 = s_tab[k0], w1 = s_tab[k1];
+      float4 o;
+      o.x = s.x * w0.x - s.y * w0.y;
+      o.y = s.x * w0.y + s.y * w0.x;
+      o.z = s.z * w1.x - s.w * w1.y;
+      o.w = s.z * w1.y + s.w * w1.x;
+      *reinterpret_cast<float4*>(dst + i0) = o;
+    } else if (i0 < span) {
+      const float2 s = src[i0];
+      const long k0 = (long)floor(__dmul_rn(__dmul_rn(f, (double)i0), 1024.0)) & (kNcoTableSize - 1);
+      const float2 w0 = s_tab[k0];
+      dst[i0] = make_float2(s.x * w0.x - s.y * w0.y, s.x * w0.y + s.y * w0.x);
+    }
+  }
+}
+
+// K2: Y = C_p * conj(X).  group = (e*P + p)*D + d, row_y = (group - g0)*B + b.
+__global__ __launch_bounds__(kBlock) void conj_mul_kernel(const float2* __restrict__ X, const float2* __restrict__ C,
+                                                           float2* __restrict__ Y, const int* __restrict__ items,
+                                                           const int* __restrict__ fset, long g0, int P, int F, int D,
+                                                           int B, int N, int chunks) {
+  const long blk = blockIdx.x;
+  const int chunk = (int)(blk % chunks);
+  const long ry = blk / chunks;
+  const int b = (int)(ry % B);
+  const long g = g0 + ry / B;
+  const int d = (int)(g % D);
+  const long ep = g / D;
+  const int p = (int)(ep % P);
+  const long e = ep / P;
+  const float2* xs = X + (((e * F + fset[p]) * D + d) * (long)B + b) * (long)N;
+  const float2* cs = C + (long)items[p] * N;
+  float2* ys = Y + ry * (long)N;
+  const int base = chunk * (kBlock * 8);
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int i0 = base + (j * kBlock + threadIdx.x) * 2;
+    if (i0 + 1 < N) {
+      const float4 xv = *reinterpret_cast<const float4*>(xs + i0);
+      const float4 cv = *reinterpret_cast<const float4*>(cs + i0);
+      float4 o;
+      o.x = cv.x * xv.x + cv.y * xv.y;
+      o.y = cv.y * xv.x - cv.x * xv.y;
+      o.z = cv.z * xv.z + cv.w * xv.w;
+      o.w = cv.w * xv.z - cv.z * xv.w;
+      *reinterpret_cast<float4*>(ys + i0) = o;
+    } else if (i0 < N) {
+      const float2 xv = xs[i0], cv = cs[i0];
+      ys[i0] = make_float2(cv.x * xv.x + cv.y * xv.y, cv.y * xv.x - cv.x * xv.y);
+    }
+  }
+}
+
+// Block-wide (peak, first index, sum) reduction shared by K3 and the LDS engine.
+__device__ __forceinline__ void block_reduce_peak(float& peak, int& idx, double& sum) {
+  __shared__ float s_peak[kBlock / 64];
+  __shared__ int s_idx[kBlock / 64];
+  __shared__ double s_sum[kBlock / 64];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float op = __shfl_down(peak, off);
+    const int oi = __shfl_down(idx, off);
+    const double os = __shfl_down(sum, off);
+    if (op > peak || (op == peak && oi < idx)) { peak = op; idx = oi; }
+    sum += os;
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s_peak[wave] = peak; s_idx[wave] = idx; s_sum[wave] = sum; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / 64; w++) {
+      if (s_peak[w] > peak || (s_peak[w] == peak && s_idx[w] < idx)) { peak = s_peak[w]; idx = s_idx[w]; }
+      sum += s_sum[w];
+    }
+  }
+}
+
+// K3: one workgroup per (e,p,d) group: q[k] = sum_b |Y[b][k]| / N, reduced to (max, argmax, sum).
+__global__ __launch_bounds__(kBlock) void mag_peak_kernel(const float2* __restrict__ Y, RowRec* __restrict__ rows,
+                                                           long g0, int B, int N, float inv_n, float* __restrict__ q_out) {
+  const long gl = blockIdx.x;
+  const float2* ys = Y + gl * (long)B * N;
+  float peak = -1.0f;
+  int idx = 0x7fffffff;
+  double sum = 0.0;
+  for (int k0 = threadIdx.x * 2; k0 < N; k0 += kBlock * 2) {
+    float q0 = 0.f, q1 = 0.f;
+    if (k0 + 1 < N) {
+      for (int b = 0; b < B; b++) {
+        const float4 v = *reinterpret_cast<const float4*>(ys + (long)b * N + k0);
+        q0 += sqrtf(v.x * v.x + v.y * v.y) * inv_n;
+        q1 += sqrtf(v.z * v.z + v.w * v.w) * inv_n;
+      }
+      if (q_out) { q_out[k0] = q0; q_out[k0 + 1] = q1; }
+      if (q0 > peak) { peak = q0; idx = k0; }
+      if (q1 > peak) { peak = q1; idx = k0 + 1; }
+      sum += (double)q0 + (double)q1;
+    } else {
+      for (int b = 0; b < B; b++) {
+        const float2 v = ys[(long)b * N + k0];
+        q0 += sqrtf(v.x * v.x + v.y * v.y) * inv_n;
+      }
+      if (q_out) q_out[k0] = q0;
+      if (q0 > peak) { peak = q0; idx = k0; }
+      sum += (double)q0;
+    }
+  }
+  block_reduce_peak(peak, idx, sum);
+  if (threadIdx.x == 0) {
+    RowRec r;
+    r.peak = peak;
+    r.idx = idx;
+    r.sum = sum;
+    rows[g0 + gl] = r;
+  }
+}
+
+// K4: per (e,p): scan Doppler bins in order, strict '>' against the running best that starts at 0.
+__global__ void best_doppler_kernel(const RowRec* __restrict__ rows, gacq_peak* __restrict__ out, long nep, int D, int N,
+                                    int normalised) {
+  const long ep = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ep >= nep) return;
+  double best = 0.0;
+  int bidx = -1, bd = -1;
+  for (int d = 0; d < D; d++) {
+    const RowRec r = rows[ep * D + d];
+    const double m = normalised ? (double)r.peak / (r.sum / (double)N) : (double)r.peak;
+    if (m > best) { best = m; bidx = r.idx; bd = d; }
+  }
+  gacq_peak o;
+  o.metric = best;
+  o.idx = bidx;
+  o.d_index = bd;
+  out[ep] = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int gacq_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+const char* gacq_last_error(gacq_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+const char* gacq_stage_name(int stage) { return (stage >= 0 && stage < GACQ_NSTAGES) ? kStageNames[stage] : nullptr; }
+
+int gacq_create(int device_id, gacq_ctx** out) {
+  if (!out) return set_error(nullptr, GACQ_ERR_BAD_ARG, "gacq_create: out is NULL");
+  *out = nullptr;
+  int ndev = gacq_device_count();
+  if (ndev <= 0) return set_error(nullptr, GACQ_ERR_NO_DEVICE, "gacq_create: no HIP device visible (this engine has no CPU fallback)");
+  if (device_id < 0 || device_id >= ndev) return set_error(nullptr, GACQ_ERR_BAD_ARG, "gacq_create: device %d out of range [0,%d)", device_id, ndev);
+  std::call_once(g_rocfft_once, [] { rocfft_setup(); });
+  gacq_ctx* ctx = new gacq_ctx();
+  ctx->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return set_error(nullptr, GACQ_ERR_HIP, "gacq_create: cannot create stream on device %d", device_id);
+  }
+  ctx->stream = ctx->own_stream;
+  // NCO phasor table: np.exp(2*pi*1j*k/1024) evaluated in fp64, rounded once to fp32 (gnsstools/nco.py:4)
+  std::vector<float2> tab(kNcoTableSize);
+  for (int k = 0; k < kNcoTableSize; k++) {
+    const double a = 2.0 * M_PI * (double)k * (1.0 / kNcoTableSize);
+    tab[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+  }
+  int rc = ensure(ctx, ctx->tab, sizeof(float2) * kNcoTableSize);
+  if (rc == GACQ_OK && hipMemcpy(ctx->tab.p, tab.data(), sizeof(float2) * kNcoTableSize, hipMemcpyHostToDevice) != hipSuccess)
+    rc = set_error(nullptr, GACQ_ERR_HIP, "gacq_create: table upload failed");
+  if (rc != GACQ_OK) { gacq_destroy(ctx); return rc; }
+  *out = ctx;
+  return GACQ_OK;
+}
+
+void gacq_destroy(gacq_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& kv : ctx->plans) {
+    if (kv.second.info) rocfft_execution_info_destroy(kv.second.info);
+    if (kv.second.plan) rocfft_plan_destroy(kv.second.plan);
+    if (kv.second.work) (void)hipFree(kv.second.work);
+  }
+  for (auto& ev : ctx->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+  DevBuf* bufs[] = {&ctx->tab, &ctx->xstage, &ctx->X, &ctx->Y, &ctx->rows, &ctx->freq, &ctx->fset, &ctx->items, &ctx->out_peaks};
+  for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+int gacq_set_stream(gacq_ctx* ctx, void* hip_stream) {
+  if (!ctx) return set_error(nullptr, GACQ_ERR_BAD_ARG, "gacq_set_stream: ctx is NULL");
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return GACQ_OK;
+}
+
+int gacq_set_engine(gacq_ctx* ctx, int engine) {
+  if (!ctx || engine < 0 || engine > 2) return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_set_engine: engine must be 0, 1 or 2");
+  ctx->engine = engine;
+  return GACQ_OK;
+}
+
+int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes) {
+  if (!ctx || bytes < ((size_t)1 << 20)) return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_set_workspace_limit: need >= 1 MiB");
+  ctx->ws_limit = bytes;
+  return GACQ_OK;
+}
+
+int gacq_set_profiling(gacq_ctx* ctx, int enabled) {
+  if (!ctx) return set_error(nullptr, GACQ_ERR_BAD_ARG, "gacq_set_profiling: ctx is NULL");
+  ctx->profiling = enabled != 0;
+  return GACQ_OK;
+}
+
+static int drain_events(gacq_ctx* ctx) {
+  if (ctx->pending.empty()) return GACQ_OK;
+  GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto& ev : ctx->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
+      ctx->stage_ms[ev.stage] += ms;
+      ctx->stage_n[ev.stage] += 1;
+    } else {
+      (void)hipGetLastError();
+    }
+    (void)hipEventDestroy(ev.a);
+    (void)hipEventDestroy(ev.b);
+  }
+  ctx->pending.clear();
+  return GACQ_OK;
+}
+
+int gacq_get_stage_time(gacq_ctx* ctx, int stage, double* total_ms, long* launches) {
+  if (!ctx || stage < 0 || stage >= GACQ_NSTAGES) return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_get_stage_time: bad stage");
+  int rc = drain_events(ctx);
+  if (rc != GACQ_OK) return rc;
+  if (total_ms) *total_ms = ctx->stage_ms[stage];
+  if (launches) *launches = ctx->stage_n[stage];
+  return GACQ_OK;
+}
+
+int gacq_reset_stage_times(gacq_ctx* ctx) {
+  if (!ctx) return set_error(nullptr, GACQ_ERR_BAD_ARG, "gacq_reset_stage_times: ctx is NULL");
+  int rc = drain_events(ctx);
+  for (int i = 0; i < GACQ_NSTAGES; i++) { ctx->stage_ms[i] = 0; ctx->stage_n[i] = 0; }
+  return rc;
+}
+
+// ---- signals ------------------------------------------------------------------------------------
+static int validate_desc(gacq_ctx* ctx, const gacq_sigdesc* d) {
+  if (!d) return set_error(ctx, GACQ_ERR_BAD_ARG, "signal descriptor is NULL");
+  if (d->code_length <= 0 || d->n <= 0 || !(d->fs > 0.0)) return set_error(ctx, GACQ_ERR_BAD_ARG, "signal descriptor: code_length, n and fs must be positive");
+  if ((long)d->n * 2 > (1L << 28)) return set_error(ctx, GACQ_ERR_BAD_ARG, "signal descriptor: n too large");
+  return GACQ_OK;
+}
+
+static int build_signal(gacq_ctx* ctx, const gacq_sigdesc* desc, const std::vector<float>& replicas, int nprn, gacq_sig** out) {
+  GACQ_HIP(ctx, hipSetDevice(ctx->device));
+  gacq_sig* s = new gacq_sig();
+  s->ctx = ctx;
+  s->desc = *desc;
+  s->nprn = nprn;
+  s->N = desc->pad ? 2 * desc->n : desc->n;
+  const size_t bytes = sizeof(float2) * (size_t)nprn * s->N;
+  if (hipMalloc((void**)&s->spectra, bytes) != hipSuccess) {
+    delete s;
+    return set_error(ctx, GACQ_ERR_HIP, "hipMalloc of %zu bytes for code spectra failed", bytes);
+  }
+  // complex replica, zero-extended to N when padded (acquire-beidou-b1i.py:24)
+  std::vector<float2> host((size_t)nprn * s->N, make_float2(0.f, 0.f));
+  for (int p = 0; p < nprn; p++)
+    for (int i = 0; i < desc->n; i++) host[(size_t)p * s->N + i].x = replicas[(size_t)p * desc->n + i];
+  int rc = GACQ_OK;
+  if (hipMemcpyAsync(s->spectra, host.data(), bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+    rc = set_error(ctx, GACQ_ERR_HIP, "replica upload failed");
+  if (rc == GACQ_OK) rc = fft_exec(ctx, s->N, nprn, false, s->spectra);     // c = fft.fft(c)   acquire-gps-l1.py:24
+  if (rc == GACQ_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "code spectrum FFT failed");
+  if (rc != GACQ_OK) { (void)hipFree(s->spectra); delete s; return rc; }
+  *out = s;
+  return GACQ_OK;
+}
+
+int gacq_signal_create(gacq_ctx* ctx, const gacq_sigdesc* desc, const char* code, const int* prns, int nprn, gacq_sig** out) {
+  if (!ctx || !out || !code || !prns || nprn <= 0) return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_signal_create: bad argument");
+  *out = nullptr;
+  int rc = validate_desc(ctx, desc);
+  if (rc != GACQ_OK) return rc;
+  const int L = gacq_code_length(code);
+  if (L < 0) return set_error(ctx, GACQ_ERR_UNKNOWN_CODE, "gacq_signal_create: unknown code '%s'", code);
+  if (L != desc->code_length) return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_signal_create: descriptor code_length %d != %d of '%s'", desc->code_length, L, code);
+  std::vector<float> rep((size_t)nprn * desc->n);
+  for (int p = 0; p < nprn; p++) {
+    rc = gacq_code_replica(code, prns[p], desc->n, desc->boc, rep.data() + (size_t)p * desc->n);
+    if (rc < 0) return set_error(ctx, rc, "gacq_signal_create: no PRN %d in '%s'", prns[p], code);
+  }
+  return build_signal(ctx, desc, rep, nprn, out);
+}
+
+int gacq_signal_create_chips(gacq_ctx* ctx, const gacq_sigdesc* desc, const uint8_t* chips, int nprn, gacq_sig** out) {
+  if (!ctx || !out || !chips || nprn <= 0) return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_signal_create_chips: bad argument");
+  *out = nullptr;
+  int rc = validate_desc(ctx, desc);
+  if (rc != GACQ_OK) return rc;
+  const int L = desc->code_length, n = desc->n;
+  const double incr = (double)L / (double)n;
+  std::vector<float> rep((size_t)nprn * n);
+  for (int p = 0; p < nprn; p++)
+    for (int i = 0; i < n; i++) {
+      const double pos = incr * (double)i;
+      float v = 1.0f - 2.0f * (float)(chips[(size_t)p * L + ((long)std::floor(pos) % L)] & 1);
+      if (desc->boc && ((long)std::floor(pos * 2.0) % 2) == 0) v = -v;
+      rep[(size_t)p * n + i] = v;
+    }
+  return build_signal(ctx, desc, rep, nprn, out);
+}
+
+void gacq_signal_destroy(gacq_sig* sig) {
+  if (!sig) return;
+  (void)hipSetDevice(sig->ctx->device);
+  (void)hipStreamSynchronize(sig->ctx->stream);
+  if (sig->spectra) (void)hipFree(sig->spectra);
+  delete sig;
+}
+
+int gacq_signal_fft_length(const gacq_sig* sig) { return sig ? sig->N : GACQ_ERR_BAD_ARG; }
+
+int gacq_signal_spectrum(gacq_sig* sig, int item, float* out_iq) {
+  if (!sig || !out_iq || item < 0 || item >= sig->nprn) return set_error(sig ? sig->ctx : nullptr, GACQ_ERR_BAD_ARG, "gacq_signal_spectrum: bad argument");
+  gacq_ctx* ctx = sig->ctx;
+  GACQ_HIP(ctx, hipSetDevice(ctx->device));
+  GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  GACQ_HIP(ctx, hipMemcpy(out_iq, sig->spectra + (size_t)item * sig->N, sizeof(float2) * sig->N, hipMemcpyDeviceToHost));
+  return GACQ_OK;
+}
+
+}  // extern "C"
+
+// ---- search ---------------------------------------------------------------------------------------
+namespace {
+
+struct Grid {
+  int F = 0;                      // distinct forward sets (carrier biases)
+  std::vector<int> fset;          // per item
+  std::vector<double> freq;       // [F][D] NCO frequency in cycles/sample
+};
+
+// f = -(bias + doppler)/fs, evaluated in fp64 in the reference's operation order
+// (acquire-gps-l1.py:28, acquire-glonass-l1.py:28)
+Grid make_grid(const gacq_sigdesc& d, int nitems, const double* dopplers, int nd, const double* bias) {
+  Grid g;
+  std::vector<double> biases;
+  g.fset.resize(nitems);
+  for (int p = 0; p < nitems; p++) {
+    const double b = bias ? bias[p] : 0.0;
+    int f = -1;
+    for (size_t k = 0; k < biases.size(); k++) if (biases[k] == b) { f = (int)k; break; }
+    if (f < 0) { f = (int)biases.size(); biases.push_back(b); }
+    g.fset[p] = f;
+  }
+  g.F = (int)biases.size();
+  g.freq.resize((size_t)g.F * nd);
+  for (int f = 0; f < g.F; f++)
+    for (int k = 0; k < nd; k++) {
+      const double dop = dopplers[k];
+      g.freq[(size_t)f * nd + k] = (biases[f] != 0.0) ? -(biases[f] + dop) / d.fs : -dop / d.fs;
+    }
+  return g;
+}
+
+int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, const int* items, int nitems,
+                  const double* dopplers, int nd, const double* bias, int blocks, gacq_peak* d_out, float* d_qrow) {
+  gacq_ctx* ctx = sig->ctx;
+  const gacq_sigdesc& ds = sig->desc;
+  const int n = ds.n, N = sig->N, B = blocks, D = nd, P = nitems;
+  hipStream_t st = ctx->stream;
+
+  Grid g = make_grid(ds, nitems, dopplers, nd, bias);
+  const int F = g.F;
+  int rc;
+  if ((rc = ensure(ctx, ctx->freq, sizeof(double) * g.freq.size())) != GACQ_OK) return rc;
+  if ((rc = ensure(ctx, ctx->fset, sizeof(int) * P)) != GACQ_OK) return rc;
+  if ((rc = ensure(ctx, ctx->items, sizeof(int) * P)) != GACQ_OK) return rc;
+  GACQ_HIP(ctx, hipMemcpyAsync(ctx->freq.p, g.freq.data(), sizeof(double) * g.freq.size(), hipMemcpyHostToDevice, st));
+  GACQ_HIP(ctx, hipMemcpyAsync(ctx->fset.p, g.fset.data(), sizeof(int) * P, hipMemcpyHostToDevice, st));
+  GACQ_HIP(ctx, hipMemcpyAsync(ctx->items.p, items, sizeof(int) * P, hipMemcpyHostToDevice, st));
+  // the host vectors above die with this frame: pageable H2D copies are staged before returning,
+  // but make that explicit rather than rely on it
+  GACQ_HIP(ctx, hipStreamSynchronize(st));
+
+  const bool use_lds = (ctx->engine == 2) || (ctx->engine == 0 && lds_supported(N) && !d_qrow);
+  if (ctx->engine == 2 && (!lds_supported(N) || d_qrow))
+    return set_error(ctx, GACQ_ERR_UNSUPPORTED, "engine 2 (LDS FFT) does not support N=%d%s", N, d_qrow ? " with row dump" : "");
+
+  // epochs per pass so that the forward-spectra buffer respects the workspace limit
+  const size_t x_epoch_bytes = sizeof(float2) * (size_t)F * D * B * N;
+  int Ec = (int)std::max<size_t>(1, std::min<size_t>((size_t)nepoch, ctx->ws_limit / std::max<size_t>(1, x_epoch_bytes)));
+  if ((rc = ensure(ctx, ctx->X, x_epoch_bytes * Ec)) != GACQ_OK) return rc;
+  if ((rc = ensure(ctx, ctx->rows, sizeof(RowRec) * (size_t)Ec * P * D)) != GACQ_OK) return rc;
+
+  const int chunksN = (N + kBlock * 8 - 1) / (kBlock * 8);
+  for (int e0 = 0; e0 < nepoch; e0 += Ec) {
+    const int ne = std::min(Ec, nepoch - e0);
+    const float2* xe = d_x + (size_t)e0 * nsamp;
+    float2* X = (float2*)ctx->X.p;
+    RowRec* rows = (RowRec*)ctx->rows.p;
+    const long rows_x = (long)ne * F * D * B;
+    if (use_lds) {
+      stage_begin(ctx, 0);
+      rc = lds_forward(ctx, xe, nsamp, ne, n, N, (const double*)ctx->freq.p, F * D, B, (const float2*)ctx->tab.p, X);
+      stage_end(ctx);
+      if (rc != GACQ_OK) return rc;
+      stage_begin(ctx, 6);
+      rc = lds_correlate(ctx, X, sig->spectra, (const int*)ctx->items.p, (const int*)ctx->fset.p, ne, P, F, D, B, N, rows);
+      stage_end(ctx);
+      if (rc != GACQ_OK) return rc;
+    } else {
+      stage_begin(ctx, 0);
+      hipLaunchKernelGGL(mix_nco_kernel, dim3((unsigned)(rows_x * chunksN)), dim3(kBlock), 0, st, xe, nsamp, X,
+                         (const double*)ctx->freq.p, (const float2*)ctx->tab.p, n, N, F * D, B, chunksN);
+      stage_end(ctx);
+      GACQ_HIP(ctx, hipGetLastError());
+      stage_begin(ctx, 1);
+      rc = fft_exec(ctx, N, rows_x, false, X);
+      stage_end(ctx);
+      if (rc != GACQ_OK) return rc;
+      // correlation workspace: chunks of whole (e,p,d) groups, B rows each
+      const long groups = (long)ne * P * D;
+      const size_t group_bytes = sizeof(float2) * (size_t)B * N;
+      long gc = (long)std::max<size_t>(1, std::min<size_t>((size_t)groups, ctx->ws_limit / group_bytes));
+      if ((rc = ensure(ctx, ctx->Y, group_bytes * gc)) != GACQ_OK) return rc;
+      float2* Y = (float2*)ctx->Y.p;
+      for (long g0 = 0; g0 < groups; g0 += gc) {
+        const long ng = std::min(gc, groups - g0);
+        stage_begin(ctx, 2);
+        hipLaunchKernelGGL(conj_mul_kernel, dim3((unsigned)(ng * B * chunksN)), dim3(kBlock), 0, st, X, sig->spectra, Y,
+                           (const int*)ctx->items.p, (const int*)ctx->fset.p, g0, P, F, D, B, N, chunksN);
+        stage_end(ctx);
+        GACQ_HIP(ctx, hipGetLastError());
+        stage_begin(ctx, 3);
+        rc = fft_exec(ctx, N, ng * B, true, Y);
+        stage_end(ctx);
+        if (rc != GACQ_OK) return rc;
+        stage_begin(ctx, 4);
+        hipLaunchKernelGGL(mag_peak_kernel, dim3((unsigned)ng), dim3(kBlock), 0, st, Y, rows, g0, B, N, 1.0f / (float)N, d_qrow);
+        stage_end(ctx);
+        GACQ_HIP(ctx, hipGetLastError());
+      }
+    }
+    const long nep = (long)ne * P;
+    stage_begin(ctx, 5);
+    hipLaunchKernelGGL(best_doppler_kernel, dim3((unsigned)((nep + 127) / 128)), dim3(128), 0, st, rows,
+                       d_out + (size_t)e0 * P, nep, D, N, ds.metric_mode);
+    stage_end(ctx);
+    GACQ_HIP(ctx, hipGetLastError());
+  }
+  return GACQ_OK;
+}
+
+int check_search_args(gacq_sig* sig, const void* x, size_t nsamp, int nepoch, const int* items, int nitems,
+                      const double* dopplers, int nd, int blocks, const void* out) {
+  gacq_ctx* ctx = sig ? sig->ctx : nullptr;
+  if (!sig || !x || !items || !out || nitems <= 0 || nepoch <= 0 || nd < 0 || blocks < 0 || (nd > 0 && !dopplers))
+    return set_error(ctx, GACQ_ERR_BAD_ARG, "search: bad argument");
+  for (int p = 0; p < nitems; p++)
+    if (items[p] < 0 || items[p] >= sig->nprn) return set_error(ctx, GACQ_ERR_BAD_PRN, "search: item index %d out of range [0,%d)", items[p], sig->nprn);
+  const size_t need = (size_t)(blocks + (sig->desc.pad ? 1 : 0)) * sig->desc.n;
+  if (blocks > 0 && nsamp < need)
+    return set_error(ctx, GACQ_ERR_SHORT_INPUT, "search: %zu samples given, %zu needed for %d block(s) of n=%d%s", nsamp, need, blocks,
+                     sig->desc.n, sig->desc.pad ? " (padded: windows span 2n)" : "");
+  return GACQ_OK;
+}
+
+__global__ void zero_peaks_kernel(gacq_peak* out, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { out[i].metric = 0.0; out[i].idx = -1; out[i].d_index = -1; }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gacq_search_batch_dev(gacq_sig* sig, const void* d_x, size_t nsamp, int nepoch, const int* items, int nitems,
+                          const double* dopplers, int nd, const double* item_bias_hz, int blocks, void* d_out) {
+  int rc = check_search_args(sig, d_x, nsamp, nepoch, items, nitems, dopplers, nd, blocks, d_out);
+  if (rc != GACQ_OK) return rc;
+  gacq_ctx* ctx = sig->ctx;
+  GACQ_HIP(ctx, hipSetDevice(ctx->device));
+  if (nd == 0 || blocks == 0) {
+    // empty Doppler grid -> the reference returns its initial (0,0,0) (acquire-gps-l1.py:25,40);
+    // zero blocks -> q == 0 everywhere, nothing beats metric 0 either (raw) / NaN never wins (normalised)
+    const long n = (long)nepoch * nitems;
+    hipLaunchKernelGGL(zero_peaks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (gacq_peak*)d_out, n);
+    GACQ_HIP(ctx, hipGetLastError());
+    return GACQ_OK;
+  }
+  return launch_search(sig, (const float2*)d_x, nsamp, nepoch, items, nitems, dopplers, nd, item_bias_hz, blocks,
+                       (gacq_peak*)d_out, nullptr);
+}
+
+int gacq_finalize(const gacq_sig* sig, const gacq_peak* peaks, int nshard, const int* shard_d0, int nitems,
+                  const double* dopplers, int nd, gacq_result* out) {
+  if (!sig || !peaks || !out || nshard <= 0 || nitems <= 0 || (nd > 0 && !dopplers))
+    return set_error(sig ? sig->ctx : nullptr, GACQ_ERR_BAD_ARG, "gacq_finalize: bad argument");
+  const gacq_sigdesc& d = sig->desc;
+  for (int p = 0; p < nitems; p++) {
+    double best = 0.0;
+    int bidx = -1, bd = -1;
+    for (int s = 0; s < nshard; s++) {               // shards in global Doppler order, strict '>'
+      const gacq_peak& k = peaks[(size_t)s * nitems + p];
+      if (k.d_index >= 0 && k.metric > best) { best = k.metric; bidx = k.idx; bd = k.d_index + (shard_d0 ? shard_d0[s] : 0); }
+    }
+    gacq_result r;
+    r.idx = bidx;
+    r.d_index = bd;
+    if (bd < 0 || bd >= nd) {
+      r.metric = 0.0; r.code_chips = 0.0; r.doppler_hz = 0.0; r.idx = -1; r.d_index = -1;
+    } else {
+      r.metric = best;
+      r.code_chips = (double)d.code_length * ((double)bidx / (double)d.n);      // acquire-gps-l1.py:38
+      if (d.fold_code) r.code_chips = std::fmod(r.code_chips, (double)d.code_length);   // acquire-beidou-b1i.py:39
+      r.doppler_hz = dopplers[bd];
+    }
+    out[p] = r;
+  }
+  return GACQ_OK;
+}
+
+int gacq_search(gacq_sig* sig, const float* x_iq, size_t nsamp, const int* items, int nitems, const double* dopplers,
+                int nd, const double* item_bias_hz, int blocks, gacq_result* out) {
+  int rc = check_search_args(sig, x_iq, nsamp, 1, items, nitems, dopplers, nd, blocks, out);
+  if (rc != GACQ_OK) return rc;
+  gacq_ctx* ctx = sig->ctx;
+  GACQ_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t need = (size_t)(blocks + (sig->desc.pad ? 1 : 0)) * sig->desc.n;
+  const size_t take = std::max<size_t>(need, 1);
+  if ((rc = ensure(ctx, ctx->xstage, sizeof(float2) * take)) != GACQ_OK) return rc;
+  if ((rc = ensure(ctx, ctx->out_peaks, sizeof(gacq_peak) * nitems)) != GACQ_OK) return rc;
+  if (need) GACQ_HIP(ctx, hipMemcpyAsync(ctx->xstage.p, x_iq, sizeof(float2) * need, hipMemcpyHostToDevice, ctx->stream));
+  rc = gacq_search_batch_dev(sig, ctx->xstage.p, take, 1, items, nitems, dopplers, nd, item_bias_hz, blocks, ctx->out_peaks.p);
+  if (rc != GACQ_OK) return rc;
+  std::vector<gacq_peak> peaks(nitems);
+  GACQ_HIP(ctx, hipMemcpyAsync(peaks.data(), ctx->out_peaks.p, sizeof(gacq_peak) * nitems, hipMemcpyDeviceToHost, ctx->stream));
+  GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return gacq_finalize(sig, peaks.data(), 1, nullptr, nitems, dopplers, nd, out);
+}
+
+int gacq_debug_row(gacq_sig* sig, const float* x_iq, size_t nsamp, int item, double doppler, double bias_hz, int blocks,
+                   float* q_out) {
+  gacq_peak dummy_out;
+  int rc = check_search_args(sig, x_iq, nsamp, 1, &item, 1, &doppler, 1, blocks, &dummy_out);
+  if (rc != GACQ_OK) return rc;
+  if (!q_out || blocks <= 0) return set_error(sig->ctx, GACQ_ERR_BAD_ARG, "gacq_debug_row: bad argument");
+  gacq_ctx* ctx = sig->ctx;
+  GACQ_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t need = (size_t)(blocks + (sig->desc.pad ? 1 : 0)) * sig->desc.n;
+  if ((rc = ensure(ctx, ctx->xstage, sizeof(float2) * need)) != GACQ_OK) return rc;
+  if ((rc = ensure(ctx, ctx->out_peaks, sizeof(gacq_peak))) != GACQ_OK) return rc;
+  float* d_q = nullptr;
+  GACQ_HIP(ctx, hipMalloc((void**)&d_q, sizeof(float) * sig->N));
+  GACQ_HIP(ctx, hipMemcpyAsync(ctx->xstage.p, x_iq, sizeof(float2) * need, hipMemcpyHostToDevice, ctx->stream));
+  const int saved = ctx->engine;
+  ctx->engine = 1;
+  rc = launch_search(sig, (const float2*)ctx->xstage.p, need, 1, &item, 1, &doppler, 1, bias_hz != 0.0 ? &bias_hz : nullptr, blocks,
+                     (gacq_peak*)ctx->out_peaks.p, d_q);
+  ctx->engine = saved;
+  if (rc == GACQ_OK && hipMemcpyAsync(q_out, d_q, sizeof(float) * sig->N, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+    rc = set_error(ctx, GACQ_ERR_HIP, "gacq_debug_row: D2H failed");
+  if (rc == GACQ_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "gacq_debug_row: sync failed");
+  (void)hipFree(d_q);
+  return rc;
+}
+
+}  // extern "C"

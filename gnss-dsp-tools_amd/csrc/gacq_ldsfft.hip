@@ -1,0 +1,279 @@
+// LDS-resident FFT engine for gfx950: the whole length-N transform of one correlation row lives in
+// one workgroup's registers + LDS, so the stage boundaries of the rocFFT pipeline (mix -> FFT,
+// conj-mul -> IFFT -> |.| -> reduce) never touch HBM.
+//
+//   lds_forward_kernel    x window --(table NCO mix)--> FFT_N --> conj --> X[row]       (K1+F1 fused)
+//   lds_correlate_kernel  for p in PRN chunk: q = sum_b | IFFT_N(C_p * X[e,f,d,b]) |/N ; (max, argmax, sum)
+//                                                                                        (K2+F2+K3 fused)
+//
+// Decomposition (N = 4096 = 16*16*16, one wave64-friendly 256-thread workgroup, 16 points per lane):
+//   n = n0 + 16 n1 + 256 n2,  k = k0 + 16 k1 + 256 k2
+//   pass 1: lane (n0,n1) holds n2=0..15 -> DFT16 over n2 -> k0 ; twiddle W_N^{(n0+16 n1) k0}
+//   pass 2: lane (n0,k0) holds n1=0..15 -> DFT16 over n1 -> k1 ; twiddle W_256^{n0 k1}
+//   pass 3: lane (k0,k1) holds n0=0..15 -> DFT16 over n0 -> k2
+// Global loads/stores are lane-contiguous in every pass-1 load and pass-3 store (index = lane + 256*j);
+// the two LDS transposes are bank-conflict free: exchange 1 is lane-contiguous on both sides, exchange 2
+// writes with row pitch 257 (odd) so that the 16 lanes of a ds_write_b64 group hit 16 distinct bank pairs.
+#include "gacq_common.h"
+
+#include <cmath>
+
+using namespace gacq;
+
+namespace {
+
+constexpr int kR = 16;                 // points per lane
+constexpr int kLdsN = 4096;            // supported length (this round)
+constexpr int kPitch = 257;            // exchange-2 row pitch in complex elements
+constexpr int kLdsElems = 16 * kPitch; // 4112 complex = 32.9 KB -> 4 workgroups per CU
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// multiply by -i (forward) or +i (inverse)
+template <bool INV> __device__ __forceinline__ float2 rot90(float2 a) { return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x); }
+
+template <bool INV> __device__ __forceinline__ void dft4(float2& a, float2& b, float2& c, float2& d) {
+  const float2 s0 = cadd(a, c), d0 = csub(a, c), s1 = cadd(b, d), d1 = rot90<INV>(csub(b, d));
+  a = cadd(s0, s1);
+  c = csub(s0, s1);
+  b = cadd(d0, d1);
+  d = csub(d0, d1);
+}
+
+// multiply by W16^m (forward: exp(-2 pi i m/16); inverse: conjugate), m compile-time
+template <bool INV, int M> __device__ __forceinline__ float2 tw16(float2 a) {
+  constexpr float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
+  constexpr int m = M & 15;
+  if (m == 0) return a;
+  float wr, wi;   // forward twiddle = wr - i*wi
+  if (m == 1) { wr = c1; wi = s1; }
+  else if (m == 2) { wr = h; wi = h; }
+  else if (m == 3) { wr = s1; wi = c1; }
+  else if (m == 4) { return rot90<INV>(a); }
+  else if (m == 6) { wr = -h; wi = h; }
+  else if (m == 9) { wr = -c1; wi = -s1; }
+  else { wr = 0.f; wi = 0.f; }
+  const float im = INV ? wi : -wi;
+  return make_float2(a.x * wr - a.y * im, a.x * im + a.y * wr);
+}
+
+// In-place 16-point DFT. Input v[n], n = 0..15; output X[k] is left in register v[4*(k&3) + (k>>2)]
+// (base-4 digit reversal) -- callers index outputs through rev16().
+__device__ __forceinline__ constexpr int rev16(int k) { return 4 * (k & 3) + (k >> 2); }
+
+template <bool INV> __device__ __forceinline__ void dft16(float2 (&v)[kR]) {
+#pragma unroll
+  for (int n0 = 0; n0 < 4; n0++) dft4<INV>(v[n0], v[n0 + 4], v[n0 + 8], v[n0 + 12]);   // -> A[n0][k0] at v[n0+4k0]
+  v[5] = tw16<INV, 1>(v[5]);   v[9] = tw16<INV, 2>(v[9]);   v[13] = tw16<INV, 3>(v[13]);
+  v[6] = tw16<INV, 2>(v[6]);   v[10] = tw16<INV, 4>(v[10]); v[14] = tw16<INV, 6>(v[14]);
+  v[7] = tw16<INV, 3>(v[7]);   v[11] = tw16<INV, 6>(v[11]); v[15] = tw16<INV, 9>(v[15]);
+#pragma unroll
+  for (int k0 = 0; k0 < 4; k0++) dft4<INV>(v[4 * k0], v[4 * k0 + 1], v[4 * k0 + 2], v[4 * k0 + 3]);   // -> X[k0+4k1] at v[4k0+k1]
+}
+
+// v[rev16(k)] *= w^k for k = 1..15, powers built with multiplication depth <= 4 from the table value.
+__device__ __forceinline__ void apply_powers(float2 (&v)[kR], float2 w1) {
+  const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
+  const float2 w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3), w8 = cmul(w4, w4);
+  const float2 w9 = cmul(w8, w1), w10 = cmul(w5, w5), w11 = cmul(w8, w3), w12 = cmul(w6, w6);
+  const float2 w13 = cmul(w8, w5), w14 = cmul(w7, w7), w15 = cmul(w8, w7);
+  v[rev16(1)] = cmul(v[rev16(1)], w1);    v[rev16(2)] = cmul(v[rev16(2)], w2);    v[rev16(3)] = cmul(v[rev16(3)], w3);
+  v[rev16(4)] = cmul(v[rev16(4)], w4);    v[rev16(5)] = cmul(v[rev16(5)], w5);    v[rev16(6)] = cmul(v[rev16(6)], w6);
+  v[rev16(7)] = cmul(v[rev16(7)], w7);    v[rev16(8)] = cmul(v[rev16(8)], w8);    v[rev16(9)] = cmul(v[rev16(9)], w9);
+  v[rev16(10)] = cmul(v[rev16(10)], w10); v[rev16(11)] = cmul(v[rev16(11)], w11); v[rev16(12)] = cmul(v[rev16(12)], w12);
+  v[rev16(13)] = cmul(v[rev16(13)], w13); v[rev16(14)] = cmul(v[rev16(14)], w14); v[rev16(15)] = cmul(v[rev16(15)], w15);
+}
+
+// Length-4096 transform of the 16 values per lane. In: v[j] = x[t + 256 j]; out: v[rev16(k2)] = X[t + 256 k2].
+// wa = W_4096^t, wb = W_256^(t & 15) (forward values; conjugated here when INV).
+template <bool INV> __device__ __forceinline__ void fft4096(float2 (&v)[kR], float2* lds, float2 wa, float2 wb) {
+  const int t = threadIdx.x;
+  if (INV) { wa.y = -wa.y; wb.y = -wb.y; }
+  dft16<INV>(v);
+  apply_powers(v, wa);
+  {  // exchange 1: (n0,n1;k0) -> (n0,k0;n1)
+    const int wbase = (t & 15) + 256 * (t >> 4);
+#pragma unroll
+    for (int k = 0; k < kR; k++) lds[wbase + 16 * k] = v[rev16(k)];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kR; j++) v[j] = lds[t + 256 * j];
+  }
+  dft16<INV>(v);
+  apply_powers(v, wb);
+  __syncthreads();   // all exchange-1 reads done before the buffer is reused
+  {  // exchange 2: (n0,k0;k1) -> (k0,k1;n0)
+    const int wbase = (t >> 4) + kPitch * (t & 15);
+#pragma unroll
+    for (int k = 0; k < kR; k++) lds[wbase + 16 * k] = v[rev16(k)];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kR; j++) v[j] = lds[t + kPitch * j];
+  }
+  dft16<INV>(v);
+}
+
+// ---- forward: one workgroup per (e, f, d, b) row -------------------------------------------------
+__global__ __launch_bounds__(kBlock) void lds_forward_kernel(const float2* __restrict__ x, size_t epoch_stride,
+                                                              float2* __restrict__ X, const double* __restrict__ freq,
+                                                              const float2* __restrict__ nco_tab,
+                                                              const float2* __restrict__ tw, int n, int FD, int B) {
+  __shared__ float2 lds[kLdsElems];
+  const int t = threadIdx.x;
+  const long row = blockIdx.x;            // ((e*FD + fd)*B + b)
+  const int b = (int)(row % B);
+  const long r2 = row / B;
+  const int fd = (int)(r2 % FD);
+  const long e = r2 / FD;
+  const double f = freq[fd];
+  const float2* src = x + e * epoch_stride + (size_t)b * n;
+  float2 v[kR];
+#pragma unroll
+  for (int j = 0; j < kR; j++) {
+    const int i = t + 256 * j;
+    const float2 s = src[i];
+    // table NCO, index in fp64 exactly as numpy: floor((0 + f*i)*1024) mod 1024   (gnsstools/nco.py:6-9)
+    const long k = (long)floor(__dmul_rn(__dmul_rn(f, (double)i), 1024.0)) & (kNcoTableSize - 1);
+    v[j] = cmul(s, nco_tab[k]);
+  }
+  fft4096<false>(v, lds, tw[t], tw[16 * (t & 15)]);
+  float2* dst = X + row * (long)kLdsN;
+#pragma unroll
+  for (int k = 0; k < kR; k++) {
+    const float2 o = v[rev16(k)];
+    dst[t + 256 * k] = make_float2(o.x, -o.y);       // store conj(FFT): np.conj(fft.fft(b))  acquire-gps-l1.py:32
+  }
+}
+
+// ---- correlate: workgroup = (epoch, doppler, chunk of items); epochs pinned to XCDs ---------------
+__global__ __launch_bounds__(kBlock) void lds_correlate_kernel(const float2* __restrict__ X, const float2* __restrict__ C,
+                                                                const int* __restrict__ items, const int* __restrict__ fset,
+                                                                const float2* __restrict__ tw, RowRec* __restrict__ rows,
+                                                                int E, int P, int F, int D, int B, int pch, int nchunk) {
+  __shared__ float2 lds[kLdsElems];
+  __shared__ float s_peak[kBlock / 64];
+  __shared__ int s_idx[kBlock / 64];
+  __shared__ double s_sum[kBlock / 64];
+  const int t = threadIdx.x;
+  // XCD-aware placement: workgroup b runs on XCD b%8 (MI355X_MICROARCH.md, workgroup dispatch), so give
+  // every epoch to one XCD: its forward spectra X[e] (D*B*32 KB) are then re-read by the P items from
+  // that XCD's own L2.
+  const int xcd = blockIdx.x & 7;
+  const long j = blockIdx.x >> 3;
+  const long per_epoch = (long)D * nchunk;
+  const long e = (j / per_epoch) * 8 + xcd;
+  if (e >= E) return;
+  const int rem = (int)(j % per_epoch);
+  const int d = rem / nchunk;
+  const int p0 = (rem % nchunk) * pch;
+  const int p1 = min(P, p0 + pch);
+  const float2 wa = tw[t], wb = tw[16 * (t & 15)];
+  const float inv_n = 1.0f / (float)kLdsN;
+  for (int p = p0; p < p1; p++) {
+    const float2* cs = C + (long)items[p] * kLdsN;
+    const float2* xs = X + (((e * F + fset[p]) * D + d) * (long)B) * kLdsN;
+    float q[kR];
+#pragma unroll
+    for (int k = 0; k < kR; k++) q[k] = 0.f;
+    for (int b = 0; b < B; b++) {
+      float2 v[kR];
+#pragma unroll
+      for (int jj = 0; jj < kR; jj++) v[jj] = cmul(cs[t + 256 * jj], xs[(long)b * kLdsN + t + 256 * jj]);
+      if (b > 0 || p > p0) __syncthreads();   // previous transform's exchange-2 reads are complete
+      fft4096<true>(v, lds, wa, wb);
+#pragma unroll
+      for (int k = 0; k < kR; k++) {
+        const float2 r = v[rev16(k)];
+        q[k] += sqrtf(r.x * r.x + r.y * r.y) * inv_n;     // np.absolute(ifft(...)), 1/N of ifft folded in
+      }
+    }
+    // (max, first argmax, sum) over the 4096 lags; lane holds lags t + 256 k
+    float peak = q[0];
+    int idx = t;
+    double sum = (double)q[0];
+#pragma unroll
+    for (int k = 1; k < kR; k++) {
+      if (q[k] > peak) { peak = q[k]; idx = t + 256 * k; }
+      sum += (double)q[k];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float op = __shfl_down(peak, off);
+      const int oi = __shfl_down(idx, off);
+      const double os = __shfl_down(sum, off);
+      if (op > peak || (op == peak && oi < idx)) { peak = op; idx = oi; }
+      sum += os;
+    }
+    if ((t & 63) == 0) { s_peak[t >> 6] = peak; s_idx[t >> 6] = idx; s_sum[t >> 6] = sum; }
+    __syncthreads();
+    if (t == 0) {
+      for (int w = 1; w < kBlock / 64; w++) {
+        if (s_peak[w] > peak || (s_peak[w] == peak && s_idx[w] < idx)) { peak = s_peak[w]; idx = s_idx[w]; }
+        sum += s_sum[w];
+      }
+      RowRec r;
+      r.peak = peak;
+      r.idx = idx;
+      r.sum = sum;
+      rows[(e * P + p) * (long)D + d] = r;
+    }
+  }
+}
+
+DevBuf g_tw[16];   // per-device W_4096 table
+
+int twiddle_table(gacq_ctx* ctx, const float2** out) {
+  DevBuf& b = g_tw[ctx->device & 15];
+  if (!b.p) {
+    std::vector<float2> h(kLdsN);
+    for (int k = 0; k < kLdsN; k++) {
+      const double a = -2.0 * M_PI * (double)k / (double)kLdsN;
+      h[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    GACQ_HIP(ctx, hipMalloc(&b.p, sizeof(float2) * kLdsN));
+    b.cap = sizeof(float2) * kLdsN;
+    GACQ_HIP(ctx, hipMemcpy(b.p, h.data(), b.cap, hipMemcpyHostToDevice));
+  }
+  *out = (const float2*)b.p;
+  return GACQ_OK;
+}
+
+}  // namespace
+
+namespace gacq {
+
+bool lds_supported(int N) { return N == kLdsN; }
+
+int lds_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n, int N, const double* d_freq, int FD,
+                int B, const float2* tab, float2* X) {
+  if (!lds_supported(N)) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "LDS FFT engine: N=%d not supported", N);
+  const float2* tw;
+  int rc = twiddle_table(ctx, &tw);
+  if (rc != GACQ_OK) return rc;
+  const long rows = (long)nepoch * FD * B;
+  hipLaunchKernelGGL(lds_forward_kernel, dim3((unsigned)rows), dim3(kBlock), 0, ctx->stream, x, nsamp, X, d_freq, tab, tw, n, FD, B);
+  GACQ_HIP(ctx, hipGetLastError());
+  return GACQ_OK;
+}
+
+int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const int* d_items, const int* d_fset, int nepoch,
+                  int nitems, int F, int D, int B, int N, RowRec* rows) {
+  if (!lds_supported(N)) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "LDS FFT engine: N=%d not supported", N);
+  const float2* tw;
+  int rc = twiddle_table(ctx, &tw);
+  if (rc != GACQ_OK) return rc;
+  // items per workgroup: keep >= ~2048 workgroups in flight (256 CUs x 4 resident x 2), at most 8 per group
+  const long rows_total = (long)nepoch * nitems * D;
+  int pch = (int)std::max<long>(1, std::min<long>(8, rows_total / 2048));
+  pch = std::min(pch, nitems);
+  const int nchunk = (nitems + pch - 1) / pch;
+  const long ex = (nepoch + 7) / 8;
+  const long grid = 8 * ex * D * nchunk;
+  hipLaunchKernelGGL(lds_correlate_kernel, dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, X, spectra, d_items, d_fset, tw,
+                     rows, nepoch, nitems, F, D, B, pch, nchunk);
+  GACQ_HIP(ctx, hipGetLastError());
+  return GACQ_OK;
+}
+
+}  // namespace gacq

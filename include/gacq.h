@@ -1,0 +1,151 @@
+/* gacq.h -- C ABI of the MI355X-native GNSS acquisition engine (libgacq.so).
+ *
+ * This is the drop-in boundary for ONE hot path of pmonta/GNSS-DSP-tools: the FFT-based parallel
+ * code-phase search that every acquire-*.py defines inline as
+ *     search(x, prn, doppler_search, ms) -> (metric, code, doppler)      acquire-gps-l1.py:18-40
+ * The reference has no FFI of its own (pure Python); the entry points below are what a ctypes
+ * binding for that function needs, and gnss-dsp-tools_amd/acquire.py is that binding
+ * (INTEGRATION.md shows the stub a maintainer would drop into acquire-gps-l1.py).
+ *
+ * Conventions: plain pointers and sizes only; every function returns GACQ_OK (0) or a negative
+ * GACQ_ERR_* code and never throws across the ABI; gacq_last_error() gives the message.
+ * Host buffers are caller-owned; device buffers passed to *_dev entry points are caller-owned
+ * device pointers (e.g. torch tensors' data_ptr()); everything else on the device is library-owned.
+ * A gacq_ctx is bound to one HIP device and is single-threaded (one process per GPU).
+ */
+#ifndef GACQ_H
+#define GACQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GACQ_OK 0
+#define GACQ_ERR_BAD_ARG (-1)
+#define GACQ_ERR_UNKNOWN_CODE (-2)
+#define GACQ_ERR_BAD_PRN (-3)
+#define GACQ_ERR_HIP (-4)
+#define GACQ_ERR_ROCFFT (-5)
+#define GACQ_ERR_SHORT_INPUT (-6)
+#define GACQ_ERR_NO_DEVICE (-7)
+#define GACQ_ERR_INTERNAL (-8)
+#define GACQ_ERR_UNSUPPORTED (-9)
+
+/* ---------------------------------------------------------------------------------------------
+ * PRN chip generators (host only, no GPU needed).  `code` is the reference module name:
+ * "gps.ca" == gnsstools/gps/ca.py, "galileo.e1b", "beidou.b1i", "glonass.ca", ...
+ * Replaces: <module>.<sig>_code(prn) and <module>.code(prn,0,0,L/n,n)  (gnsstools/gps/ca.py:101-112)
+ *           nco.boc11(0,0,L/n,n)                                         (gnsstools/nco.py:12-19)
+ * ------------------------------------------------------------------------------------------- */
+int gacq_code_count(void);
+const char* gacq_code_name(int index);
+int gacq_code_length(const char* code);                 /* chips, or GACQ_ERR_UNKNOWN_CODE */
+double gacq_code_chip_rate(const char* code);
+int gacq_code_prns(const char* code, int* out, int cap);/* returns number of valid PRNs */
+int gacq_code_chips(const char* code, int prn, uint8_t* out, int cap);   /* {0,1} per chip */
+int gacq_code_replica(const char* code, int prn, int n, int boc, float* out); /* +-1 samples */
+
+/* ---------------------------------------------------------------------------------------------
+ * Acquisition engine.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct gacq_ctx gacq_ctx;
+typedef struct gacq_sig gacq_sig;
+
+/* The six knobs that distinguish the 28 FFT search() variants. */
+typedef struct gacq_sigdesc {
+  int code_length;   /* chips in one code period                      (ca.code_length)            */
+  int n;             /* samples per coherent block at the internal fs (acquire-gps-l1.py:20)      */
+  int pad;           /* 1: replica zero-extended to N=2n, windows x[b*n:(b+2)*n]                  */
+                     /*    (acquire-beidou-b1i.py:24,30); 0: N=n (acquire-gps-l1.py:24,30)        */
+  int boc;           /* 1: replica multiplied by nco.boc11 (acquire-galileo-e1b.py:25-26)         */
+  int metric_mode;   /* 1: max/mean (acquire-gps-l1.py:35); 0: raw max (acquire-beidou-b1i.py:36) */
+  int fold_code;     /* 1: code phase reported modulo code_length (acquire-beidou-b1i.py:39)      */
+  double fs;         /* internal sampling rate in Hz                  (acquire-gps-l1.py:19)      */
+} gacq_sigdesc;
+
+/* Final per-item answer == the reference's return tuple (acquire-gps-l1.py:40), plus raw indices. */
+typedef struct gacq_result {
+  double metric;      /* m_metric                                                    */
+  double code_chips;  /* m_code   = code_length*(float(idx)/n) [% code_length]       */
+  double doppler_hz;  /* m_doppler                                                   */
+  int idx;            /* argmax lag of the winning Doppler bin (-1 if no bin won)    */
+  int d_index;        /* index of the winning bin in the Doppler grid (-1 if none)   */
+} gacq_result;
+
+/* Device-side record: best over a (local) Doppler slice for one (epoch, item). 16 bytes.
+ * This is what crosses GPUs (one gather of these). */
+typedef struct gacq_peak {
+  double metric;      /* 0.0 when nothing beat the initial m_metric = 0 (acquire-gps-l1.py:25) */
+  int idx;
+  int d_index;
+} gacq_peak;
+
+int gacq_device_count(void);
+int gacq_create(int device_id, gacq_ctx** out);
+void gacq_destroy(gacq_ctx* ctx);
+const char* gacq_last_error(gacq_ctx* ctx);             /* ctx may be NULL: last global error */
+
+/* Use the caller's HIP stream (hipStream_t passed as void*; NULL = the ctx-owned stream). */
+int gacq_set_stream(gacq_ctx* ctx, void* hip_stream);
+/* Engine selection: 0 = auto, 1 = rocFFT pipeline (any N), 2 = LDS-resident FFT kernels (N = 4096...). */
+int gacq_set_engine(gacq_ctx* ctx, int engine);
+/* Upper bound for the library-owned correlation workspace in bytes (default 4 GiB). */
+int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes);
+
+/* Build a signal: replicas from the built-in generators -> code spectra C_p resident on the device.
+ * Replaces acquire-gps-l1.py:22-24 (c = ca.code(...); c = fft.fft(c)) for every PRN in `prns`. */
+int gacq_signal_create(gacq_ctx* ctx, const gacq_sigdesc* desc, const char* code,
+                       const int* prns, int nprn, gacq_sig** out);
+/* Same, caller supplies the chips ({0,1} bytes, nprn rows of desc->code_length). */
+int gacq_signal_create_chips(gacq_ctx* ctx, const gacq_sigdesc* desc, const uint8_t* chips,
+                             int nprn, gacq_sig** out);
+void gacq_signal_destroy(gacq_sig* sig);
+int gacq_signal_fft_length(const gacq_sig* sig);        /* N = n or 2n */
+/* Copy the device code spectrum of item `item` back (interleaved complex64, N values). Test hook. */
+int gacq_signal_spectrum(gacq_sig* sig, int item, float* out_iq);
+
+/* One search() per item over the same samples (host buffers, synchronous).
+ *   x_iq      interleaved complex64, nsamp complex samples at desc->fs; needs (blocks+pad)*n
+ *   items     indices into the signal's PRN list (0-based), nitems of them
+ *   dopplers  the Doppler grid values np.arange(min,max,incr) produced (acquire-gps-l1.py:26)
+ *   item_bias_hz  NULL, or per-item carrier bias added to the Doppler before the NCO
+ *                 (GLONASS FDMA: 562500*chan, acquire-glonass-l1.py:28)
+ *   blocks    number of non-coherent blocks B (the per-signal ms->B rule stays in the caller)
+ * Replaces acquire-gps-l1.py:25-40 for all items at once (and the mp.Pool.map at :105-108). */
+int gacq_search(gacq_sig* sig, const float* x_iq, size_t nsamp, const int* items, int nitems,
+                const double* dopplers, int nd, const double* item_bias_hz, int blocks,
+                gacq_result* out);
+
+/* Batched, device-resident form: nepoch independent sample blocks already in HBM, results left in
+ * HBM; asynchronous on the ctx stream.  d_x: complex64 [nepoch][nsamp]; d_out: gacq_peak
+ * [nepoch][nitems] holding the best over `dopplers` (a rank's slice of the grid when sharded). */
+int gacq_search_batch_dev(gacq_sig* sig, const void* d_x, size_t nsamp, int nepoch,
+                          const int* items, int nitems, const double* dopplers, int nd,
+                          const double* item_bias_hz, int blocks, void* d_out);
+
+/* Host-side last step (acquire-gps-l1.py:36-40): merge `nshard` peaks per item in shard order with
+ * strict '>' (shard s covers Doppler indices [shard_d0[s], ...)), then convert to the reference's
+ * return tuple.  peaks: [nshard][nitems]; dopplers: the FULL grid. */
+int gacq_finalize(const gacq_sig* sig, const gacq_peak* peaks, int nshard, const int* shard_d0,
+                  int nitems, const double* dopplers, int nd, gacq_result* out);
+
+/* Per-stage GPU time from HIP events recorded on the launch stream (profiling aid for bench.py).
+ * Stages: 0 mix/forward, 1 forward FFT (rocFFT), 2 conj-multiply, 3 inverse FFT (rocFFT),
+ *         4 magnitude/peak reduce, 5 best-over-Doppler, 6 fused correlate kernel (LDS FFT). */
+#define GACQ_NSTAGES 7
+int gacq_set_profiling(gacq_ctx* ctx, int enabled);
+int gacq_get_stage_time(gacq_ctx* ctx, int stage, double* total_ms, long* launches);
+int gacq_reset_stage_times(gacq_ctx* ctx);
+const char* gacq_stage_name(int stage);
+
+/* Full accumulated magnitude row q[0..N) for one (item, doppler) -- debugging / golden rows. */
+int gacq_debug_row(gacq_sig* sig, const float* x_iq, size_t nsamp, int item, double doppler,
+                   double bias_hz, int blocks, float* q_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GACQ_H */

@@ -1,0 +1,261 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY.  Never imported by the product path.
+
+Pure-Python restatement of the reference's PRN chip constructions,
+written list-of-stages style like the ICDs describe them.  Slow on purpose (it is a checker):
+one code costs a few ms, results are cached.  Pinned by tests/golden/chips_sha256.json, which
+tools/make_goldens.py produced by importing the reference itself, and by the ICD known-answer
+vectors in tests/golden/icd_kat.json.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import json
+import os
+import struct
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+
+with open(os.path.join(_HERE, "icd_tables.json")) as _f:
+    _T = json.load(_f)
+
+
+def _row(table, prn):
+    t = _T[table]
+    if str(prn) not in t:
+        raise KeyError("PRN %r not in %s" % (prn, table))
+    return t[str(prn)]
+
+
+def _stages(value, nbits):
+    """integer -> list of stages, stage i = bit i."""
+    return [(value >> i) & 1 for i in range(nbits)]
+
+
+def _step(reg, taps):
+    """One shift: feedback = xor of tapped stages enters stage 0 (gnsstools/gps/ca.py:55-59)."""
+    fb = 0
+    for t in taps:
+        fb ^= reg[t]
+    return [fb] + reg[:-1]
+
+
+def _run(reg, taps, out_stage, count):
+    seq = []
+    for _ in range(count):
+        seq.append(reg[out_stage])
+        reg = _step(reg, taps)
+    return seq
+
+
+# ---- GPS ----------------------------------------------------------------------------------
+def _gps_ca(prn):                                   # gnsstools/gps/ca.py:61-104
+    (delay,) = _row("gps_ca", prn)[:1]
+    g1 = _run([1] * 10, (9, 2), 9, 1023)
+    g2 = _run([1] * 10, (9, 8, 7, 5, 2, 1), 9, 1023)
+    return [g1[i] ^ g2[(i - delay) % 1023] for i in range(1023)]
+
+
+def _gps_l5(table, prn):                            # gnsstools/gps/l5i.py:73-107 (l5q.py identical shape)
+    (advance,) = _row(table, prn)[:1]
+    xb = _run([1] * 13, (12, 11, 7, 6, 5, 3, 2, 0), 12, 8191)
+    xa, reg = [], [1] * 13
+    for _ in range(10230):
+        xa.append(reg[12])
+        reg = [1] * 13 if reg == [1] * 11 + [0, 1] else _step(reg, (12, 11, 9, 8))
+    return [xa[i] ^ xb[(advance + i) % 8191] for i in range(10230)]
+
+
+def _gps_l2cm(prn):                                 # gnsstools/gps/l2cm.py:40-50
+    (state,) = _row("gps_l2cm", prn)[:1]
+    seq = []
+    for _ in range(10230):
+        seq.append(state & 1)
+        state = (state >> 1) ^ ((state & 1) * 0o445112474)
+    return seq
+
+
+def l2cm_end_state(prn):
+    """State after code_length-1 shifts (the ICD known answer, gnsstools/gps/l2cm.py:128-133)."""
+    (state,) = _row("gps_l2cm", prn)[:1]
+    for _ in range(10229):
+        state = (state >> 1) ^ ((state & 1) * 0o445112474)
+    return state
+
+
+def l5_xb_start_state(table, prn):
+    """XB register contents after `advance` shifts (gnsstools/gps/l5i.py:145-151)."""
+    (advance,) = _row(table, prn)[:1]
+    reg = [1] * 13
+    for _ in range(advance):
+        reg = _step(reg, (12, 11, 7, 6, 5, 3, 2, 0))
+    return reg
+
+
+_LEGENDRE = {}
+
+
+def _legendre(N):                                   # gnsstools/gps/l1cd.py:59-62 (sympy.legendre_symbol, -1/0 -> 0)
+    if N not in _LEGENDRE:
+        v = [0] * N
+        for k in range(1, N):
+            v[(k * k) % N] = 1
+        _LEGENDRE[N] = v
+    return _LEGENDRE[N]
+
+
+def _weil_gps(table, prn):                          # gnsstools/gps/l1cd.py:64-69
+    w, p = _row(table, prn)[:2]
+    L, N = _legendre(10223), 10223
+    W = [L[k] ^ L[(k + w) % N] for k in range(N)]
+    return W[:p - 1] + [0, 1, 1, 0, 1, 0, 0] + W[p - 1:]
+
+
+def _weil_bds(table, prn):                          # gnsstools/beidou/b1cd.py:34-38
+    w, p = _row(table, prn)[:2]
+    L, N = _legendre(10243), 10243
+    return [L[(n + p - 1) % N] ^ L[((n + p - 1) % N + w) % N] for n in range(10230)]
+
+
+# ---- Galileo --------------------------------------------------------------------------------
+_E5_TAPS = {"gal_e5ai": ((13, 7, 5, 0), (13, 11, 7, 6, 4, 3)),     # gnsstools/galileo/e5ai.py:48-52
+            "gal_e5aq": ((13, 7, 5, 0), (13, 11, 7, 6, 4, 3)),     # gnsstools/galileo/e5aq.py:76-80
+            "gal_e5bi": ((13, 12, 10, 3), (13, 11, 8, 7, 4, 1)),   # gnsstools/galileo/e5bi.py:34-38
+            "gal_e5bq": ((13, 12, 10, 3), (13, 9, 8, 5, 4, 0))}    # gnsstools/galileo/e5bq.py:76-80
+
+
+def _gal_e5(table, prn):
+    (start,) = _row(table, prn)[:1]
+    t1, t2 = _E5_TAPS[table]
+    r1 = _run([1] * 14, t1, 13, 10230)
+    r2 = _run(_stages(start, 14), t2, 13, 10230)
+    return [a ^ b for a, b in zip(r1, r2)]
+
+
+# ---- BeiDou ---------------------------------------------------------------------------------
+def _bds_b1i(prn):                                  # gnsstools/beidou/b1i.py:27-56
+    taps = [t for t in _row("bds_b1i", prn)[:3] if t]
+    g1 = g2 = [0, 1] * 5 + [0]
+    seq = []
+    for _ in range(2046):
+        v = g1[10]
+        for t in taps:
+            v ^= g2[t - 1]
+        seq.append(v)
+        g1 = _step(g1, (0, 6, 7, 8, 9, 10))
+        g2 = _step(g2, (0, 1, 2, 3, 4, 7, 8, 10))
+    return seq
+
+
+_BDS13 = {"bds_b2ad": ((0, 4, 10, 12), (2, 4, 8, 10, 11, 12)),      # gnsstools/beidou/b2ad.py:35-39
+          "bds_b2ap": ((2, 5, 6, 12), (0, 4, 6, 7, 11, 12)),        # gnsstools/beidou/b2ap.py:39-43
+          "bds_b2bd": ((0, 8, 9, 12), (2, 3, 5, 8, 11, 12)),        # gnsstools/beidou/b2bd.py:36-40
+          "bds_b2bp": ((0, 10, 11, 12), (1, 7, 8, 9, 10, 12)),      # gnsstools/beidou/b2bp.py:36-40
+          "bds_b3i": ((0, 2, 3, 12), (0, 4, 5, 6, 8, 9, 11, 12))}   # gnsstools/beidou/b3i.py:27-34
+
+
+def _bds_13(table, prn):                            # gnsstools/beidou/b2ad.py:41-59, b3i.py:36-46
+    (init,) = _row(table, prn)[:1]
+    t1, t2 = _BDS13[table]
+    g1, g2 = [1] * 13, _stages(init, 13)
+    seq = []
+    for i in range(10230):
+        seq.append(g1[12] ^ g2[12])
+        if table == "bds_b3i":
+            g1 = [1] * 13 if g1 == [1] * 11 + [0, 0] else _step(g1, t1)
+        else:
+            g1 = [1] * 13 if i == 8189 else _step(g1, t1)
+        g2 = _step(g2, t2)
+    return seq
+
+
+# ---- GLONASS --------------------------------------------------------------------------------
+def _glo_ca(_prn):                                  # gnsstools/glonass/ca.py:10-21
+    return _run([1] * 9, (8, 4), 6, 511)
+
+
+def _glo_l3oc(pilot, n):                            # gnsstools/glonass/l3ocd.py:13-34, l3ocp.py:13-33
+    seed = n + 64 if pilot else n
+    small = [(seed >> (6 - i)) & 1 for i in range(7)]
+    big = [0, 0, 1, 1, 0, 1, 0, 0, 1, 1, 1, 0, 0, 0]
+    a = _run(small, (6, 5), 6, 10230)
+    b = _run(big, (13, 12, 7, 3), 13, 10230)
+    return [u ^ v for u, v in zip(a, b)]
+
+
+# ---- memory codes (E1B/E1C/E6B/E6C/B2bI/B2bQ/Xona): packed-chip data file ---------------------
+_MEM = None
+
+
+def _mem_tables():
+    global _MEM
+    if _MEM is None:
+        path = os.path.join(_ROOT, "gnss-dsp-tools_amd", "data", "memcodes.bin")
+        blob = open(path, "rb").read()
+        assert blob[:4] == b"GMC1"
+        (count,) = struct.unpack_from("<I", blob, 4)
+        _MEM = {}
+        for i in range(count):
+            off = 8 + 28 * i
+            name = blob[off:off + 12].rstrip(b"\0").decode()
+            nprn, L, ids_off, bits_off = struct.unpack_from("<IIII", blob, off + 12)
+            ids = struct.unpack_from("<%di" % nprn, blob, ids_off)
+            nb = (L + 7) // 8
+            _MEM[name] = (L, {p: blob[bits_off + k * nb: bits_off + (k + 1) * nb] for k, p in enumerate(ids)})
+    return _MEM
+
+
+def _mem(name, prn):
+    L, rows = _mem_tables()[name]
+    if prn not in rows:
+        raise KeyError("PRN %r not in %s" % (prn, name))
+    return list(np.unpackbits(np.frombuffer(rows[prn], dtype=np.uint8))[:L])
+
+
+_GENERATORS = {
+    "gps.ca": _gps_ca,
+    "gps.l5i": lambda p: _gps_l5("gps_l5i", p),
+    "gps.l5q": lambda p: _gps_l5("gps_l5q", p),
+    "gps.l2cm": _gps_l2cm,
+    "gps.l1cd": lambda p: _weil_gps("gps_l1cd", p),
+    "gps.l1cp": lambda p: _weil_gps("gps_l1cp", p),
+    "beidou.b1cd": lambda p: _weil_bds("bds_b1cd", p),
+    "beidou.b1cp": lambda p: _weil_bds("bds_b1cp", p),
+    "galileo.e5ai": lambda p: _gal_e5("gal_e5ai", p),
+    "galileo.e5aq": lambda p: _gal_e5("gal_e5aq", p),
+    "galileo.e5bi": lambda p: _gal_e5("gal_e5bi", p),
+    "galileo.e5bq": lambda p: _gal_e5("gal_e5bq", p),
+    "beidou.b1i": _bds_b1i,
+    "beidou.b2ad": lambda p: _bds_13("bds_b2ad", p),
+    "beidou.b2ap": lambda p: _bds_13("bds_b2ap", p),
+    "beidou.b2bd": lambda p: _bds_13("bds_b2bd", p),
+    "beidou.b2bp": lambda p: _bds_13("bds_b2bp", p),
+    "beidou.b3i": lambda p: _bds_13("bds_b3i", p),
+    "glonass.ca": _glo_ca,
+    "glonass.l3ocd": lambda p: _glo_l3oc(False, p),
+    "glonass.l3ocp": lambda p: _glo_l3oc(True, p),
+    "galileo.e1b": lambda p: _mem("gal_e1b", p),
+    "galileo.e1c": lambda p: _mem("gal_e1c", p),
+    "galileo.e6b": lambda p: _mem("gal_e6b", p),
+    "galileo.e6c": lambda p: _mem("gal_e6c", p),
+    "beidou.b2bi": lambda p: _mem("bds_b2bi", p),
+    "beidou.b2bq": lambda p: _mem("bds_b2bq", p),
+    "xona.x1p": lambda p: _mem("xona_x1p", p),
+    "xona.x1d": lambda p: _mem("xona_x1d", p),
+    "xona.x5p": lambda p: _mem("xona_x5p", p),
+}
+
+_CACHE = {}
+
+
+def code_names():
+    return sorted(_GENERATORS)
+
+
+def chips(code, prn):
+    """{0,1} chips of one code period as uint8 (cached like the reference's `codes` dicts)."""
+    key = (code, prn)
+    if key not in _CACHE:
+        _CACHE[key] = np.asarray(_GENERATORS[code](prn), dtype=np.uint8)
+    return _CACHE[key]

@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE in this container.
+
+The reference ships no tests and pins no search() result, so parity is pinned by
+outputs of the reference itself: each acquire-*.py is exec'd up to its "# main program" marker
+(the scripts have no __main__ guard) to obtain its unmodified search(); inputs are the seeded
+synthetic IQ of gnss-dsp-tools_amd/synth.py (spec stored next to the results so tests regenerate
+the identical samples; a SHA-256 of the sample bytes guards the generator).
+
+Outputs (data only -- no reference source text):
+  tests/golden/search_cases.json   per case: spec + [(metric, code, doppler)] + formatted lines
+  tests/golden/rows.npz            a few full accumulated-magnitude rows q (fp64)
+  tests/golden/chips_sha256.json   SHA-256 + first/last 24 chips of every PRN of every code family
+  tests/golden/nco_indices.json    nco.nco table-index vectors (hash + head) for benchmark (fs, doppler) pairs
+
+Needs /root/reference and a built libgacq.so (host part only; no GPU).  Never runs on the GPU box.
+"""
+import hashlib
+import importlib
+import json
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+
+REF = os.environ.get("GNSS_REFERENCE", "/root/reference")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+warnings.filterwarnings("ignore")
+
+import gnss_dsp_tools_amd  # noqa: E402
+from gnss_dsp_tools_amd import signals, synth  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def load_reference_script(name):
+    """exec the head of acquire-<name>.py (imports + search()) and return its namespace."""
+    path = os.path.join(REF, "acquire-%s.py" % name)
+    src = open(path).read()
+    head = src.split("#\n# main program\n#")[0]
+    ns = {}
+    exec(compile(head, path, "exec"), ns)
+    return ns
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+# (case id, script, items, doppler_search, ms, seed offset, sats [(item, amp, dop, delay)])
+def cases():
+    A, F, Dl = synth.AMPLITUDES, synth.DOPPLERS_HZ, synth.DELAYS
+    gps4 = [(3, A[0], F[0], Dl[0]), (11, A[1], F[1], Dl[1]), (19, A[2], F[2], Dl[2]), (28, A[3], F[3], Dl[3])]
+    out = []
+    out.append(("cfg1_gps_l1_prn1", "gps-l1", [1], [-5000.0, 5000.0, 500.0], 1, 1,
+                [(1, A[1], F[0], Dl[0])] + gps4[1:]))
+    out.append(("cfg2_gps_l1_all32", "gps-l1", list(range(1, 33)), [-5000.0, 5000.0, 250.0], 1, 2, gps4))
+    out.append(("gps_l1_ms3", "gps-l1", [1, 3, 11, 19, 20, 28, 31, 32], [-5000.0, 5000.0, 500.0], 3, 3, gps4))
+    out.append(("gps_l1_default_grid", "gps-l1", [3, 4, 28], [-7000.0, 7000.0, 200.0], 2, 4, gps4))
+    e1 = [(5, A[0], F[0], 1201), (24, A[2], F[1], 20077)]
+    out.append(("cfg3_e1b_subset", "galileo-e1b", [5, 6, 24, 36], [-4000.0, 4000.0, 125.0], 8, 5, e1))
+    out.append(("cfg3_e1c_subset", "galileo-e1c", [5, 24], [-4000.0, 4000.0, 125.0], 8, 6, e1))
+    out.append(("e1b_ms12", "galileo-e1b", [24], [-3500.0, -3000.0, 125.0], 12, 7, e1))
+    l5 = [(7, A[0], F[0], 1201), (30, A[1], F[1], 29000)]
+    out.append(("cfg4_l5i_subset", "gps-l5i", [7, 8, 30], [-7000.0, 7000.0, 200.0], 1, 8, l5))
+    out.append(("l5q_subset", "gps-l5q", [7], [-4000.0, -2000.0, 200.0], 2, 9, [(7, A[0], F[1], 77)]))
+    out.append(("cfg4_b2ad_b80", "beidou-b2ad", [12], [1000.0, 2200.0, 200.0], 80, 10, [(12, 0.1, F[0], 1201)]))
+    b1 = [(6, A[0], F[0], 1201), (33, A[2], F[3], 5000)]
+    out.append(("cfg5_b1i_ms10", "beidou-b1i", [6, 7, 33, 63], [-1000.0, 2000.0, 100.0], 10, 11, b1))
+    out.append(("b2i_ms2", "beidou-b2i", [6, 33], [-1000.0, 2000.0, 500.0], 2, 12, b1))
+    glo = [(-7, A[0], F[0], 1201), (3, A[1], F[1], 9000)]
+    out.append(("cfg5_glonass_l1", "glonass-l1", [-7, 0, 3], [-4000.0, 2000.0, 100.0], 2, 13, glo))
+    out.append(("glonass_l2", "glonass-l2", [3, 6], [-4000.0, -2000.0, 200.0], 1, 14, glo))
+    out.append(("gps_l1cd", "gps-l1cd", [9, 10], [1400.0, 1700.0, 20.0], 10, 15, [(9, 0.2, F[0], 1201)]))
+    out.append(("bds_b1cp", "beidou-b1cp", [20], [1480.0, 1600.0, 20.0], 20, 16, [(20, 0.2, F[0], 70000)]))
+    out.append(("gps_l2cm", "gps-l2cm", [15], [1500.0, 1600.0, 20.0], 40, 17, [(15, 0.2, F[0], 1201)]))
+    out.append(("gal_e6b", "galileo-e6b", [2, 3], [1000.0, 2000.0, 200.0], 2, 18, [(2, A[0], F[0], 1201)]))
+    out.append(("gal_e5bq", "galileo-e5bq", [50], [1000.0, 2000.0, 200.0], 1, 19, [(50, A[0], F[0], 1201)]))
+    out.append(("bds_b3i", "beidou-b3i", [1], [1000.0, 2000.0, 200.0], 1, 20, [(1, A[0], F[0], 1201)]))
+    out.append(("bds_b2bi", "beidou-b2bi", [19], [1000.0, 2000.0, 200.0], 1, 21, [(19, A[0], F[0], 1201)]))
+    out.append(("glo_l3ocd", "glonass-l3ocd", [0, 63], [1000.0, 2000.0, 200.0], 1, 22, [(63, A[0], F[0], 1201)]))
+    out.append(("xona_x1", "xona-x1", [0], [-2000.0, 3000.0, 200.0], 2, 23, [(0, A[1], F[0], 1201)]))
+    out.append(("xona_x5p", "xona-x5p", [0], [1000.0, 2000.0, 200.0], 2, 24, [(0, A[1], F[0], 1201)]))
+    # edge cases: empty Doppler grid, zero blocks (initial values come back untouched)
+    out.append(("edge_empty_grid", "gps-l1", [1, 2], [1000.0, 1000.0, 100.0], 1, 25, gps4))
+    out.append(("edge_zero_blocks_l1", "gps-l1", [3], [-1000.0, 1000.0, 500.0], 0, 26, gps4))
+    out.append(("edge_zero_blocks_e1b", "galileo-e1b", [5], [-1000.0, 1000.0, 500.0], 4, 27, e1))
+    out.append(("edge_fractional_grid", "gps-l1", [3, 28], [-409.3, 1600.7, 333.3], 1, 28, gps4))
+    return out
+
+
+def ref_row(ns, sig, x, item, doppler, blocks):
+    """Accumulated q row of one Doppler bin, evaluated with the reference's own primitives in the
+    reference's statement order (acquire-gps-l1.py:22-33 / acquire-galileo-e1b.py:23-35)."""
+    fft, nco = ns["fft"], ns["nco"]
+    mod = importlib.import_module("gnsstools." + sig.code)
+    n = sig.n
+    incr = float(mod.code_length) / n
+    c = mod.code(0, 0, incr, n) if sig.code == "glonass.ca" else mod.code(item, 0, 0, incr, n)
+    if sig.boc:
+        c = c * nco.boc11(0, 0, incr, n)
+    span = 2 * n if sig.pad else n
+    if sig.pad:
+        c = np.concatenate((c, np.zeros(n)))
+    c = fft.fft(c)
+    q = np.zeros(span)
+    if sig.bias_hz:
+        w = nco.nco(-(int(sig.bias_hz) * item + doppler) / sig.fs, 0, span)
+    else:
+        w = nco.nco(-doppler / sig.fs, 0, span)
+    for block in range(blocks):
+        b = x[(block * n):(block * n + span)]
+        b = b * w
+        r = fft.ifft(c * np.conj(fft.fft(b)))
+        q = q + np.absolute(r)
+    return q
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    scripts = {}
+    out_cases = []
+    rows = {}
+    row_plan = {"cfg2_gps_l1_all32": [(3, 1500.0), (20, -250.0)], "gps_l1_ms3": [(28, -500.0)],
+                "cfg5_b1i_ms10": [(6, 1500.0)], "cfg5_glonass_l1": [(-7, 1500.0)]}
+    for cid, name, items, ds, ms, soff, sats in cases():
+        sig = signals.get(name)
+        if name not in scripts:
+            scripts[name] = load_reference_script(name)
+        ns = scripts[name]
+        blocks = max(sig.blocks(ms), 0)
+        x64 = synth.make_iq(sig, blocks, synth.BASE_SEED + soff, sats)
+        x = x64.astype(np.complex128)
+        t0 = time.time()
+        results, lines = [], []
+        for it in items:
+            m, c, d = ns["search"](x, it, ds, ms)
+            results.append([float(m), float(c), float(d)])
+            lines.append(sig.fmt % (it, d, m, c))
+        dt = time.time() - t0
+        out_cases.append({"id": cid, "script": name, "items": items, "doppler_search": ds, "ms": ms,
+                          "seed": synth.BASE_SEED + soff, "sats": [list(s) for s in sats], "nsamp": int(len(x64)),
+                          "x_sha256": sha(x64), "results": results, "lines": lines, "ref_seconds": round(dt, 3)})
+        print("%-24s %-14s items=%d  %.2fs  %s" % (cid, name, len(items), dt, lines[0]))
+        for it, dop in row_plan.get(cid, []):
+            rows["%s|%d|%g" % (cid, it, dop)] = ref_row(ns, sig, x, it, dop, blocks)
+    with open(os.path.join(GOLD, "search_cases.json"), "w") as f:
+        json.dump({"generator": "tools/make_goldens.py", "reference": "pmonta/GNSS-DSP-tools @ 2025-08-29",
+                   "numpy": np.__version__, "scipy": importlib.import_module("scipy").__version__,
+                   "cases": out_cases}, f, indent=1)
+    np.savez_compressed(os.path.join(GOLD, "rows.npz"), **rows)
+
+    # ---- chips: every PRN of every family ------------------------------------------------------
+    from gnss_dsp_tools_amd import codes
+    chips = {}
+    for code in codes.names():
+        mod = importlib.import_module("gnsstools." + code)
+        fn = [v for k, v in vars(mod).items() if k.endswith("_code") and callable(v)][0]
+        fam = {}
+        for prn in codes.prns(code):
+            c = np.asarray(fn() if code == "glonass.ca" else fn(prn)).astype(np.uint8)
+            fam[str(prn)] = {"sha256": sha(c), "head": "".join(map(str, c[:24])), "tail": "".join(map(str, c[-24:]))}
+        chips[code] = {"code_length": int(mod.code_length), "chip_rate": float(mod.chip_rate), "prns": fam}
+        print("chips", code, len(fam))
+    with open(os.path.join(GOLD, "chips_sha256.json"), "w") as f:
+        json.dump(chips, f, sort_keys=True, separators=(",", ":"))
+
+    # ---- nco index vectors + boc + code sampling ---------------------------------------------------
+    nco = importlib.import_module("gnsstools.nco")
+    vec = []
+    for fs, n, dops in ((4096000.0, 4096, (-5000.0, -250.0, 0.0, 1750.0, 4750.0, -409.3 + 3 * 333.3)),
+                        (8192000.0, 65536, (-4000.0, 125.0, 3875.0)), (30690000.0, 61380, (-7000.0, 200.0, 6800.0)),
+                        (16384000.0, 16384, (-10000.0, 100.0)), (8192000.0, 16384, (-9900.0, 9900.0))):
+        for dop in dops:
+            w = nco.nco(-dop / fs, 0, n)
+            idx = np.mod(np.floor((0 + (-dop / fs) * np.arange(n)) * nco.NT).astype("int"), nco.NT)
+            assert np.array_equal(nco.nco_table[idx], w)
+            vec.append({"fs": fs, "n": n, "doppler": dop, "sha256": sha(idx.astype(np.int32)),
+                        "head": [int(v) for v in idx[:16]], "tail": [int(v) for v in idx[-16:]]})
+    for chan in (-7, 3):
+        fs, n, dop = 16384000.0, 16384, 1500.0
+        f = -(562500 * chan + dop) / fs
+        idx = np.mod(np.floor((0 + f * np.arange(n)) * nco.NT).astype("int"), nco.NT)
+        vec.append({"fs": fs, "n": n, "doppler": dop, "bias": 562500.0 * chan, "sha256": sha(idx.astype(np.int32)),
+                    "head": [int(v) for v in idx[:16]], "tail": [int(v) for v in idx[-16:]]})
+    boc = {"n32768_L4092": sha(nco.boc11(0, 0, 4092.0 / 32768, 32768).astype(np.int8)),
+           "n81920_L10230": sha(nco.boc11(0, 0, 10230.0 / 81920, 81920).astype(np.int8))}
+    table = {"sha256_c128": sha(nco.nco_table), "k1": [nco.nco_table[1].real, nco.nco_table[1].imag],
+             "k513": [nco.nco_table[513].real, nco.nco_table[513].imag]}
+    with open(os.path.join(GOLD, "nco_indices.json"), "w") as f:
+        json.dump({"vectors": vec, "boc11": boc, "table": table}, f, separators=(",", ":"))
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
