@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Benchmark of the acquisition hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): GPS L1 C/A, all 32 PRNs, 1 ms coherent, fs = 4.096 MS/s
+(the reference's hard-coded rate), Doppler grid np.arange(-5000, 5000, 250) = 40 bins,
+n = N = 4096 code-phase lags -> 5 242 880 cells per 1 ms epoch.  One "step" = one pass of the hot
+path over a batch of EPOCHS independent 1 ms sample blocks that are already resident in HBM
+(synthetic seeded IQ): table-NCO mix -> forward FFT -> x conj code spectrum ->
+inverse FFT -> |.| -> peak/mean per Doppler bin -> best per PRN.
+
+N GPUs (one process per GPU, torch.distributed/RCCL): the PRN x Doppler grid is sharded by Doppler
+slice, every rank processes its slice for N*EPOCHS epochs (per-GPU work fixed -> "weak" scaling),
+then ONE all-gather of the per-shard peak records and a device-side merge.
+
+Prints ONE JSON line (rank 0).  `value` = cells/s of the whole job with inputs resident in HBM.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+S = 8                           # bytes per complex64
+
+
+def a_pipe_bytes(N, P, D, B, F=1):
+    """Algorithmic bytes of ONE search under the stage-boundary model (SURVEY.md section 8d / BASELINE.md section 3):
+    A_pipe = S*N*(4*D*B*F + P + 5*P*D*B) + 8*N*P*D*(B-1)."""
+    return S * N * (4 * D * B * F + P + 5 * P * D * B) + 8 * N * P * D * (B - 1)
+
+
+def stage_bytes(N, P, D, B, F=1):
+    """Per-stage split of A_pipe for one search (each stage reads its input once and writes its output once)."""
+    return {
+        "mix_nco": S * N * 2 * D * B * F,            # read x window + write mixed block
+        "rocfft_forward": S * N * 2 * D * B * F,     # read + write
+        "conj_mul": S * N * (P + 2 * P * D * B),     # read C_p, read X, write Y
+        "rocfft_inverse": S * N * 2 * P * D * B,     # read + write
+        "mag_peak": S * N * P * D * B + 8 * N * P * D * (B - 1),
+        # fused LDS engine: the correlate kernel covers conj-mul + inverse FFT + magnitude/peak,
+        # the forward kernel covers mix + forward FFT
+        "lds_correlate": S * N * (P + 5 * P * D * B) + 8 * N * P * D * (B - 1),
+        "lds_forward": S * N * 4 * D * B * F,
+    }
+
+
+def cpu_baseline(sig, xs, items, ds, ms, budget_s=12.0):
+    """The oracle (numpy fp64 restatement of the reference, reference loop order) on this host, 1 core."""
+    from oracle import acq_oracle           # checker / baseline only
+    n_cells_epoch = len(items) * len(np.arange(*ds)) * sig.nfft
+    t0 = time.perf_counter()
+    done = 0
+    for e in range(xs.shape[0]):
+        x = xs[e].astype(np.complex128)
+        for it in items:
+            acq_oracle.search_script(sig.name, x, it, ds, ms)
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done * n_cells_epoch / dt, "unit": "cells/s", "cores": 1, "kind": "port",
+            "sample": "%d epoch(s) x %d PRNs x %d Doppler bins x %d lags, numpy/scipy fp64 oracle in the reference's loop order "
+                      "(per-PRN forward FFT), %.1f s on %d-core host" % (done, len(items), len(np.arange(*ds)), sig.nfft, dt, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--epochs", type=int, default=64, help="1 ms epochs per GPU per step")
+    ap.add_argument("--engine", type=int, default=0, help="0 auto, 1 rocFFT pipeline, 2 LDS FFT kernels")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from gnss_dsp_tools_amd import acquire, sharded, signals, synth
+
+    sig = signals.get("gps-l1")
+    items = list(range(1, 33))
+    ds = [-5000.0, 5000.0, 250.0]
+    ms = 1
+    B = sig.blocks(ms)
+    dop = acquire.doppler_grid(ds)
+    P, D, N = len(items), len(dop), sig.nfft
+    E_total = args.epochs * world                       # weak scaling: per-GPU work is fixed
+    sats = synth.default_sats(items)
+    # a few distinct seeded epochs tiled to the batch (content does not change the work)
+    base = synth.make_epochs(sig, B, synth.BASE_SEED + 2, sats, min(8, E_total), nsamp=B * sig.n)
+    xs = np.concatenate([base] * ((E_total + len(base) - 1) // len(base)))[:E_total]
+    x_dev = torch.from_numpy(np.ascontiguousarray(xs)).to(dev)
+
+    eng = acquire.Engine(local_rank, engine=args.engine)
+    stream = torch.cuda.current_stream(dev)
+    eng.set_stream(stream.cuda_stream)                  # same stream as the RCCL collective -> ordered
+    sh = sharded.ShardedSearch(engine=eng)
+
+    def step():
+        return sh.search_batch(sig, x_dev, items, dop, B)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        merged = step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        merged = step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- correctness spot check of what was just computed (not timed) ----------------------------
+    res = sh.results(sig, items, merged[:1], dop)[0]
+    detected = {it: r for it, r in zip(items, res)}
+    for it, amp, f, delay in sats:
+        if amp >= 0.25:
+            want_code = 1023 * (((-delay) % sig.n) / sig.n)
+            assert abs(detected[it][1] - want_code) < 1e-9, ("bench self-check failed", it, detected[it], want_code)
+
+    # ---- roofline of the dominant kernel: HIP events on the launch stream, separate profiled pass ---
+    cells_step = E_total * P * D * N
+    bounds = sharded.doppler_bounds(D, world)
+    D_local = bounds[rank + 1] - bounds[rank]
+    eng.set_profiling(True)
+    eng.reset_stage_times()
+    prof_steps = max(3, min(10, args.steps))
+    for _ in range(prof_steps):
+        step()
+    torch.cuda.synchronize(dev)
+    stages = eng.stage_times()
+    eng.set_profiling(False)
+    sb = stage_bytes(N, P, D_local, B)
+    per_stage = {}
+    for name, (tot_ms, n) in stages.items():
+        if n:
+            key = "lds_forward" if (name == "mix_nco" and stages["lds_correlate"][1]) else name
+            per_stage[name] = {"avg_ms": tot_ms / n, "launches_per_step": n / prof_steps,
+                               "alg_bytes_per_launch": sb.get(key, 0) * E_total * (prof_steps / n) if key in sb else None}
+    dominant = max((k for k in per_stage if per_stage[k]["alg_bytes_per_launch"]), key=lambda k: per_stage[k]["avg_ms"] * per_stage[k]["launches_per_step"])
+    dk = per_stage[dominant]
+    achieved = dk["alg_bytes_per_launch"] / (dk["avg_ms"] * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("kernel_stage") == dominant and tj.get("epochs") == E_total and world == 1:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "avg_kernel_ms": dk["avg_ms"], "alg_bytes_per_launch": dk["alg_bytes_per_launch"],
+                "model": "stage-boundary A_pipe share of this kernel (SURVEY.md 8d); fused kernels keep stage boundaries in LDS, "
+                         "so achieved can exceed what HBM alone could deliver -- see traffic for measured HBM bytes"}
+
+    out = None
+    if rank == 0:
+        a_pipe_step = a_pipe_bytes(N, P, D, B) * E_total
+        out = {
+            "metric": "acquisition cells/s (PRN x Doppler x code-phase), GPS L1 C/A 1 ms",
+            "value": cells_step * args.steps / dt,
+            "unit": "cells/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "complex64 (f32)",
+            "data": "synthetic",
+            "config": {"workload": "GPS L1 C/A all 32 PRNs, 1 ms coherent (B=1), fs=4.096 MS/s, n=N=4096, "
+                                   "Doppler arange(-5000,5000,250)=40 bins; %d epochs/step/GPU batched, inputs resident in HBM" % args.epochs,
+                       "prns": P, "doppler_bins": D, "lags": N, "blocks": B, "epochs_per_step": E_total,
+                       "cells_per_step": cells_step, "sharding": "doppler-slice x%d + 1 all-gather of peaks" % world,
+                       "engine": {0: "auto", 1: "rocfft", 2: "lds-fft"}[args.engine]},
+            "roofline": roofline,
+            "pipeline": {"a_pipe_bytes_per_step": a_pipe_step, "achieved_GBps": a_pipe_step / (dt / args.steps) / 1e9,
+                         "frac_of_8TBps": a_pipe_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS,
+                         "us_per_search": dt / args.steps / E_total * 1e6, "stages": per_stage},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(sig, base, items, ds, ms)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -78,7 +78,9 @@ SYMBOLS = {
     "gacq_search_batch_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
                                              c_int_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p,
                                              ctypes.c_int, ctypes.c_void_p]),
-    "gacq_finalize": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Peak), ctypes.c_int, c_int_p, ctypes.c_int,
+    "gacq_merge_peaks_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c_int_p, ctypes.c_long,
+                                            ctypes.c_void_p]),
+    "gacq_finalize": (ctypes.c_int, [ctypes.POINTER(SigDesc), ctypes.POINTER(Peak), ctypes.c_int, c_int_p, ctypes.c_int,
                                      c_double_p, ctypes.c_int, ctypes.POINTER(Result)]),
     "gacq_set_profiling": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "gacq_get_stage_time": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, ctypes.POINTER(ctypes.c_long)]),

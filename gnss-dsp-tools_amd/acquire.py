@@ -220,18 +220,43 @@ class Engine:
         return out
 
     def finalize(self, name, items, peaks, dopplers, shard_d0=None):
-        """Host-side last step: peaks [nshard, nitems] (PEAK_DTYPE) -> list of (metric, code, doppler)."""
-        sig = _signals.get(name) if isinstance(name, str) else name
-        s, idx, _ = self._plan(sig, items)
-        peaks = np.ascontiguousarray(peaks).view(PEAK_DTYPE).reshape(-1, len(idx))
-        nshard = peaks.shape[0]
-        dopplers = np.ascontiguousarray(dopplers, dtype=np.float64)
-        d0 = np.ascontiguousarray(shard_d0 if shard_d0 is not None else np.zeros(nshard), dtype=np.int32)
-        res = (nat.Result * len(idx))()
-        nat.check(nat.lib.gacq_finalize(s._h, peaks.ctypes.data_as(ctypes.POINTER(nat.Peak)), nshard,
-                                        d0.ctypes.data_as(nat.c_int_p), len(idx),
-                                        dopplers.ctypes.data_as(nat.c_double_p), len(dopplers), res), self._ctx)
-        return [_as_tuple(r) for r in res]
+        return finalize(name, items, peaks, dopplers, shard_d0)
+
+    def merge_peaks_dev(self, gathered, shard_d0, out=None):
+        """gathered: torch float64 CUDA tensor [nshard, ..., 2] of gacq_peak records (all_gather output);
+        returns the merged [..., 2] tensor with global Doppler indices (device-side, asynchronous)."""
+        import torch
+        nshard = gathered.shape[0]
+        n = int(gathered[0].numel() // 2)
+        if out is None:
+            out = torch.empty(gathered.shape[1:], dtype=torch.float64, device=gathered.device)
+        d0 = np.ascontiguousarray(shard_d0, dtype=np.int32)
+        nat.check(nat.lib.gacq_merge_peaks_dev(self._ctx, ctypes.c_void_p(gathered.data_ptr()), nshard,
+                                               d0.ctypes.data_as(nat.c_int_p), n, ctypes.c_void_p(out.data_ptr())), self._ctx)
+        return out
+
+
+def descriptor(name):
+    sig = _signals.get(name) if isinstance(name, str) else name
+    L = nat.check(nat.lib.gacq_code_length(sig.code.encode()))
+    return nat.SigDesc(L, sig.n, int(sig.pad), int(sig.boc), int(sig.normalised), int(sig.fold), sig.fs)
+
+
+def finalize(name, items, peaks, dopplers, shard_d0=None):
+    """Host-side last step (no GPU needed): peaks [nshard, nitems] (PEAK_DTYPE) -> [(metric, code, doppler)].
+    Shards are merged in Doppler order with strict '>' (acquire-gps-l1.py:36-39), then converted
+    to the reference's return tuple (acquire-gps-l1.py:38-40)."""
+    nitems = len(items)
+    peaks = np.ascontiguousarray(peaks).view(PEAK_DTYPE).reshape(-1, nitems)
+    nshard = peaks.shape[0]
+    dopplers = np.ascontiguousarray(dopplers, dtype=np.float64)
+    d0 = np.ascontiguousarray(shard_d0 if shard_d0 is not None else np.zeros(nshard), dtype=np.int32)
+    desc = descriptor(name)
+    res = (nat.Result * nitems)()
+    nat.check(nat.lib.gacq_finalize(ctypes.byref(desc), peaks.ctypes.data_as(ctypes.POINTER(nat.Peak)), nshard,
+                                    d0.ctypes.data_as(nat.c_int_p), nitems,
+                                    dopplers.ctypes.data_as(nat.c_double_p), len(dopplers), res))
+    return [_as_tuple(r) for r in res]
 
 
 def _as_tuple(r):

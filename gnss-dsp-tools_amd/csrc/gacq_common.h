@@ -48,11 +48,14 @@ struct gacq_ctx {
   int engine = 0;
   size_t ws_limit = (size_t)4 << 30;
   std::map<std::pair<long, long>, gacq::FftPlan> plans;   // (N * 2 + inverse, batch)
-  gacq::DevBuf tab, xstage, X, Y, rows, freq, fset, items, out_peaks;
+  gacq::DevBuf tab, xstage, X, Y, rows, freq, fset, items, out_peaks, d0;
   bool profiling = false;
   double stage_ms[GACQ_NSTAGES] = {0};
   long stage_n[GACQ_NSTAGES] = {0};
   std::vector<gacq::StageEvent> pending;
+  // last grid uploaded to freq/fset/items (skip the H2D + sync when a call repeats it, as batched loops do)
+  std::vector<double> up_freq;
+  std::vector<int> up_fset, up_items, up_d0;
 };
 
 struct gacq_sig {

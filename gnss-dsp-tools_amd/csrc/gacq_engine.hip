@@ -319,7 +319,7 @@ void gacq_destroy(gacq_ctx* ctx) {
     if (kv.second.work) (void)hipFree(kv.second.work);
   }
   for (auto& ev : ctx->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-  DevBuf* bufs[] = {&ctx->tab, &ctx->xstage, &ctx->X, &ctx->Y, &ctx->rows, &ctx->freq, &ctx->fset, &ctx->items, &ctx->out_peaks};
+  DevBuf* bufs[] = {&ctx->tab, &ctx->xstage, &ctx->X, &ctx->Y, &ctx->rows, &ctx->freq, &ctx->fset, &ctx->items, &ctx->out_peaks, &ctx->d0};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -514,15 +514,22 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
   Grid g = make_grid(ds, nitems, dopplers, nd, bias);
   const int F = g.F;
   int rc;
+  const void* before[3] = {ctx->freq.p, ctx->fset.p, ctx->items.p};
   if ((rc = ensure(ctx, ctx->freq, sizeof(double) * g.freq.size())) != GACQ_OK) return rc;
   if ((rc = ensure(ctx, ctx->fset, sizeof(int) * P)) != GACQ_OK) return rc;
   if ((rc = ensure(ctx, ctx->items, sizeof(int) * P)) != GACQ_OK) return rc;
-  GACQ_HIP(ctx, hipMemcpyAsync(ctx->freq.p, g.freq.data(), sizeof(double) * g.freq.size(), hipMemcpyHostToDevice, st));
-  GACQ_HIP(ctx, hipMemcpyAsync(ctx->fset.p, g.fset.data(), sizeof(int) * P, hipMemcpyHostToDevice, st));
-  GACQ_HIP(ctx, hipMemcpyAsync(ctx->items.p, items, sizeof(int) * P, hipMemcpyHostToDevice, st));
-  // the host vectors above die with this frame: pageable H2D copies are staged before returning,
-  // but make that explicit rather than rely on it
-  GACQ_HIP(ctx, hipStreamSynchronize(st));
+  const std::vector<int> items_v(items, items + P);
+  if (before[0] != ctx->freq.p || before[1] != ctx->fset.p || before[2] != ctx->items.p) ctx->up_freq.clear();   // reallocated
+  if (g.freq != ctx->up_freq || g.fset != ctx->up_fset || items_v != ctx->up_items) {
+    GACQ_HIP(ctx, hipMemcpyAsync(ctx->freq.p, g.freq.data(), sizeof(double) * g.freq.size(), hipMemcpyHostToDevice, st));
+    GACQ_HIP(ctx, hipMemcpyAsync(ctx->fset.p, g.fset.data(), sizeof(int) * P, hipMemcpyHostToDevice, st));
+    GACQ_HIP(ctx, hipMemcpyAsync(ctx->items.p, items, sizeof(int) * P, hipMemcpyHostToDevice, st));
+    // the host vectors die with this frame; a repeated grid (batched loops) skips both copy and sync
+    GACQ_HIP(ctx, hipStreamSynchronize(st));
+    ctx->up_freq = g.freq;
+    ctx->up_fset = g.fset;
+    ctx->up_items = items_v;
+  }
 
   const bool use_lds = (ctx->engine == 2) || (ctx->engine == 0 && lds_supported(N) && !d_qrow);
   if (ctx->engine == 2 && (!lds_supported(N) || d_qrow))
@@ -634,11 +641,46 @@ int gacq_search_batch_dev(gacq_sig* sig, const void* d_x, size_t nsamp, int nepo
                        (gacq_peak*)d_out, nullptr);
 }
 
-int gacq_finalize(const gacq_sig* sig, const gacq_peak* peaks, int nshard, const int* shard_d0, int nitems,
+__global__ void merge_peaks_kernel(const gacq_peak* __restrict__ peaks, gacq_peak* __restrict__ out, long n, int nshard,
+                                   const int* __restrict__ d0) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  gacq_peak best;
+  best.metric = 0.0;
+  best.idx = -1;
+  best.d_index = -1;
+  for (int s = 0; s < nshard; s++) {
+    const gacq_peak k = peaks[(long)s * n + i];
+    if (k.d_index >= 0 && k.metric > best.metric) { best.metric = k.metric; best.idx = k.idx; best.d_index = k.d_index + d0[s]; }
+  }
+  out[i] = best;
+}
+
+int gacq_merge_peaks_dev(gacq_ctx* ctx, const void* d_peaks, int nshard, const int* shard_d0, long n, void* d_out) {
+  if (!ctx || !d_peaks || !d_out || !shard_d0 || nshard <= 0 || nshard > 4096 || n <= 0)
+    return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_merge_peaks_dev: bad argument");
+  GACQ_HIP(ctx, hipSetDevice(ctx->device));
+  const void* d0_before = ctx->d0.p;
+  int rc = ensure(ctx, ctx->d0, sizeof(int) * 4096);
+  if (rc != GACQ_OK) return rc;
+  if (d0_before != ctx->d0.p) ctx->up_d0.clear();
+  const std::vector<int> d0_v(shard_d0, shard_d0 + nshard);
+  if (d0_v != ctx->up_d0) {
+    GACQ_HIP(ctx, hipMemcpyAsync(ctx->d0.p, shard_d0, sizeof(int) * nshard, hipMemcpyHostToDevice, ctx->stream));
+    GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->up_d0 = d0_v;
+  }
+  hipLaunchKernelGGL(merge_peaks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const gacq_peak*)d_peaks,
+                     (gacq_peak*)d_out, n, nshard, (const int*)ctx->d0.p);
+  GACQ_HIP(ctx, hipGetLastError());
+  return GACQ_OK;
+}
+
+int gacq_finalize(const gacq_sigdesc* desc, const gacq_peak* peaks, int nshard, const int* shard_d0, int nitems,
                   const double* dopplers, int nd, gacq_result* out) {
-  if (!sig || !peaks || !out || nshard <= 0 || nitems <= 0 || (nd > 0 && !dopplers))
-    return set_error(sig ? sig->ctx : nullptr, GACQ_ERR_BAD_ARG, "gacq_finalize: bad argument");
-  const gacq_sigdesc& d = sig->desc;
+  if (!desc || !peaks || !out || nshard <= 0 || nitems <= 0 || (nd > 0 && !dopplers) || desc->n <= 0)
+    return set_error(nullptr, GACQ_ERR_BAD_ARG, "gacq_finalize: bad argument");
+  const gacq_sigdesc& d = *desc;
   for (int p = 0; p < nitems; p++) {
     double best = 0.0;
     int bidx = -1, bd = -1;
@@ -678,7 +720,7 @@ int gacq_search(gacq_sig* sig, const float* x_iq, size_t nsamp, const int* items
   std::vector<gacq_peak> peaks(nitems);
   GACQ_HIP(ctx, hipMemcpyAsync(peaks.data(), ctx->out_peaks.p, sizeof(gacq_peak) * nitems, hipMemcpyDeviceToHost, ctx->stream));
   GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return gacq_finalize(sig, peaks.data(), 1, nullptr, nitems, dopplers, nd, out);
+  return gacq_finalize(&sig->desc, peaks.data(), 1, nullptr, nitems, dopplers, nd, out);
 }
 
 int gacq_debug_row(gacq_sig* sig, const float* x_iq, size_t nsamp, int item, double doppler, double bias_hz, int blocks,

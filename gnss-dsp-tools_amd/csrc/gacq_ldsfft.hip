@@ -17,6 +17,7 @@
 #include "gacq_common.h"
 
 #include <cmath>
+#include <cstdlib>
 
 using namespace gacq;
 
@@ -27,67 +28,98 @@ constexpr int kLdsN = 4096;            // supported length (this round)
 constexpr int kPitch = 257;            // exchange-2 row pitch in complex elements
 constexpr int kLdsElems = 16 * kPitch; // 4112 complex = 32.9 KB -> 4 workgroups per CU
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-// multiply by -i (forward) or +i (inverse)
-template <bool INV> __device__ __forceinline__ float2 rot90(float2 a) { return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x); }
+// Complex arithmetic on packed-f32 VALU ops.  A complex value is one 64-bit VGPR pair (re, im);
+// v_pk_{add,mul,fma}_f32 process both halves per lane, and their op_sel / neg modifiers give the
+// swaps and sign flips of complex products for free.  hipcc does not find these forms on its own
+// (it emits 3-4 instructions + v_mov per complex multiply), hence the one-instruction asm wrappers.
+typedef float v2 __attribute__((ext_vector_type(2)));
 
-template <bool INV> __device__ __forceinline__ void dft4(float2& a, float2& b, float2& c, float2& d) {
-  const float2 s0 = cadd(a, c), d0 = csub(a, c), s1 = cadd(b, d), d1 = rot90<INV>(csub(b, d));
-  a = cadd(s0, s1);
-  c = csub(s0, s1);
-  b = cadd(d0, d1);
-  d = csub(d0, d1);
+// a + i*b = (a.re - b.im, a.im + b.re)
+__device__ __forceinline__ v2 add_i(v2 a, v2 b) {
+  v2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// a - i*b = (a.re + b.im, a.im - b.re)
+__device__ __forceinline__ v2 sub_i(v2 a, v2 b) {
+  v2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// a*b: t = (-a.im*b.im, a.im*b.re); r = (a.re*b.re + t.lo, a.re*b.im + t.hi)
+__device__ __forceinline__ v2 cmul(v2 a, v2 b) {
+  v2 t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]" : "=v"(t) : "v"(a), "v"(b));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+  return r;
+}
+// a*w with w a compile-time constant held in an SGPR pair (one constant-bus operand per instruction)
+__device__ __forceinline__ v2 cmul_k(v2 a, v2 w) {
+  v2 t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]" : "=v"(t) : "v"(a), "s"(w));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "s"(w), "v"(t));
+  return r;
 }
 
-// multiply by W16^m (forward: exp(-2 pi i m/16); inverse: conjugate), m compile-time
-template <bool INV, int M> __device__ __forceinline__ float2 tw16(float2 a) {
+// 4-point DFT, forward W4 = -i (INV: +i).  ROTC: input c still needs its W16^4 = -/+i factor (folded into the adds).
+template <bool INV, bool ROTC> __device__ __forceinline__ void dft4(v2& a, v2& b, v2& c, v2& d) {
+  v2 s0, d0;
+  if (ROTC) {
+    s0 = INV ? add_i(a, c) : sub_i(a, c);
+    d0 = INV ? sub_i(a, c) : add_i(a, c);
+  } else {
+    s0 = a + c;
+    d0 = a - c;
+  }
+  const v2 s1 = b + d, t = b - d;
+  a = s0 + s1;
+  c = s0 - s1;
+  b = INV ? add_i(d0, t) : sub_i(d0, t);
+  d = INV ? sub_i(d0, t) : add_i(d0, t);
+}
+
+// W16^m as (re, im): forward exp(-2 pi i m/16), inverse the conjugate
+template <bool INV, int M> __device__ __forceinline__ v2 w16() {
   constexpr float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
-  constexpr int m = M & 15;
-  if (m == 0) return a;
-  float wr, wi;   // forward twiddle = wr - i*wi
-  if (m == 1) { wr = c1; wi = s1; }
-  else if (m == 2) { wr = h; wi = h; }
-  else if (m == 3) { wr = s1; wi = c1; }
-  else if (m == 4) { return rot90<INV>(a); }
-  else if (m == 6) { wr = -h; wi = h; }
-  else if (m == 9) { wr = -c1; wi = -s1; }
-  else { wr = 0.f; wi = 0.f; }
-  const float im = INV ? wi : -wi;
-  return make_float2(a.x * wr - a.y * im, a.x * im + a.y * wr);
+  constexpr float re = (M == 1) ? c1 : (M == 2) ? h : (M == 3) ? s1 : (M == 6) ? -h : (M == 9) ? -c1 : 0.f;
+  constexpr float im = (M == 1) ? s1 : (M == 2) ? h : (M == 3) ? c1 : (M == 6) ? h : (M == 9) ? -s1 : 0.f;
+  v2 w = {re, INV ? im : -im};
+  return w;
 }
 
 // In-place 16-point DFT. Input v[n], n = 0..15; output X[k] is left in register v[4*(k&3) + (k>>2)]
-// (base-4 digit reversal) -- callers index outputs through rev16().
+// (base-4 digit reversal) -- callers index outputs through rev16().  64 + 16 packed instructions.
 __device__ __forceinline__ constexpr int rev16(int k) { return 4 * (k & 3) + (k >> 2); }
 
-template <bool INV> __device__ __forceinline__ void dft16(float2 (&v)[kR]) {
+template <bool INV> __device__ __forceinline__ void dft16(v2 (&v)[kR]) {
 #pragma unroll
-  for (int n0 = 0; n0 < 4; n0++) dft4<INV>(v[n0], v[n0 + 4], v[n0 + 8], v[n0 + 12]);   // -> A[n0][k0] at v[n0+4k0]
-  v[5] = tw16<INV, 1>(v[5]);   v[9] = tw16<INV, 2>(v[9]);   v[13] = tw16<INV, 3>(v[13]);
-  v[6] = tw16<INV, 2>(v[6]);   v[10] = tw16<INV, 4>(v[10]); v[14] = tw16<INV, 6>(v[14]);
-  v[7] = tw16<INV, 3>(v[7]);   v[11] = tw16<INV, 6>(v[11]); v[15] = tw16<INV, 9>(v[15]);
-#pragma unroll
-  for (int k0 = 0; k0 < 4; k0++) dft4<INV>(v[4 * k0], v[4 * k0 + 1], v[4 * k0 + 2], v[4 * k0 + 3]);   // -> X[k0+4k1] at v[4k0+k1]
+  for (int n0 = 0; n0 < 4; n0++) dft4<INV, false>(v[n0], v[n0 + 4], v[n0 + 8], v[n0 + 12]);   // -> A[n0][k0] at v[n0+4k0]
+  v[5] = cmul_k(v[5], w16<INV, 1>());   v[9] = cmul_k(v[9], w16<INV, 2>());   v[13] = cmul_k(v[13], w16<INV, 3>());
+  v[6] = cmul_k(v[6], w16<INV, 2>());   /* v[10]: W16^4 folded into dft4<ROTC> */ v[14] = cmul_k(v[14], w16<INV, 6>());
+  v[7] = cmul_k(v[7], w16<INV, 3>());   v[11] = cmul_k(v[11], w16<INV, 6>()); v[15] = cmul_k(v[15], w16<INV, 9>());
+  dft4<INV, false>(v[0], v[1], v[2], v[3]);
+  dft4<INV, false>(v[4], v[5], v[6], v[7]);
+  dft4<INV, true>(v[8], v[9], v[10], v[11]);
+  dft4<INV, false>(v[12], v[13], v[14], v[15]);                                               // -> X[k0+4k1] at v[4k0+k1]
 }
 
 // v[rev16(k)] *= w^k for k = 1..15, powers built with multiplication depth <= 4 from the table value.
-__device__ __forceinline__ void apply_powers(float2 (&v)[kR], float2 w1) {
-  const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
-  const float2 w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3), w8 = cmul(w4, w4);
-  const float2 w9 = cmul(w8, w1), w10 = cmul(w5, w5), w11 = cmul(w8, w3), w12 = cmul(w6, w6);
-  const float2 w13 = cmul(w8, w5), w14 = cmul(w7, w7), w15 = cmul(w8, w7);
+__device__ __forceinline__ void apply_powers(v2 (&v)[kR], v2 w1) {
+  const v2 w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
   v[rev16(1)] = cmul(v[rev16(1)], w1);    v[rev16(2)] = cmul(v[rev16(2)], w2);    v[rev16(3)] = cmul(v[rev16(3)], w3);
+  const v2 w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3), w8 = cmul(w4, w4);
   v[rev16(4)] = cmul(v[rev16(4)], w4);    v[rev16(5)] = cmul(v[rev16(5)], w5);    v[rev16(6)] = cmul(v[rev16(6)], w6);
-  v[rev16(7)] = cmul(v[rev16(7)], w7);    v[rev16(8)] = cmul(v[rev16(8)], w8);    v[rev16(9)] = cmul(v[rev16(9)], w9);
-  v[rev16(10)] = cmul(v[rev16(10)], w10); v[rev16(11)] = cmul(v[rev16(11)], w11); v[rev16(12)] = cmul(v[rev16(12)], w12);
+  v[rev16(7)] = cmul(v[rev16(7)], w7);
+  const v2 w9 = cmul(w8, w1), w10 = cmul(w5, w5), w11 = cmul(w8, w3), w12 = cmul(w6, w6);
+  v[rev16(8)] = cmul(v[rev16(8)], w8);    v[rev16(9)] = cmul(v[rev16(9)], w9);    v[rev16(10)] = cmul(v[rev16(10)], w10);
+  v[rev16(11)] = cmul(v[rev16(11)], w11); v[rev16(12)] = cmul(v[rev16(12)], w12);
+  const v2 w13 = cmul(w8, w5), w14 = cmul(w7, w7), w15 = cmul(w8, w7);
   v[rev16(13)] = cmul(v[rev16(13)], w13); v[rev16(14)] = cmul(v[rev16(14)], w14); v[rev16(15)] = cmul(v[rev16(15)], w15);
 }
 
 // Length-4096 transform of the 16 values per lane. In: v[j] = x[t + 256 j]; out: v[rev16(k2)] = X[t + 256 k2].
 // wa = W_4096^t, wb = W_256^(t & 15) (forward values; conjugated here when INV).
-template <bool INV> __device__ __forceinline__ void fft4096(float2 (&v)[kR], float2* lds, float2 wa, float2 wb) {
+template <bool INV> __device__ __forceinline__ void fft4096(v2 (&v)[kR], v2* lds, v2 wa, v2 wb) {
   const int t = threadIdx.x;
   if (INV) { wa.y = -wa.y; wb.y = -wb.y; }
   dft16<INV>(v);
@@ -114,12 +146,14 @@ template <bool INV> __device__ __forceinline__ void fft4096(float2 (&v)[kR], flo
   dft16<INV>(v);
 }
 
+__device__ __forceinline__ v2 ld2(const float2* p) { return *reinterpret_cast<const v2*>(p); }
+
 // ---- forward: one workgroup per (e, f, d, b) row -------------------------------------------------
 __global__ __launch_bounds__(kBlock) void lds_forward_kernel(const float2* __restrict__ x, size_t epoch_stride,
                                                               float2* __restrict__ X, const double* __restrict__ freq,
                                                               const float2* __restrict__ nco_tab,
                                                               const float2* __restrict__ tw, int n, int FD, int B) {
-  __shared__ float2 lds[kLdsElems];
+  __shared__ v2 lds[kLdsElems];
   const int t = threadIdx.x;
   const long row = blockIdx.x;            // ((e*FD + fd)*B + b)
   const int b = (int)(row % B);
@@ -128,30 +162,37 @@ __global__ __launch_bounds__(kBlock) void lds_forward_kernel(const float2* __res
   const long e = r2 / FD;
   const double f = freq[fd];
   const float2* src = x + e * epoch_stride + (size_t)b * n;
-  float2 v[kR];
+  v2 v[kR];
 #pragma unroll
   for (int j = 0; j < kR; j++) {
     const int i = t + 256 * j;
-    const float2 s = src[i];
+    const v2 s = ld2(src + i);
     // table NCO, index in fp64 exactly as numpy: floor((0 + f*i)*1024) mod 1024   (gnsstools/nco.py:6-9)
     const long k = (long)floor(__dmul_rn(__dmul_rn(f, (double)i), 1024.0)) & (kNcoTableSize - 1);
-    v[j] = cmul(s, nco_tab[k]);
+    v[j] = cmul(s, ld2(nco_tab + k));
   }
-  fft4096<false>(v, lds, tw[t], tw[16 * (t & 15)]);
+  fft4096<false>(v, lds, ld2(tw + t), ld2(tw + 16 * (t & 15)));
   float2* dst = X + row * (long)kLdsN;
 #pragma unroll
   for (int k = 0; k < kR; k++) {
-    const float2 o = v[rev16(k)];
+    const v2 o = v[rev16(k)];
     dst[t + 256 * k] = make_float2(o.x, -o.y);       // store conj(FFT): np.conj(fft.fft(b))  acquire-gps-l1.py:32
   }
 }
 
 // ---- correlate: workgroup = (epoch, doppler, chunk of items); epochs pinned to XCDs ---------------
-__global__ __launch_bounds__(kBlock) void lds_correlate_kernel(const float2* __restrict__ X, const float2* __restrict__ C,
-                                                                const int* __restrict__ items, const int* __restrict__ fset,
-                                                                const float2* __restrict__ tw, RowRec* __restrict__ rows,
-                                                                int E, int P, int F, int D, int B, int pch, int nchunk) {
-  __shared__ float2 lds[kLdsElems];
+// Template knobs (register budget vs occupancy, see DESIGN.md "LDS engine tuning"):
+//   MINW    __launch_bounds__ waves per SIMD (4 -> <=128 VGPRs -> 4 workgroups/CU, the LDS limit)
+//   B1      single block (B == 1): no q[] accumulator, magnitudes are reduced as they are produced
+//   CACHEX  B1 only: keep the forward spectrum X[e,d] in registers across the item loop (halves L2 reads)
+//   OPAQUE  recompute the twiddle powers w^1..w^15 per pass instead of letting the compiler hoist all
+//           2 x 15 of them out of the item loop (60 VGPRs that would cost two waves of occupancy)
+template <int MINW, bool B1, bool CACHEX, bool OPAQUE>
+__global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float2* __restrict__ X, const float2* __restrict__ C,
+                                                                      const int* __restrict__ items, const int* __restrict__ fset,
+                                                                      const float2* __restrict__ tw, RowRec* __restrict__ rows,
+                                                                      int E, int P, int F, int D, int B, int pch, int nchunk) {
+  __shared__ v2 lds[kLdsElems];
   __shared__ float s_peak[kBlock / 64];
   __shared__ int s_idx[kBlock / 64];
   __shared__ double s_sum[kBlock / 64];
@@ -168,34 +209,70 @@ __global__ __launch_bounds__(kBlock) void lds_correlate_kernel(const float2* __r
   const int d = rem / nchunk;
   const int p0 = (rem % nchunk) * pch;
   const int p1 = min(P, p0 + pch);
-  const float2 wa = tw[t], wb = tw[16 * (t & 15)];
+  v2 wa = ld2(tw + t), wb = ld2(tw + 16 * (t & 15));
   const float inv_n = 1.0f / (float)kLdsN;
+  v2 xr[(B1 && CACHEX) ? kR : 1];
+  if (B1 && CACHEX) {
+    const float2* xs = X + (((e * F + fset[p0]) * D + d) * (long)B) * kLdsN;      // F == 1 whenever items share a set
+#pragma unroll
+    for (int jj = 0; jj < kR; jj++) xr[jj] = ld2(xs + t + 256 * jj);
+  }
   for (int p = p0; p < p1; p++) {
     const float2* cs = C + (long)items[p] * kLdsN;
     const float2* xs = X + (((e * F + fset[p]) * D + d) * (long)B) * kLdsN;
-    float q[kR];
+    float peak, sum_f = 0.f;
+    int idx;
+    float q[B1 ? 1 : kR];
+    if (!B1) {
 #pragma unroll
-    for (int k = 0; k < kR; k++) q[k] = 0.f;
-    for (int b = 0; b < B; b++) {
-      float2 v[kR];
+      for (int k = 0; k < kR; k++) q[k] = 0.f;
+    }
+    const int nb = B1 ? 1 : B;
+    for (int b = 0; b < nb; b++) {
+      if (OPAQUE) asm volatile("" : "+v"(wa.x), "+v"(wa.y), "+v"(wb.x), "+v"(wb.y));
+      v2 v[kR];
+      if (B1 && CACHEX) {
 #pragma unroll
-      for (int jj = 0; jj < kR; jj++) v[jj] = cmul(cs[t + 256 * jj], xs[(long)b * kLdsN + t + 256 * jj]);
-      if (b > 0 || p > p0) __syncthreads();   // previous transform's exchange-2 reads are complete
+        for (int jj = 0; jj < kR; jj++) v[jj] = cmul(ld2(cs + t + 256 * jj), xr[jj]);
+      } else {
+#pragma unroll
+        for (int jj = 0; jj < kR; jj++) v[jj] = cmul(ld2(cs + t + 256 * jj), ld2(xs + (long)b * kLdsN + t + 256 * jj));
+      }
+      if (!B1 && b > 0) __syncthreads();   // previous transform's exchange-2 reads are complete
       fft4096<true>(v, lds, wa, wb);
+      if (B1) {
+        // (max, first argmax, sum) straight from the transform output; lane holds lags t + 256 k
+        const v2 r0 = v[rev16(0)];
+        peak = __builtin_amdgcn_sqrtf(r0.x * r0.x + r0.y * r0.y) * inv_n;      // np.absolute(ifft(...)), 1/N folded in
+        idx = t;
+        sum_f = peak;
 #pragma unroll
-      for (int k = 0; k < kR; k++) {
-        const float2 r = v[rev16(k)];
-        q[k] += sqrtf(r.x * r.x + r.y * r.y) * inv_n;     // np.absolute(ifft(...)), 1/N of ifft folded in
+        for (int k = 1; k < kR; k++) {
+          const v2 r = v[rev16(k)];
+          const float m = __builtin_amdgcn_sqrtf(r.x * r.x + r.y * r.y) * inv_n;
+          if (m > peak) { peak = m; idx = t + 256 * k; }
+          sum_f += m;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < kR; k++) {
+          const v2 r = v[rev16(k)];
+          q[k] += __builtin_amdgcn_sqrtf(r.x * r.x + r.y * r.y) * inv_n;
+        }
       }
     }
-    // (max, first argmax, sum) over the 4096 lags; lane holds lags t + 256 k
-    float peak = q[0];
-    int idx = t;
-    double sum = (double)q[0];
+    double sum;
+    if (B1) {
+      sum = (double)sum_f;                     // 16 addends of equal scale: fp32 partial, fp64 from here on
+    } else {
+      peak = q[0];
+      idx = t;
+      sum = (double)q[0];
 #pragma unroll
-    for (int k = 1; k < kR; k++) {
-      if (q[k] > peak) { peak = q[k]; idx = t + 256 * k; }
-      sum += (double)q[k];
+      for (int k = 1; k < kR; k++) {
+        if (q[k] > peak) { peak = q[k]; idx = t + 256 * k; }
+        sum += (double)q[k];
+      }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -206,7 +283,7 @@ __global__ __launch_bounds__(kBlock) void lds_correlate_kernel(const float2* __r
       sum += os;
     }
     if ((t & 63) == 0) { s_peak[t >> 6] = peak; s_idx[t >> 6] = idx; s_sum[t >> 6] = sum; }
-    __syncthreads();
+    __syncthreads();   // also orders this item's exchange-2 reads before the next item's exchange-1 writes
     if (t == 0) {
       for (int w = 1; w < kBlock / 64; w++) {
         if (s_peak[w] > peak || (s_peak[w] == peak && s_idx[w] < idx)) { peak = s_peak[w]; idx = s_idx[w]; }
@@ -220,6 +297,22 @@ __global__ __launch_bounds__(kBlock) void lds_correlate_kernel(const float2* __r
     }
   }
 }
+
+typedef void (*CorrKernel)(const float2*, const float2*, const int*, const int*, const float2*, RowRec*, int, int, int, int, int, int, int);
+
+struct CorrVariant { const char* name; CorrKernel b1; CorrKernel bn; };
+
+// variant table; index chosen by GACQ_LDS_VARIANT (tuning aid), default = kDefaultVariant
+const CorrVariant kVariants[] = {
+  {"w1-hoist", lds_correlate_kernel<1, true, false, false>, lds_correlate_kernel<1, false, false, false>},
+  {"w2-hoist-cachex", lds_correlate_kernel<2, true, true, false>, lds_correlate_kernel<2, false, false, false>},
+  {"w4-opaque-cachex", lds_correlate_kernel<4, true, true, true>, lds_correlate_kernel<4, false, false, true>},
+  {"w4-opaque", lds_correlate_kernel<4, true, false, true>, lds_correlate_kernel<4, false, false, true>},
+  {"w3-opaque-cachex", lds_correlate_kernel<3, true, true, true>, lds_correlate_kernel<3, false, false, true>},
+  {"w2-opaque-cachex", lds_correlate_kernel<2, true, true, true>, lds_correlate_kernel<2, false, false, true>},
+};
+constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
+constexpr int kDefaultVariant = 2;
 
 DevBuf g_tw[16];   // per-device W_4096 table
 
@@ -270,8 +363,13 @@ int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const i
   const int nchunk = (nitems + pch - 1) / pch;
   const long ex = (nepoch + 7) / 8;
   const long grid = 8 * ex * D * nchunk;
-  hipLaunchKernelGGL(lds_correlate_kernel, dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, X, spectra, d_items, d_fset, tw,
-                     rows, nepoch, nitems, F, D, B, pch, nchunk);
+  int variant = kDefaultVariant;
+  if (const char* ev = getenv("GACQ_LDS_VARIANT")) { const int k = atoi(ev); if (k >= 0 && k < kNumVariants) variant = k; }
+  // register-cached X needs all items of a workgroup to share one forward set
+  const bool b1 = (B == 1) && (F == 1);
+  CorrKernel kern = b1 ? kVariants[variant].b1 : kVariants[variant].bn;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, X, spectra, d_items, d_fset, tw, rows, nepoch,
+                     nitems, F, D, B, pch, nchunk);
   GACQ_HIP(ctx, hipGetLastError());
   return GACQ_OK;
 }

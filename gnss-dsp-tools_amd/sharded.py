@@ -1,0 +1,76 @@
+"""PRN x Doppler grid sharded over one-process-per-GPU ranks (torch.distributed; backend "nccl" is
+RCCL over xGMI on ROCm, "gloo" in the CPU tests).
+
+The reference's only parallelism is one task per PRN through multiprocessing.Pool
+(acquire-gps-l1.py:105-108).  Here every (PRN, Doppler) row is independent, so the Doppler grid is
+cut into contiguous slices, one per rank: forward FFTs are not duplicated and every rank keeps all
+code spectra.  The path has exactly ONE exchange step: an all-gather of the per-rank peak records
+(16 B per (epoch, PRN)), followed by a merge that scans the shards in global Doppler order with
+strict '>' so ties resolve to the lowest Doppler bin exactly like the reference's scan
+(acquire-gps-l1.py:36-39).  A plain max all-reduce would lose that tie rule.
+"""
+import numpy as np
+
+from . import acquire
+
+
+def doppler_bounds(nd, world):
+    """Contiguous, balanced slices of the Doppler grid: rank r owns [b[r], b[r+1])."""
+    return [(r * nd) // world for r in range(world + 1)]
+
+
+class ShardedSearch:
+    def __init__(self, engine=None, group=None, local_fn=None):
+        """engine: acquire.Engine on this rank's GPU.  local_fn(name, x, items, dopplers_slice, blocks) ->
+        peaks tensor [nepoch, nitems, 2] float64 replaces the engine (CPU tests drive the exchange/merge
+        logic with it; the product path always passes an engine)."""
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.engine = engine
+        self.local_fn = local_fn
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def search_batch(self, name, x, items, dopplers, blocks):
+        """x: [nepoch, nsamp] complex64 tensor, identical on every rank (CUDA for the engine path).
+        Returns the merged peaks tensor [nepoch, nitems, 2] (gacq_peak records, global Doppler index)
+        on every rank."""
+        import torch
+        dopplers = np.ascontiguousarray(dopplers, dtype=np.float64)
+        b = doppler_bounds(len(dopplers), self.world)
+        lo, hi = b[self.rank], b[self.rank + 1]
+        if self.local_fn is not None:
+            local = self.local_fn(name, x, items, dopplers[lo:hi], blocks)
+        else:
+            local = self.engine.search_batch_dev(name, x, items, dopplers[lo:hi], blocks)
+        if self.world == 1:
+            return local
+        flat = local.contiguous().view(-1)
+        gathered = torch.empty(self.world * flat.numel(), dtype=local.dtype, device=local.device)
+        self.dist.all_gather_into_tensor(gathered, flat, group=self.group)                  # the ONE collective
+        gathered = gathered.view((self.world,) + tuple(local.shape))
+        if gathered.is_cuda:
+            return self.engine.merge_peaks_dev(gathered, b[:-1])
+        return merge_peaks_host(gathered.numpy(), b[:-1])
+
+    def results(self, name, items, merged, dopplers):
+        """Merged peaks -> per-epoch lists of the reference's (metric, code, doppler) tuples."""
+        pk = merged.cpu().numpy() if hasattr(merged, "cpu") else np.asarray(merged)
+        pk = pk.view(acquire.PEAK_DTYPE).reshape(-1, len(items))
+        return [acquire.finalize(name, items, pk[e], dopplers) for e in range(pk.shape[0])]
+
+
+def merge_peaks_host(gathered, shard_d0):
+    """numpy form of gacq_merge_peaks_dev for CPU tensors: [nshard, nepoch, nitems, 2] -> [nepoch, nitems, 2]."""
+    import torch
+    g = np.ascontiguousarray(gathered).view(acquire.PEAK_DTYPE).reshape(gathered.shape[0], -1)
+    out = np.zeros(g.shape[1], dtype=acquire.PEAK_DTYPE)
+    out["idx"] = -1
+    out["d_index"] = -1
+    for s in range(g.shape[0]):
+        win = (g[s]["d_index"] >= 0) & (g[s]["metric"] > out["metric"])       # strict '>' in shard order
+        out["metric"][win] = g[s]["metric"][win]
+        out["idx"][win] = g[s]["idx"][win]
+        out["d_index"][win] = g[s]["d_index"][win] + shard_d0[s]
+    return torch.from_numpy(out.view(np.float64).reshape(gathered.shape[1:]).copy())

@@ -126,10 +126,17 @@ int gacq_search_batch_dev(gacq_sig* sig, const void* d_x, size_t nsamp, int nepo
                           const int* items, int nitems, const double* dopplers, int nd,
                           const double* item_bias_hz, int blocks, void* d_out);
 
+/* Device-side shard merge: d_peaks [nshard][n] (as gathered from the ranks, shard s covering Doppler
+ * indices from shard_d0[s]) -> d_out [n] with global d_index; shards scanned in order with strict '>'
+ * so the lowest Doppler bin wins ties exactly like the reference's scan (acquire-gps-l1.py:36-39).
+ * Asynchronous on the ctx stream. */
+int gacq_merge_peaks_dev(gacq_ctx* ctx, const void* d_peaks, int nshard, const int* shard_d0, long n,
+                         void* d_out);
+
 /* Host-side last step (acquire-gps-l1.py:36-40): merge `nshard` peaks per item in shard order with
  * strict '>' (shard s covers Doppler indices [shard_d0[s], ...)), then convert to the reference's
- * return tuple.  peaks: [nshard][nitems]; dopplers: the FULL grid. */
-int gacq_finalize(const gacq_sig* sig, const gacq_peak* peaks, int nshard, const int* shard_d0,
+ * return tuple.  peaks: [nshard][nitems]; dopplers: the FULL grid.  Needs no GPU. */
+int gacq_finalize(const gacq_sigdesc* desc, const gacq_peak* peaks, int nshard, const int* shard_d0,
                   int nitems, const double* dopplers, int nd, gacq_result* out);
 
 /* Per-stage GPU time from HIP events recorded on the launch stream (profiling aid for bench.py).

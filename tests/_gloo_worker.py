@@ -1,0 +1,59 @@
+"""One rank of the CPU (gloo) sharded-search test; launched by tests/test_sharded_gloo.py.
+usage: _gloo_worker.py <out.json> <name> <items csv> <doppler csv> <ms>   (RANK/WORLD_SIZE/MASTER_* in env)"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def oracle_local(name, x, items, dopplers, blocks):
+    """Per-rank stand-in for Engine.search_batch_dev built on the oracle: best over the local Doppler slice."""
+    from gnss_dsp_tools_amd import acquire
+    from oracle import acq_oracle, codes_oracle
+    code, fs, n, pad, boc, norm, _fold, _b, bias = acq_oracle.VARIANTS[name]
+    xs = x.numpy().astype(np.complex128)
+    out = np.zeros((xs.shape[0], len(items)), dtype=acquire.PEAK_DTYPE)
+    out["idx"] = -1
+    out["d_index"] = -1
+    for e in range(xs.shape[0]):
+        for p, it in enumerate(items):
+            chips = codes_oracle.chips(code, 0 if bias else it)
+            for k, dop in enumerate(dopplers):
+                q = acq_oracle.search_row(xs[e], chips, dop, blocks, fs=fs, n=n, pad=pad, boc=boc, bias_hz=bias * it)
+                i = int(np.argmax(q))
+                m = q[i] / np.mean(q) if norm else q[i]
+                if m > out[e, p]["metric"]:
+                    out[e, p] = (m, i, k)
+    return torch.from_numpy(out.view(np.float64).reshape(xs.shape[0], len(items), 2).copy())
+
+
+def main():
+    out_path, name = sys.argv[1], sys.argv[2]
+    items = [int(v) for v in sys.argv[3].split(",")]
+    ds = [float(v) for v in sys.argv[4].split(",")]
+    ms = int(sys.argv[5])
+    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    try:
+        from gnss_dsp_tools_amd import acquire, sharded, signals, synth
+        sig = signals.get(name)
+        blocks = sig.blocks(ms)
+        dop = acquire.doppler_grid(ds)
+        xs = synth.make_epochs(sig, blocks, 5150, [(items[0], 0.4, 1537.0, 1201)], 2)
+        sh = sharded.ShardedSearch(engine=None, local_fn=oracle_local)
+        merged = sh.search_batch(name, torch.from_numpy(xs), items, dop, blocks)
+        res = sh.results(name, items, merged, dop)
+        if dist.get_rank() == 0:
+            with open(out_path, "w") as f:
+                json.dump([[[float(v) for v in r] for r in ep] for ep in res], f)
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -239,9 +239,10 @@ def test_full_size_properties_config2(engine):
         if amp < 0.25:
             continue
         # the NCO phase restarts at the block start, so a circular shift of x only adds a constant carrier
-        # phase: the correlation peak moves by exactly -s lags (mod 4096) and stays in the same Doppler bin
+        # phase: the correlation peak moves by exactly -s lags (mod 4096); the injected Dopplers sit between two
+        # bins, so the winning bin may flip to its neighbour (different noise after the wrap), never further
         assert np.all((shifted["idx"][:, c] - base["idx"][:, c]) % 4096 == (-s) % 4096), it
-        assert np.all(shifted["d_index"][:, c] == base["d_index"][:, c]), it
+        assert np.all(np.abs(shifted["d_index"][:, c] - base["d_index"][:, c]) <= 1), it
     np.testing.assert_array_equal(scaled["idx"], base["idx"])
     np.testing.assert_array_equal(scaled["d_index"], base["d_index"])
     np.testing.assert_allclose(scaled["metric"], base["metric"], rtol=2e-6)
