@@ -182,6 +182,14 @@ def main():
                 "model": "stage-boundary A_pipe share of this kernel (SURVEY.md 8d); fused kernels keep stage boundaries in LDS, "
                          "so achieved can exceed what HBM alone could deliver -- see traffic for measured HBM bytes"}
 
+    # the fused LDS kernel is VALU-bound: useful FP32 work vs the 157.3 TFLOP/s vector peak (MI355X_MICROARCH.md)
+    valu = None
+    if dominant == "lds_correlate":
+        rows_launch = E_total * P * D_local * B / dk["launches_per_step"]
+        flops = rows_launch * (5.0 * N * np.log2(N) + 6.0 * N + 4.0 * N)     # inverse FFT + C*X + |.|
+        valu = {"useful_flop_per_launch": flops, "achieved_TFLOPs": flops / (dk["avg_ms"] * 1e-3) / 1e12, "peak_TFLOPs": 157.3,
+                "frac": flops / (dk["avg_ms"] * 1e-3) / 1e12 / 157.3}
+
     out = None
     if rank == 0:
         a_pipe_step = a_pipe_bytes(N, P, D, B) * E_total
@@ -204,6 +212,7 @@ def main():
                        "cells_per_step": cells_step, "sharding": "doppler-slice x%d + 1 all-gather of peaks" % world,
                        "engine": {0: "auto", 1: "rocfft", 2: "lds-fft"}[args.engine]},
             "roofline": roofline,
+            "valu": valu,
             "pipeline": {"a_pipe_bytes_per_step": a_pipe_step, "achieved_GBps": a_pipe_step / (dt / args.steps) / 1e9,
                          "frac_of_8TBps": a_pipe_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS,
                          "us_per_search": dt / args.steps / E_total * 1e6, "stages": per_stage},
