@@ -1,0 +1,83 @@
+"""Command-line shim with the argument surface and output lines of the reference's acquire scripts:
+
+    python -m gnss_dsp_tools_amd.cli gps-l1 [--prn 1-32] [--doppler-search MIN,MAX,INCR] [--time MS] FILE FS COFFSET
+    python -m gnss_dsp_tools_amd.cli glonass-l1 [--channel -7:7] ... FILE FS COFFSET
+
+== acquire-gps-l1.py:46-111 (options, positionals, one result line per item in input order).  The search itself
+runs on the GPU (acquire.Engine.search_all replaces the multiprocessing.Pool over PRNs, :105-108)."""
+import argparse
+import sys
+
+from . import acquire, codes, frontend, signals
+
+
+def build_parser(sig):
+    ap = argparse.ArgumentParser(prog="acquire-%s" % sig.name, description="Acquire %s signals on MI355X" % sig.name)
+    ap.add_argument(sig.item_opt, dest="items", default=sig.default_items,
+                    help="items to search, e.g. 1,3,7%s14 (default %%(default)s)" % sig.item_sep)
+    ap.add_argument("--doppler-search", metavar="MIN,MAX,INCR", default=",".join("%g" % v for v in sig.default_doppler),
+                    help="Doppler search grid: min,max,increment (default %(default)s)")
+    ap.add_argument("--time", type=int, default=80, help="integration time in milliseconds (default %(default)s)")
+    ap.add_argument("--device", type=int, default=0, help="GPU index")
+    ap.add_argument("input_filename")
+    ap.add_argument("sample_rate", type=float)
+    ap.add_argument("carrier_offset", type=float)
+    return ap
+
+
+_VALUE_OPTS = ("--prn", "--channel", "--doppler-search", "--time", "--device")
+
+
+def _join_option_values(argv):
+    """optparse (the reference) accepts '--doppler-search -7000,7000,200' and '--channel -7:7'; argparse would take
+    the value for an option because it starts with '-'.  Rewrite 'opt value' as 'opt=value'."""
+    out, i = [], 0
+    while i < len(argv):
+        if argv[i] in _VALUE_OPTS and i + 1 < len(argv):
+            out.append(argv[i] + "=" + argv[i + 1])
+            i += 2
+        else:
+            out.append(argv[i])
+            i += 1
+    return out
+
+
+def run(name, argv, out=sys.stdout):
+    sig = signals.get(name)
+    args = build_parser(sig).parse_args(_join_option_values(list(argv)))
+    if args.items:
+        items = acquire.parse_list_ranges(args.items, sep=sig.item_sep)
+    else:
+        items = codes.prns(sig.code)            # acquire-beidou-b2bi.py:70: default = every PRN in the table
+    doppler_search = acquire.parse_list_floats(args.doppler_search)
+    ms = args.time
+    ms_pad = ms + 5                             # acquire-gps-l1.py:80
+    n = int(args.sample_rate * 0.001 * ms_pad)
+    with open(args.input_filename, "rb") as fp:
+        x = frontend.read_iq_int8(fp, n)
+    if x is None:
+        raise SystemExit("input file too short: need %d complex int8 samples" % n)
+    x = frontend.condition(x, args.sample_rate, args.carrier_offset, sig, ms_pad)
+    eng = acquire.Engine(args.device)
+    try:
+        results = eng.search_all(sig, x, items, doppler_search, ms)
+    finally:
+        eng.close()
+    lines = [acquire.format_result(sig, it, r) for it, r in zip(items, results)]
+    for line in lines:
+        print(line, file=out)
+    return lines
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if not argv or argv[0] in ("-h", "--help"):
+        print(__doc__)
+        print("signals:", ", ".join(sorted(signals.SIGNALS)))
+        return 0
+    run(argv[0], argv[1:])
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -63,7 +63,8 @@ struct gacq_sig {
   gacq_sigdesc desc{};
   int nprn = 0;
   int N = 0;                 // FFT length: n or 2n
-  float2* spectra = nullptr; // [nprn][N] code spectra C_p = fft(replica), complex64
+  float2* spectra = nullptr; // [nprn][N] code spectra C_p = fft(replica), complex64, natural order
+  float2* spectra_lds = nullptr;   // same in the LDS engine's lane-pair layout (only when lds_supported(N))
 };
 
 namespace gacq {
@@ -76,6 +77,7 @@ void stage_end(gacq_ctx* ctx);
 
 // LDS-resident FFT engine (gacq_ldsfft.hip): supported lengths and the two launches.
 bool lds_supported(int N);
+int lds_prepare_spectra(gacq_ctx* ctx, const float2* natural, float2* perm, int nprn, int N);
 // X[row][k] = conj(FFT_N(x_window * nco))   rows = ((e*F + f)*D + d)*B + b
 int lds_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n, int N, const double* d_freq,
                 int FD, int B, const float2* tab, float2* X);

@@ -411,8 +411,12 @@ static int build_signal(gacq_ctx* ctx, const gacq_sigdesc* desc, const std::vect
   if (hipMemcpyAsync(s->spectra, host.data(), bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
     rc = set_error(ctx, GACQ_ERR_HIP, "replica upload failed");
   if (rc == GACQ_OK) rc = fft_exec(ctx, s->N, nprn, false, s->spectra);     // c = fft.fft(c)   acquire-gps-l1.py:24
+  if (rc == GACQ_OK && lds_supported(s->N)) {
+    if (hipMalloc((void**)&s->spectra_lds, bytes) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "hipMalloc for LDS-layout spectra failed");
+    else rc = lds_prepare_spectra(ctx, s->spectra, s->spectra_lds, nprn, s->N);
+  }
   if (rc == GACQ_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "code spectrum FFT failed");
-  if (rc != GACQ_OK) { (void)hipFree(s->spectra); delete s; return rc; }
+  if (rc != GACQ_OK) { (void)hipFree(s->spectra); if (s->spectra_lds) (void)hipFree(s->spectra_lds); delete s; return rc; }
   *out = s;
   return GACQ_OK;
 }
@@ -456,6 +460,7 @@ void gacq_signal_destroy(gacq_sig* sig) {
   (void)hipSetDevice(sig->ctx->device);
   (void)hipStreamSynchronize(sig->ctx->stream);
   if (sig->spectra) (void)hipFree(sig->spectra);
+  if (sig->spectra_lds) (void)hipFree(sig->spectra_lds);
   delete sig;
 }
 
@@ -554,7 +559,7 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
       stage_end(ctx);
       if (rc != GACQ_OK) return rc;
       stage_begin(ctx, 6);
-      rc = lds_correlate(ctx, X, sig->spectra, (const int*)ctx->items.p, (const int*)ctx->fset.p, ne, P, F, D, B, N, rows);
+      rc = lds_correlate(ctx, X, sig->spectra_lds, (const int*)ctx->items.p, (const int*)ctx->fset.p, ne, P, F, D, B, N, rows);
       stage_end(ctx);
       if (rc != GACQ_OK) return rc;
     } else {

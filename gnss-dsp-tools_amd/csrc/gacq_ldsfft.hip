@@ -148,6 +148,23 @@ template <bool INV> __device__ __forceinline__ void fft4096(v2 (&v)[kR], v2* lds
 
 __device__ __forceinline__ v2 ld2(const float2* p) { return *reinterpret_cast<const v2*>(p); }
 
+// Lane-pair layout used for X and C_p inside this engine: natural index i = t + 256 j (t = lane, j = 0..15)
+// is stored at (j>>1)*512 + 2 t + (j&1), so one lane's values for j = 2jp, 2jp+1 are 16 contiguous bytes and
+// a wave reads/writes 1 KiB per instruction.  Rows are fetched with buffer loads: the row base lives in an
+// SGPR resource, the lane offset (16 t) in one VGPR, the piece offset in an SGPR -- no VALU address math.
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const float2* row) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, kLdsN * (int)sizeof(float2), 0x00020000);
+}
+// values j = 2jp (lo) and 2jp+1 (hi) of this lane
+__device__ __forceinline__ void ld_pair(__amdgpu_buffer_rsrc_t r, unsigned lane_off, int jp, v2& a, v2& b) {
+  const f4 q = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, (unsigned)jp * 4096u, 0));
+  a = q.xy;
+  b = q.zw;
+}
+
 // ---- forward: one workgroup per (e, f, d, b) row -------------------------------------------------
 __global__ __launch_bounds__(kBlock) void lds_forward_kernel(const float2* __restrict__ x, size_t epoch_stride,
                                                               float2* __restrict__ X, const double* __restrict__ freq,
@@ -174,9 +191,23 @@ __global__ __launch_bounds__(kBlock) void lds_forward_kernel(const float2* __res
   fft4096<false>(v, lds, ld2(tw + t), ld2(tw + 16 * (t & 15)));
   float2* dst = X + row * (long)kLdsN;
 #pragma unroll
-  for (int k = 0; k < kR; k++) {
-    const v2 o = v[rev16(k)];
-    dst[t + 256 * k] = make_float2(o.x, -o.y);       // store conj(FFT): np.conj(fft.fft(b))  acquire-gps-l1.py:32
+  for (int jp = 0; jp < kR / 2; jp++) {
+    const v2 a = v[rev16(2 * jp)], b = v[rev16(2 * jp + 1)];
+    // store conj(FFT) in the lane-pair layout: np.conj(fft.fft(b))  acquire-gps-l1.py:32
+    *reinterpret_cast<float4*>(dst + jp * 512 + 2 * t) = make_float4(a.x, -a.y, b.x, -b.y);
+  }
+}
+
+// natural -> lane-pair layout for the code spectra (once per signal)
+__global__ __launch_bounds__(kBlock) void lds_permute_kernel(const float2* __restrict__ nat, float2* __restrict__ perm) {
+  const long row = blockIdx.x;
+  const int t = threadIdx.x;
+  const float2* src = nat + row * kLdsN;
+  float2* dst = perm + row * kLdsN;
+#pragma unroll
+  for (int jp = 0; jp < kR / 2; jp++) {
+    const float2 a = src[t + 256 * (2 * jp)], b = src[t + 256 * (2 * jp + 1)];
+    *reinterpret_cast<float4*>(dst + jp * 512 + 2 * t) = make_float4(a.x, a.y, b.x, b.y);
   }
 }
 
@@ -197,28 +228,29 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float
   __shared__ int s_idx[kBlock / 64];
   __shared__ double s_sum[kBlock / 64];
   const int t = threadIdx.x;
-  // XCD-aware placement: workgroup b runs on XCD b%8 (MI355X_MICROARCH.md, workgroup dispatch), so give
-  // every epoch to one XCD: its forward spectra X[e] (D*B*32 KB) are then re-read by the P items from
-  // that XCD's own L2.
+  // XCD-aware placement: workgroup b runs on XCD b%8 (MI355X_MICROARCH.md, workgroup dispatch).  The unit of
+  // reuse is one (epoch, Doppler) pair u: its forward spectrum X[u] (B*32 KB) is read by all nchunk workgroups
+  // of that unit, so they are all placed on XCD u%8 and share that XCD's L2; the code spectra (P*32 KB) end
+  // up resident in every XCD's 4 MB L2.  Works for any E (a single-epoch search still fills all 8 XCDs).
   const int xcd = blockIdx.x & 7;
   const long j = blockIdx.x >> 3;
-  const long per_epoch = (long)D * nchunk;
-  const long e = (j / per_epoch) * 8 + xcd;
-  if (e >= E) return;
-  const int rem = (int)(j % per_epoch);
-  const int d = rem / nchunk;
-  const int p0 = (rem % nchunk) * pch;
+  const long u = (j / nchunk) * 8 + xcd;
+  if (u >= (long)E * D) return;
+  const long e = u / D;
+  const int d = (int)(u % D);
+  const int p0 = (int)(j % nchunk) * pch;
   const int p1 = min(P, p0 + pch);
   v2 wa = ld2(tw + t), wb = ld2(tw + 16 * (t & 15));
   const float inv_n = 1.0f / (float)kLdsN;
   v2 xr[(B1 && CACHEX) ? kR : 1];
+  const unsigned lane_off = (unsigned)t * 16u;
   if (B1 && CACHEX) {
-    const float2* xs = X + (((e * F + fset[p0]) * D + d) * (long)B) * kLdsN;      // F == 1 whenever items share a set
+    const __amdgpu_buffer_rsrc_t xres = row_rsrc(X + (((e * F + fset[p0]) * D + d) * (long)B) * kLdsN);   // F == 1 here
 #pragma unroll
-    for (int jj = 0; jj < kR; jj++) xr[jj] = ld2(xs + t + 256 * jj);
+    for (int jp = 0; jp < kR / 2; jp++) ld_pair(xres, lane_off, jp, xr[2 * jp], xr[2 * jp + 1]);
   }
   for (int p = p0; p < p1; p++) {
-    const float2* cs = C + (long)items[p] * kLdsN;
+    const __amdgpu_buffer_rsrc_t cres = row_rsrc(C + (long)items[p] * kLdsN);
     const float2* xs = X + (((e * F + fset[p]) * D + d) * (long)B) * kLdsN;
     float peak, sum_f = 0.f;
     int idx;
@@ -233,10 +265,22 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float
       v2 v[kR];
       if (B1 && CACHEX) {
 #pragma unroll
-        for (int jj = 0; jj < kR; jj++) v[jj] = cmul(ld2(cs + t + 256 * jj), xr[jj]);
+        for (int jp = 0; jp < kR / 2; jp++) {
+          v2 c0, c1;
+          ld_pair(cres, lane_off, jp, c0, c1);
+          v[2 * jp] = cmul(c0, xr[2 * jp]);
+          v[2 * jp + 1] = cmul(c1, xr[2 * jp + 1]);
+        }
       } else {
+        const __amdgpu_buffer_rsrc_t xres = row_rsrc(xs + (long)b * kLdsN);
 #pragma unroll
-        for (int jj = 0; jj < kR; jj++) v[jj] = cmul(ld2(cs + t + 256 * jj), ld2(xs + (long)b * kLdsN + t + 256 * jj));
+        for (int jp = 0; jp < kR / 2; jp++) {
+          v2 c0, c1, x0, x1;
+          ld_pair(cres, lane_off, jp, c0, c1);
+          ld_pair(xres, lane_off, jp, x0, x1);
+          v[2 * jp] = cmul(c0, x0);
+          v[2 * jp + 1] = cmul(c1, x1);
+        }
       }
       if (!B1 && b > 0) __syncthreads();   // previous transform's exchange-2 reads are complete
       fft4096<true>(v, lds, wa, wb);
@@ -338,6 +382,13 @@ namespace gacq {
 
 bool lds_supported(int N) { return N == kLdsN; }
 
+int lds_prepare_spectra(gacq_ctx* ctx, const float2* natural, float2* perm, int nprn, int N) {
+  if (!lds_supported(N)) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "LDS FFT engine: N=%d not supported", N);
+  hipLaunchKernelGGL(lds_permute_kernel, dim3((unsigned)nprn), dim3(kBlock), 0, ctx->stream, natural, perm);
+  GACQ_HIP(ctx, hipGetLastError());
+  return GACQ_OK;
+}
+
 int lds_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n, int N, const double* d_freq, int FD,
                 int B, const float2* tab, float2* X) {
   if (!lds_supported(N)) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "LDS FFT engine: N=%d not supported", N);
@@ -361,8 +412,8 @@ int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const i
   int pch = (int)std::max<long>(1, std::min<long>(8, rows_total / 2048));
   pch = std::min(pch, nitems);
   const int nchunk = (nitems + pch - 1) / pch;
-  const long ex = (nepoch + 7) / 8;
-  const long grid = 8 * ex * D * nchunk;
+  const long units8 = ((long)nepoch * D + 7) / 8;
+  const long grid = 8 * units8 * nchunk;
   int variant = kDefaultVariant;
   if (const char* ev = getenv("GACQ_LDS_VARIANT")) { const int k = atoi(ev); if (k >= 0 && k < kNumVariants) variant = k; }
   // register-cached X needs all items of a workgroup to share one forward set
