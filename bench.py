@@ -80,12 +80,14 @@ def main():
     ap.add_argument("--epochs", type=int, default=64, help="1 ms epochs per GPU per step")
     ap.add_argument("--engine", type=int, default=0, help="0 auto, 1 rocFFT pipeline, 2 LDS FFT kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-gather", action="store_true", help="run the all-gather + merge even on 1 rank (test aid)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)     # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if args.gpus != world and rank == 0 and world > 1:
@@ -110,16 +112,15 @@ def main():
     x_dev = torch.from_numpy(np.ascontiguousarray(xs)).to(dev)
 
     eng = acquire.Engine(local_rank, engine=args.engine)
-    stream = torch.cuda.current_stream(dev)
-    eng.set_stream(stream.cuda_stream)                  # same stream as the RCCL collective -> ordered
-    sh = sharded.ShardedSearch(engine=eng)
+    eng.use_torch_stream(dev)                           # same stream as the RCCL collective -> ordered
+    sh = sharded.ShardedSearch(engine=eng, always_gather=args.force_gather)
 
     def step():
         return sh.search_batch(sig, x_dev, items, dop, B)
 
     def sync_all():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -129,10 +130,10 @@ def main():
     for _ in range(args.steps):
         merged = step()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -224,7 +225,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

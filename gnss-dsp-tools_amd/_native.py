@@ -64,6 +64,7 @@ SYMBOLS = {
     "gacq_destroy": (None, [ctypes.c_void_p]),
     "gacq_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
     "gacq_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "gacq_use_null_stream": (ctypes.c_int, [ctypes.c_void_p]),
     "gacq_set_engine": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "gacq_set_workspace_limit": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]),
     "gacq_signal_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(SigDesc), ctypes.c_char_p,

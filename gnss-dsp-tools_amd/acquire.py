@@ -98,8 +98,19 @@ class Engine:
         nat.check(nat.lib.gacq_set_engine(self._ctx, int(engine)), self._ctx)
 
     def set_stream(self, stream_handle):
-        """Launch on the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream); 0/None = own stream."""
-        nat.check(nat.lib.gacq_set_stream(self._ctx, ctypes.c_void_p(stream_handle or None)), self._ctx)
+        """Launch on the caller's HIP stream, e.g. torch.cuda.current_stream().cuda_stream.  Handle 0 is the legacy
+        default stream (torch's current stream outside any stream context); None returns to the engine's own stream."""
+        if stream_handle is None:
+            nat.check(nat.lib.gacq_set_stream(self._ctx, None), self._ctx)
+        elif int(stream_handle) == 0:
+            nat.check(nat.lib.gacq_use_null_stream(self._ctx), self._ctx)
+        else:
+            nat.check(nat.lib.gacq_set_stream(self._ctx, ctypes.c_void_p(int(stream_handle))), self._ctx)
+
+    def use_torch_stream(self, device=None):
+        """Order the engine's launches with torch work (incl. RCCL collectives) on torch's current stream."""
+        import torch
+        self.set_stream(torch.cuda.current_stream(device).cuda_stream)
 
     def set_profiling(self, on):
         nat.check(nat.lib.gacq_set_profiling(self._ctx, int(bool(on))), self._ctx)

@@ -331,6 +331,12 @@ int gacq_set_stream(gacq_ctx* ctx, void* hip_stream) {
   return GACQ_OK;
 }
 
+int gacq_use_null_stream(gacq_ctx* ctx) {
+  if (!ctx) return set_error(nullptr, GACQ_ERR_BAD_ARG, "gacq_use_null_stream: ctx is NULL");
+  ctx->stream = (hipStream_t) nullptr;
+  return GACQ_OK;
+}
+
 int gacq_set_engine(gacq_ctx* ctx, int engine) {
   if (!ctx || engine < 0 || engine > 2) return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_set_engine: engine must be 0, 1 or 2");
   ctx->engine = engine;

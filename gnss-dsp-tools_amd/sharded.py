@@ -20,7 +20,7 @@ def doppler_bounds(nd, world):
 
 
 class ShardedSearch:
-    def __init__(self, engine=None, group=None, local_fn=None):
+    def __init__(self, engine=None, group=None, local_fn=None, always_gather=False):
         """engine: acquire.Engine on this rank's GPU.  local_fn(name, x, items, dopplers_slice, blocks) ->
         peaks tensor [nepoch, nitems, 2] float64 replaces the engine (CPU tests drive the exchange/merge
         logic with it; the product path always passes an engine)."""
@@ -29,6 +29,7 @@ class ShardedSearch:
         self.group = group
         self.engine = engine
         self.local_fn = local_fn
+        self.always_gather = always_gather          # run the collective + merge even for world_size 1 (tests)
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
@@ -43,8 +44,11 @@ class ShardedSearch:
         if self.local_fn is not None:
             local = self.local_fn(name, x, items, dopplers[lo:hi], blocks)
         else:
+            # kernels, the collective and the merge must share one stream: RCCL orders itself against torch's
+            # current stream only
+            self.engine.use_torch_stream(x.device)
             local = self.engine.search_batch_dev(name, x, items, dopplers[lo:hi], blocks)
-        if self.world == 1:
+        if self.world == 1 and not (self.always_gather and self.dist.is_initialized()):
             return local
         flat = local.contiguous().view(-1)
         gathered = torch.empty(self.world * flat.numel(), dtype=local.dtype, device=local.device)

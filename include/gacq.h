@@ -90,6 +90,9 @@ const char* gacq_last_error(gacq_ctx* ctx);             /* ctx may be NULL: last
 
 /* Use the caller's HIP stream (hipStream_t passed as void*; NULL = the ctx-owned stream). */
 int gacq_set_stream(gacq_ctx* ctx, void* hip_stream);
+/* Launch on the legacy default ("null") stream -- what torch.cuda.current_stream() is unless the caller
+ * entered a stream context; needed so that work is ordered with collectives issued on that stream. */
+int gacq_use_null_stream(gacq_ctx* ctx);
 /* Engine selection: 0 = auto, 1 = rocFFT pipeline (any N), 2 = LDS-resident FFT kernels (N = 4096...). */
 int gacq_set_engine(gacq_ctx* ctx, int engine);
 /* Upper bound for the library-owned correlation workspace in bytes (default 4 GiB). */

@@ -253,3 +253,27 @@ def test_full_size_properties_config2(engine):
     for (it, amp, f, delay), c in zip(sats, sat_cols):
         if amp >= 0.25:
             assert np.all(base["idx"][:, c] == (-delay) % 4096), it
+
+
+def test_bench_under_torchrun_single_rank_exercises_rccl_path():
+    """The driver launches N>1 through torch.distributed.run; with one GPU the same launcher + --force-gather still
+    exercises RCCL init, the all-gather of peak records on the engine's stream, the device-side merge and the
+    barrier/max-reduce timing code."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--epochs", "8", "--force-gather", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 1 and j["value"] > 1e9 and j["roofline"]["kernel"]

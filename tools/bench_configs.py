@@ -42,7 +42,7 @@ def main():
     ap.add_argument("cases", nargs="*")
     args = ap.parse_args()
     eng = acquire.Engine(0, engine=args.engine)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.use_torch_stream()
     for cid in (args.cases or list(CASES)):
         name, items, ds, ms, E = CASES[cid]
         sig = signals.get(name)
