@@ -117,13 +117,27 @@ __device__ __forceinline__ void apply_powers(v2 (&v)[kR], v2 w1) {
   v[rev16(13)] = cmul(v[rev16(13)], w13); v[rev16(14)] = cmul(v[rev16(14)], w14); v[rev16(15)] = cmul(v[rev16(15)], w15);
 }
 
+// w^1..w^15 into pw[0..14] (same product tree as apply_powers)
+__device__ __forceinline__ void make_powers(v2 (&pw)[15], v2 w1) {
+  pw[0] = w1;
+  pw[1] = cmul(w1, w1);        pw[2] = cmul(pw[1], w1);      pw[3] = cmul(pw[1], pw[1]);
+  pw[4] = cmul(pw[3], w1);     pw[5] = cmul(pw[2], pw[2]);   pw[6] = cmul(pw[3], pw[2]);   pw[7] = cmul(pw[3], pw[3]);
+  pw[8] = cmul(pw[7], w1);     pw[9] = cmul(pw[4], pw[4]);   pw[10] = cmul(pw[7], pw[2]);  pw[11] = cmul(pw[5], pw[5]);
+  pw[12] = cmul(pw[7], pw[4]); pw[13] = cmul(pw[6], pw[6]);  pw[14] = cmul(pw[7], pw[6]);
+}
+__device__ __forceinline__ void apply_table(v2 (&v)[kR], const v2 (&pw)[15]) {
+#pragma unroll
+  for (int k = 1; k < kR; k++) v[rev16(k)] = cmul(v[rev16(k)], pw[k - 1]);
+}
+
 // Length-4096 transform of the 16 values per lane. In: v[j] = x[t + 256 j]; out: v[rev16(k2)] = X[t + 256 k2].
 // wa = W_4096^t, wb = W_256^(t & 15) (forward values; conjugated here when INV).
-template <bool INV> __device__ __forceinline__ void fft4096(v2 (&v)[kR], v2* lds, v2 wa, v2 wb) {
+template <bool INV, bool PRE = false>
+__device__ __forceinline__ void fft4096(v2 (&v)[kR], v2* lds, v2 wa, v2 wb, const v2 (*pa)[15] = nullptr, const v2 (*pb)[15] = nullptr) {
   const int t = threadIdx.x;
-  if (INV) { wa.y = -wa.y; wb.y = -wb.y; }
+  if (INV && !PRE) { wa.y = -wa.y; wb.y = -wb.y; }
   dft16<INV>(v);
-  apply_powers(v, wa);
+  if (PRE) apply_table(v, *pa); else apply_powers(v, wa);
   {  // exchange 1: (n0,n1;k0) -> (n0,k0;n1)
     const int wbase = (t & 15) + 256 * (t >> 4);
 #pragma unroll
@@ -133,7 +147,7 @@ template <bool INV> __device__ __forceinline__ void fft4096(v2 (&v)[kR], v2* lds
     for (int j = 0; j < kR; j++) v[j] = lds[t + 256 * j];
   }
   dft16<INV>(v);
-  apply_powers(v, wb);
+  if (PRE) apply_table(v, *pb); else apply_powers(v, wb);
   __syncthreads();   // all exchange-1 reads done before the buffer is reused
   {  // exchange 2: (n0,k0;k1) -> (k0,k1;n0)
     const int wbase = (t >> 4) + kPitch * (t & 15);
@@ -218,7 +232,8 @@ __global__ __launch_bounds__(kBlock) void lds_permute_kernel(const float2* __res
 //   CACHEX  B1 only: keep the forward spectrum X[e,d] in registers across the item loop (halves L2 reads)
 //   OPAQUE  recompute the twiddle powers w^1..w^15 per pass instead of letting the compiler hoist all
 //           2 x 15 of them out of the item loop (60 VGPRs that would cost two waves of occupancy)
-template <int MINW, bool B1, bool CACHEX, bool OPAQUE>
+//   PRETW   keep all 2 x 15 twiddle powers in registers for the whole item loop (60 VGPRs, saves 56 ops per row)
+template <int MINW, bool B1, bool CACHEX, bool OPAQUE, bool PRETW = false>
 __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float2* __restrict__ X, const float2* __restrict__ C,
                                                                       const int* __restrict__ items, const int* __restrict__ fset,
                                                                       const float2* __restrict__ tw, RowRec* __restrict__ rows,
@@ -241,6 +256,13 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float
   const int p0 = (int)(j % nchunk) * pch;
   const int p1 = min(P, p0 + pch);
   v2 wa = ld2(tw + t), wb = ld2(tw + 16 * (t & 15));
+  v2 pwa[PRETW ? 15 : 1], pwb[PRETW ? 15 : 1];
+  if (PRETW) {
+    wa.y = -wa.y;                      // inverse transform: conjugate twiddles
+    wb.y = -wb.y;
+    make_powers(reinterpret_cast<v2(&)[15]>(pwa), wa);
+    make_powers(reinterpret_cast<v2(&)[15]>(pwb), wb);
+  }
   const float inv_n = 1.0f / (float)kLdsN;
   v2 xr[(B1 && CACHEX) ? kR : 1];
   const unsigned lane_off = (unsigned)t * 16u;
@@ -283,7 +305,8 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float
         }
       }
       if (!B1 && b > 0) __syncthreads();   // previous transform's exchange-2 reads are complete
-      fft4096<true>(v, lds, wa, wb);
+      if (PRETW) fft4096<true, true>(v, lds, wa, wb, reinterpret_cast<const v2(*)[15]>(pwa), reinterpret_cast<const v2(*)[15]>(pwb));
+      else fft4096<true>(v, lds, wa, wb);
       if (B1) {
         // (max, first argmax, sum) straight from the transform output; lane holds lags t + 256 k
         const v2 r0 = v[rev16(0)];
@@ -354,9 +377,13 @@ const CorrVariant kVariants[] = {
   {"w4-opaque", lds_correlate_kernel<4, true, false, true>, lds_correlate_kernel<4, false, false, true>},
   {"w3-opaque-cachex", lds_correlate_kernel<3, true, true, true>, lds_correlate_kernel<3, false, false, true>},
   {"w2-opaque-cachex", lds_correlate_kernel<2, true, true, true>, lds_correlate_kernel<2, false, false, true>},
+  {"w3-pretw-cachex", lds_correlate_kernel<3, true, true, false, true>, lds_correlate_kernel<3, false, false, false, true>},
+  {"w2-pretw-cachex", lds_correlate_kernel<2, true, true, false, true>, lds_correlate_kernel<2, false, false, false, true>},
+  {"w3-pretw", lds_correlate_kernel<3, true, false, false, true>, lds_correlate_kernel<3, false, false, false, true>},
+  {"w4-pretw", lds_correlate_kernel<4, true, false, false, true>, lds_correlate_kernel<4, false, false, false, true>},
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
-constexpr int kDefaultVariant = 2;
+constexpr int kDefaultVariant = 1;   // profiles/r01_ab_variants_*.log: all packed-math variants are within 5 %; this one led twice
 
 DevBuf g_tw[16];   // per-device W_4096 table
 
@@ -410,6 +437,7 @@ int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const i
   // items per workgroup: keep >= ~2048 workgroups in flight (256 CUs x 4 resident x 2), at most 8 per group
   const long rows_total = (long)nepoch * nitems * D;
   int pch = (int)std::max<long>(1, std::min<long>(8, rows_total / 2048));
+  if (const char* ev = getenv("GACQ_LDS_PCH")) { const int k = atoi(ev); if (k >= 1) pch = k; }
   pch = std::min(pch, nitems);
   const int nchunk = (nitems + pch - 1) / pch;
   const long units8 = ((long)nepoch * D + 7) / 8;
