@@ -48,7 +48,7 @@ struct gacq_ctx {
   int engine = 0;
   size_t ws_limit = (size_t)4 << 30;
   std::map<std::pair<long, long>, gacq::FftPlan> plans;   // (N * 2 + inverse, batch)
-  gacq::DevBuf tab, xstage, X, Y, rows, freq, fset, items, out_peaks, d0;
+  gacq::DevBuf tab, xstage, X, Y, rows, freq, fset, items, out_peaks, d0, partial;
   bool profiling = false;
   double stage_ms[GACQ_NSTAGES] = {0};
   long stage_n[GACQ_NSTAGES] = {0};
@@ -64,6 +64,7 @@ struct gacq_sig {
   int nprn = 0;
   int N = 0;                 // FFT length: n or 2n
   float2* spectra = nullptr; // [nprn][N] code spectra C_p = fft(replica), complex64, natural order
+  float2* spectra_pfa = nullptr;   // same in the radix-31 engine's [k1][k2] order (only when pfa_supported(N))
   float2* spectra_lds = nullptr;   // same in the LDS engine's lane-pair layout (only when lds_supported(N))
 };
 
@@ -84,6 +85,14 @@ int lds_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n,
 // rows[(e*P + p)*D + d] = reduce_k sum_b | IFFT_N(C_p * X[e,f(p),d,b]) | / N
 int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const int* d_items, const int* d_fset,
                   int nepoch, int nitems, int F, int D, int B, int N, RowRec* rows);
+
+// radix-31 split engine (gacq_pfa31.hip): N = 31*M with M handled natively by rocFFT
+bool pfa_supported(int N);
+// outer DFT-31 (+NCO mix when mix) + twiddle, then the inner forward transforms; X in [k1][k2] order
+int pfa_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, long rows, int n, int N, const double* d_freq, int FD, int B,
+                const float2* tab, float2* X, bool mix);
+// inner inverse transforms on Y (in place), then twiddle + inverse DFT-31 + |.|/N + sum over B + reduce -> rows[g0..g0+ng)
+int pfa_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng, int B, int N, float* q_out);
 
 #define GACQ_HIP(ctx, call)                                                                         \
   do {                                                                                              \

@@ -319,7 +319,7 @@ void gacq_destroy(gacq_ctx* ctx) {
     if (kv.second.work) (void)hipFree(kv.second.work);
   }
   for (auto& ev : ctx->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-  DevBuf* bufs[] = {&ctx->tab, &ctx->xstage, &ctx->X, &ctx->Y, &ctx->rows, &ctx->freq, &ctx->fset, &ctx->items, &ctx->out_peaks, &ctx->d0};
+  DevBuf* bufs[] = {&ctx->tab, &ctx->xstage, &ctx->X, &ctx->Y, &ctx->rows, &ctx->freq, &ctx->fset, &ctx->items, &ctx->out_peaks, &ctx->d0, &ctx->partial};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -338,7 +338,7 @@ int gacq_use_null_stream(gacq_ctx* ctx) {
 }
 
 int gacq_set_engine(gacq_ctx* ctx, int engine) {
-  if (!ctx || engine < 0 || engine > 2) return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_set_engine: engine must be 0, 1 or 2");
+  if (!ctx || engine < 0 || engine > 3) return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_set_engine: engine must be 0..3");
   ctx->engine = engine;
   return GACQ_OK;
 }
@@ -417,12 +417,23 @@ static int build_signal(gacq_ctx* ctx, const gacq_sigdesc* desc, const std::vect
   if (hipMemcpyAsync(s->spectra, host.data(), bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
     rc = set_error(ctx, GACQ_ERR_HIP, "replica upload failed");
   if (rc == GACQ_OK) rc = fft_exec(ctx, s->N, nprn, false, s->spectra);     // c = fft.fft(c)   acquire-gps-l1.py:24
+  if (rc == GACQ_OK && pfa_supported(s->N)) {
+    // the radix-31 engine keeps spectra in [k1][k2] order: transform the (still natural-order) replica with it
+    float2* tmp = nullptr;
+    if (hipMalloc((void**)&s->spectra_pfa, bytes) != hipSuccess || hipMalloc((void**)&tmp, bytes) != hipSuccess)
+      rc = set_error(ctx, GACQ_ERR_HIP, "hipMalloc for radix-31 spectra failed");
+    if (rc == GACQ_OK && hipMemcpyAsync(tmp, host.data(), bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+      rc = set_error(ctx, GACQ_ERR_HIP, "replica upload failed");
+    if (rc == GACQ_OK) rc = pfa_forward(ctx, tmp, 0, nprn, s->N, s->N, nullptr, 1, 1, nullptr, s->spectra_pfa, false);
+    if (rc == GACQ_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "radix-31 code spectrum failed");
+    if (tmp) (void)hipFree(tmp);
+  }
   if (rc == GACQ_OK && lds_supported(s->N)) {
     if (hipMalloc((void**)&s->spectra_lds, bytes) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "hipMalloc for LDS-layout spectra failed");
     else rc = lds_prepare_spectra(ctx, s->spectra, s->spectra_lds, nprn, s->N);
   }
   if (rc == GACQ_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "code spectrum FFT failed");
-  if (rc != GACQ_OK) { (void)hipFree(s->spectra); if (s->spectra_lds) (void)hipFree(s->spectra_lds); delete s; return rc; }
+  if (rc != GACQ_OK) { (void)hipFree(s->spectra); if (s->spectra_lds) (void)hipFree(s->spectra_lds); if (s->spectra_pfa) (void)hipFree(s->spectra_pfa); delete s; return rc; }
   *out = s;
   return GACQ_OK;
 }
@@ -467,6 +478,7 @@ void gacq_signal_destroy(gacq_sig* sig) {
   (void)hipStreamSynchronize(sig->ctx->stream);
   if (sig->spectra) (void)hipFree(sig->spectra);
   if (sig->spectra_lds) (void)hipFree(sig->spectra_lds);
+  if (sig->spectra_pfa) (void)hipFree(sig->spectra_pfa);
   delete sig;
 }
 
@@ -545,6 +557,9 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
   const bool use_lds = (ctx->engine == 2) || (ctx->engine == 0 && lds_supported(N) && !d_qrow);
   if (ctx->engine == 2 && (!lds_supported(N) || d_qrow))
     return set_error(ctx, GACQ_ERR_UNSUPPORTED, "engine 2 (LDS FFT) does not support N=%d%s", N, d_qrow ? " with row dump" : "");
+  const bool use_pfa = (ctx->engine == 3) || (ctx->engine == 0 && pfa_supported(N));
+  if (ctx->engine == 3 && !pfa_supported(N))
+    return set_error(ctx, GACQ_ERR_UNSUPPORTED, "engine 3 (radix-31 split) does not support N=%d", N);
 
   // epochs per pass so that the forward-spectra buffer respects the workspace limit
   const size_t x_epoch_bytes = sizeof(float2) * (size_t)F * D * B * N;
@@ -569,15 +584,22 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
       stage_end(ctx);
       if (rc != GACQ_OK) return rc;
     } else {
-      stage_begin(ctx, 0);
-      hipLaunchKernelGGL(mix_nco_kernel, dim3((unsigned)(rows_x * chunksN)), dim3(kBlock), 0, st, xe, nsamp, X,
-                         (const double*)ctx->freq.p, (const float2*)ctx->tab.p, n, N, F * D, B, chunksN);
-      stage_end(ctx);
-      GACQ_HIP(ctx, hipGetLastError());
-      stage_begin(ctx, 1);
-      rc = fft_exec(ctx, N, rows_x, false, X);
-      stage_end(ctx);
-      if (rc != GACQ_OK) return rc;
+      if (use_pfa) {
+        stage_begin(ctx, 0);
+        rc = pfa_forward(ctx, xe, nsamp, rows_x, n, N, (const double*)ctx->freq.p, F * D, B, (const float2*)ctx->tab.p, X, true);
+        stage_end(ctx);
+        if (rc != GACQ_OK) return rc;
+      } else {
+        stage_begin(ctx, 0);
+        hipLaunchKernelGGL(mix_nco_kernel, dim3((unsigned)(rows_x * chunksN)), dim3(kBlock), 0, st, xe, nsamp, X,
+                           (const double*)ctx->freq.p, (const float2*)ctx->tab.p, n, N, F * D, B, chunksN);
+        stage_end(ctx);
+        GACQ_HIP(ctx, hipGetLastError());
+        stage_begin(ctx, 1);
+        rc = fft_exec(ctx, N, rows_x, false, X);
+        stage_end(ctx);
+        if (rc != GACQ_OK) return rc;
+      }
       // correlation workspace: chunks of whole (e,p,d) groups, B rows each
       const long groups = (long)ne * P * D;
       const size_t group_bytes = sizeof(float2) * (size_t)B * N;
@@ -587,18 +609,26 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
       for (long g0 = 0; g0 < groups; g0 += gc) {
         const long ng = std::min(gc, groups - g0);
         stage_begin(ctx, 2);
-        hipLaunchKernelGGL(conj_mul_kernel, dim3((unsigned)(ng * B * chunksN)), dim3(kBlock), 0, st, X, sig->spectra, Y,
+        hipLaunchKernelGGL(conj_mul_kernel, dim3((unsigned)(ng * B * chunksN)), dim3(kBlock), 0, st, X,
+                           use_pfa ? sig->spectra_pfa : sig->spectra, Y,
                            (const int*)ctx->items.p, (const int*)ctx->fset.p, g0, P, F, D, B, N, chunksN);
         stage_end(ctx);
         GACQ_HIP(ctx, hipGetLastError());
-        stage_begin(ctx, 3);
-        rc = fft_exec(ctx, N, ng * B, true, Y);
-        stage_end(ctx);
-        if (rc != GACQ_OK) return rc;
-        stage_begin(ctx, 4);
-        hipLaunchKernelGGL(mag_peak_kernel, dim3((unsigned)ng), dim3(kBlock), 0, st, Y, rows, g0, B, N, 1.0f / (float)N, d_qrow);
-        stage_end(ctx);
-        GACQ_HIP(ctx, hipGetLastError());
+        if (use_pfa) {
+          stage_begin(ctx, 3);
+          rc = pfa_inverse_reduce(ctx, Y, rows, g0, ng, B, N, d_qrow);      // inner inverse FFTs + outer DFT-31 + |.| + reduce
+          stage_end(ctx);
+          if (rc != GACQ_OK) return rc;
+        } else {
+          stage_begin(ctx, 3);
+          rc = fft_exec(ctx, N, ng * B, true, Y);
+          stage_end(ctx);
+          if (rc != GACQ_OK) return rc;
+          stage_begin(ctx, 4);
+          hipLaunchKernelGGL(mag_peak_kernel, dim3((unsigned)ng), dim3(kBlock), 0, st, Y, rows, g0, B, N, 1.0f / (float)N, d_qrow);
+          stage_end(ctx);
+          GACQ_HIP(ctx, hipGetLastError());
+        }
       }
     }
     const long nep = (long)ne * P;
@@ -749,7 +779,7 @@ int gacq_debug_row(gacq_sig* sig, const float* x_iq, size_t nsamp, int item, dou
   GACQ_HIP(ctx, hipMalloc((void**)&d_q, sizeof(float) * sig->N));
   GACQ_HIP(ctx, hipMemcpyAsync(ctx->xstage.p, x_iq, sizeof(float2) * need, hipMemcpyHostToDevice, ctx->stream));
   const int saved = ctx->engine;
-  ctx->engine = 1;
+  ctx->engine = (saved == 3) ? 3 : 1;      // row dump exists in the rocFFT pipeline and the radix-31 split
   rc = launch_search(sig, (const float2*)ctx->xstage.p, need, 1, &item, 1, &doppler, 1, bias_hz != 0.0 ? &bias_hz : nullptr, blocks,
                      (gacq_peak*)ctx->out_peaks.p, d_q);
   ctx->engine = saved;
