@@ -1,0 +1,204 @@
+// Device-side complex arithmetic and small DFTs on packed-f32 VALU ops (shared by the LDS FFT engine and the
+// split-radix engines).  A complex value is one 64-bit VGPR pair (re, im); v_pk_{add,mul,fma}_f32 process both
+// halves per lane and their op_sel / neg modifiers give the swaps and sign flips of complex products for free.
+// hipcc does not find these forms on its own (3-4 instructions + v_mov per complex multiply), hence the asm wrappers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace gacq {
+
+typedef float v2 __attribute__((ext_vector_type(2)));
+
+// a + i*b = (a.re - b.im, a.im + b.re)
+__device__ __forceinline__ v2 add_i(v2 a, v2 b) {
+  v2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// a - i*b = (a.re + b.im, a.im - b.re)
+__device__ __forceinline__ v2 sub_i(v2 a, v2 b) {
+  v2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// a*b: t = (-a.im*b.im, a.im*b.re); r = (a.re*b.re + t.lo, a.re*b.im + t.hi)
+__device__ __forceinline__ v2 cmul(v2 a, v2 b) {
+  v2 t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]" : "=v"(t) : "v"(a), "v"(b));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+  return r;
+}
+// a*w with w a compile-time constant held in an SGPR pair (one constant-bus operand per instruction)
+__device__ __forceinline__ v2 cmul_k(v2 a, v2 w) {
+  v2 t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]" : "=v"(t) : "v"(a), "s"(w));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "s"(w), "v"(t));
+  return r;
+}
+// real constant x complex value, constant pair cs = (c, s) in SGPRs, one half broadcast to both lanes:
+// acc + x*cs.lo | acc + x*cs.hi | acc - x*cs.hi | x*cs.hi | -x*cs.hi
+__device__ __forceinline__ v2 fma_lo(v2 acc, v2 x, v2 cs) {
+  v2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(x), "s"(cs), "v"(acc));
+  return r;
+}
+__device__ __forceinline__ v2 fma_hi(v2 acc, v2 x, v2 cs) {
+  v2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(x), "s"(cs), "v"(acc));
+  return r;
+}
+__device__ __forceinline__ v2 fms_hi(v2 acc, v2 x, v2 cs) {
+  v2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(r) : "v"(x), "s"(cs), "v"(acc));
+  return r;
+}
+__device__ __forceinline__ v2 mul_hi(v2 x, v2 cs) {
+  v2 r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(x), "s"(cs));
+  return r;
+}
+__device__ __forceinline__ v2 mul_hi_neg(v2 x, v2 cs) {
+  v2 r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "s"(cs));
+  return r;
+}
+
+// 4-point DFT, forward W4 = -i (INV: +i).  ROTC: input c still needs its -/+i factor (folded into the adds).
+template <bool INV, bool ROTC> __device__ __forceinline__ void dft4(v2& a, v2& b, v2& c, v2& d) {
+  v2 s0, d0;
+  if (ROTC) {
+    s0 = INV ? add_i(a, c) : sub_i(a, c);
+    d0 = INV ? sub_i(a, c) : add_i(a, c);
+  } else {
+    s0 = a + c;
+    d0 = a - c;
+  }
+  const v2 s1 = b + d, t = b - d;
+  a = s0 + s1;
+  c = s0 - s1;
+  b = INV ? add_i(d0, t) : sub_i(d0, t);
+  d = INV ? sub_i(d0, t) : add_i(d0, t);
+}
+
+// W16^m as (re, im): forward exp(-2 pi i m/16), inverse the conjugate
+template <bool INV, int M> __device__ __forceinline__ v2 w16() {
+  constexpr float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
+  constexpr float re = (M == 1) ? c1 : (M == 2) ? h : (M == 3) ? s1 : (M == 6) ? -h : (M == 9) ? -c1 : 0.f;
+  constexpr float im = (M == 1) ? s1 : (M == 2) ? h : (M == 3) ? c1 : (M == 6) ? h : (M == 9) ? -s1 : 0.f;
+  v2 w = {re, INV ? im : -im};
+  return w;
+}
+
+// In-place 16-point DFT. Input v[n], n = 0..15; output X[k] is left in register v[4*(k&3) + (k>>2)]
+// (base-4 digit reversal) -- callers index outputs through rev16().  64 + 16 packed instructions.
+__device__ __forceinline__ constexpr int rev16(int k) { return 4 * (k & 3) + (k >> 2); }
+
+template <bool INV> __device__ __forceinline__ void dft16(v2 (&v)[16]) {
+#pragma unroll
+  for (int n0 = 0; n0 < 4; n0++) dft4<INV, false>(v[n0], v[n0 + 4], v[n0 + 8], v[n0 + 12]);   // -> A[n0][k0] at v[n0+4k0]
+  v[5] = cmul_k(v[5], w16<INV, 1>());   v[9] = cmul_k(v[9], w16<INV, 2>());   v[13] = cmul_k(v[13], w16<INV, 3>());
+  v[6] = cmul_k(v[6], w16<INV, 2>());   /* v[10]: W16^4 folded into dft4<ROTC> */ v[14] = cmul_k(v[14], w16<INV, 6>());
+  v[7] = cmul_k(v[7], w16<INV, 3>());   v[11] = cmul_k(v[11], w16<INV, 6>()); v[15] = cmul_k(v[15], w16<INV, 9>());
+  dft4<INV, false>(v[0], v[1], v[2], v[3]);
+  dft4<INV, false>(v[4], v[5], v[6], v[7]);
+  dft4<INV, true>(v[8], v[9], v[10], v[11]);
+  dft4<INV, false>(v[12], v[13], v[14], v[15]);                                               // -> X[k0+4k1] at v[4k0+k1]
+}
+
+// cos/sin(2 pi m / P) for the odd primes used as outer radices
+template <int P> struct Trig;
+template <> struct Trig<31> {
+  static constexpr float c[16] = {1.f, 0.97952994125249448f, 0.9189578116202306f, 0.82076344120727629f, 0.68896691907568663f,
+                                  0.52896401032696239f, 0.34730525284482028f, 0.1514277775045767f, -0.050649168838712642f,
+                                  -0.25065253225872042f, -0.44039415155763439f, -0.61210598254766257f, -0.75875812269279086f,
+                                  -0.87434661614458209f, -0.95413925640004882f, -0.99486932339189504f};
+  static constexpr float s[16] = {0.f, 0.20129852008866006f, 0.39435585511331855f, 0.57126821509479231f, 0.72479278722911988f,
+                                  0.84864425749475092f, 0.93775213214708042f, 0.98846832432811138f, 0.99871650717105276f,
+                                  0.96807711886620429f, 0.89780453957074158f, 0.79077573693769887f, 0.65137248272222226f,
+                                  0.48530196253108104f, 0.29936312297335804f, 0.10116832198743272f};
+};
+template <> struct Trig<5> {
+  static constexpr float c[3] = {1.f, 0.30901699437494742f, -0.80901699437494742f};
+  static constexpr float s[3] = {0.f, 0.95105651629515357f, 0.58778525229247313f};
+};
+
+// P-point DFT (P odd prime) through the conjugate symmetry of W_P: with s_n = x[n] + x[P-n], d_n = x[n] - x[P-n]
+//   A_k = x[0] + sum_{n=1..h} cos(2 pi n k/P) s_n,   B_k = sum_{n=1..h} sin(2 pi n k/P) d_n,   h = (P-1)/2
+//   forward X[k] = A_k - i B_k, X[P-k] = A_k + i B_k (inverse: signs swapped)
+// Real constant x complex value = one v_pk_fma_f32 with the constant broadcast from an SGPR: (P-1) + 2 h^2 + ... packed
+// instructions, a quarter of the P x P complex products.  Outputs go to sink(k, value) as they are produced.
+template <int P, bool INV, class Sink> __device__ __forceinline__ void dft_prime(const v2 (&x)[P], Sink&& sink) {
+  constexpr int H = (P - 1) / 2;
+  v2 s[H + 1], d[H + 1];
+  v2 sum = x[0];
+#pragma unroll
+  for (int n = 1; n <= H; n++) {
+    s[n] = x[n] + x[P - n];
+    d[n] = x[n] - x[P - n];
+    sum += s[n];
+  }
+  sink(0, sum);
+#pragma unroll
+  for (int k = 1; k <= H; k++) {
+    v2 A = x[0], B;
+#pragma unroll
+    for (int n = 1; n <= H; n++) {
+      const int m = (n * k) % P;
+      const int mm = m <= H ? m : P - m;
+      const v2 cs = {Trig<P>::c[mm], Trig<P>::s[mm]};
+      A = fma_lo(A, s[n], cs);
+      if (n == 1) B = (m <= H) ? mul_hi(d[n], cs) : mul_hi_neg(d[n], cs);
+      else B = (m <= H) ? fma_hi(B, d[n], cs) : fms_hi(B, d[n], cs);
+    }
+    sink(k, INV ? add_i(A, B) : sub_i(A, B));
+    sink(P - k, INV ? sub_i(A, B) : add_i(A, B));
+  }
+}
+
+// Generic R-point DFT used as the OUTER stage of the split engines: x[0..R) -> sink(k, X[k]).
+template <int R, bool INV> struct OuterDft;
+template <bool INV> struct OuterDft<31, INV> {
+  template <class Sink> static __device__ __forceinline__ void run(v2 (&x)[31], Sink&& sink) { dft_prime<31, INV>(x, sink); }
+};
+template <bool INV> struct OuterDft<4, INV> {
+  template <class Sink> static __device__ __forceinline__ void run(v2 (&x)[4], Sink&& sink) {
+    dft4<INV, false>(x[0], x[1], x[2], x[3]);
+    sink(0, x[0]); sink(1, x[1]); sink(2, x[2]); sink(3, x[3]);
+  }
+};
+template <bool INV> struct OuterDft<16, INV> {
+  template <class Sink> static __device__ __forceinline__ void run(v2 (&x)[16], Sink&& sink) {
+    dft16<INV>(x);
+#pragma unroll
+    for (int k = 0; k < 16; k++) sink(k, x[rev16(k)]);
+  }
+};
+
+// w^k for k = 0..43 from base-4 digits: w^k = p[k & 3] * q[k >> 2], p[a] = w^a, q[b] = w^(4b); multiplication depth <= 5
+struct TwPow {
+  v2 p[4], q[11];
+  template <int KMAX> __device__ __forceinline__ void init(v2 w) {
+    p[1] = w;
+    p[2] = cmul(w, w);
+    p[3] = cmul(p[2], w);
+    q[1] = cmul(p[2], p[2]);
+    if (KMAX >= 8) q[2] = cmul(q[1], q[1]);
+    if (KMAX >= 12) q[3] = cmul(q[2], q[1]);
+    if (KMAX >= 16) q[4] = cmul(q[2], q[2]);
+    if (KMAX >= 20) q[5] = cmul(q[4], q[1]);
+    if (KMAX >= 24) q[6] = cmul(q[3], q[3]);
+    if (KMAX >= 28) q[7] = cmul(q[4], q[3]);
+    if (KMAX >= 32) q[8] = cmul(q[4], q[4]);
+    if (KMAX >= 36) q[9] = cmul(q[8], q[1]);
+    if (KMAX >= 40) q[10] = cmul(q[5], q[5]);
+  }
+  // v * w^k, k compile-time after unrolling
+  __device__ __forceinline__ v2 apply(v2 v, int k) const {
+    const int a = k & 3, b = k >> 2;
+    if (a) v = cmul(v, p[a]);
+    if (b) v = cmul(v, q[b]);
+    return v;
+  }
+};
+
+}  // namespace gacq

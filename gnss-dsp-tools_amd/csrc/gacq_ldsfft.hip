@@ -15,6 +15,7 @@
 // the two LDS transposes are bank-conflict free: exchange 1 is lane-contiguous on both sides, exchange 2
 // writes with row pitch 257 (odd) so that the 16 lanes of a ds_write_b64 group hit 16 distinct bank pairs.
 #include "gacq_common.h"
+#include "gacq_cplx.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -27,81 +28,6 @@ constexpr int kR = 16;                 // points per lane
 constexpr int kLdsN = 4096;            // supported length (this round)
 constexpr int kPitch = 257;            // exchange-2 row pitch in complex elements
 constexpr int kLdsElems = 16 * kPitch; // 4112 complex = 32.9 KB -> 4 workgroups per CU
-
-// Complex arithmetic on packed-f32 VALU ops.  A complex value is one 64-bit VGPR pair (re, im);
-// v_pk_{add,mul,fma}_f32 process both halves per lane, and their op_sel / neg modifiers give the
-// swaps and sign flips of complex products for free.  hipcc does not find these forms on its own
-// (it emits 3-4 instructions + v_mov per complex multiply), hence the one-instruction asm wrappers.
-typedef float v2 __attribute__((ext_vector_type(2)));
-
-// a + i*b = (a.re - b.im, a.im + b.re)
-__device__ __forceinline__ v2 add_i(v2 a, v2 b) {
-  v2 r;
-  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-// a - i*b = (a.re + b.im, a.im - b.re)
-__device__ __forceinline__ v2 sub_i(v2 a, v2 b) {
-  v2 r;
-  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-// a*b: t = (-a.im*b.im, a.im*b.re); r = (a.re*b.re + t.lo, a.re*b.im + t.hi)
-__device__ __forceinline__ v2 cmul(v2 a, v2 b) {
-  v2 t, r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]" : "=v"(t) : "v"(a), "v"(b));
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
-  return r;
-}
-// a*w with w a compile-time constant held in an SGPR pair (one constant-bus operand per instruction)
-__device__ __forceinline__ v2 cmul_k(v2 a, v2 w) {
-  v2 t, r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]" : "=v"(t) : "v"(a), "s"(w));
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "s"(w), "v"(t));
-  return r;
-}
-
-// 4-point DFT, forward W4 = -i (INV: +i).  ROTC: input c still needs its W16^4 = -/+i factor (folded into the adds).
-template <bool INV, bool ROTC> __device__ __forceinline__ void dft4(v2& a, v2& b, v2& c, v2& d) {
-  v2 s0, d0;
-  if (ROTC) {
-    s0 = INV ? add_i(a, c) : sub_i(a, c);
-    d0 = INV ? sub_i(a, c) : add_i(a, c);
-  } else {
-    s0 = a + c;
-    d0 = a - c;
-  }
-  const v2 s1 = b + d, t = b - d;
-  a = s0 + s1;
-  c = s0 - s1;
-  b = INV ? add_i(d0, t) : sub_i(d0, t);
-  d = INV ? sub_i(d0, t) : add_i(d0, t);
-}
-
-// W16^m as (re, im): forward exp(-2 pi i m/16), inverse the conjugate
-template <bool INV, int M> __device__ __forceinline__ v2 w16() {
-  constexpr float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
-  constexpr float re = (M == 1) ? c1 : (M == 2) ? h : (M == 3) ? s1 : (M == 6) ? -h : (M == 9) ? -c1 : 0.f;
-  constexpr float im = (M == 1) ? s1 : (M == 2) ? h : (M == 3) ? c1 : (M == 6) ? h : (M == 9) ? -s1 : 0.f;
-  v2 w = {re, INV ? im : -im};
-  return w;
-}
-
-// In-place 16-point DFT. Input v[n], n = 0..15; output X[k] is left in register v[4*(k&3) + (k>>2)]
-// (base-4 digit reversal) -- callers index outputs through rev16().  64 + 16 packed instructions.
-__device__ __forceinline__ constexpr int rev16(int k) { return 4 * (k & 3) + (k >> 2); }
-
-template <bool INV> __device__ __forceinline__ void dft16(v2 (&v)[kR]) {
-#pragma unroll
-  for (int n0 = 0; n0 < 4; n0++) dft4<INV, false>(v[n0], v[n0 + 4], v[n0 + 8], v[n0 + 12]);   // -> A[n0][k0] at v[n0+4k0]
-  v[5] = cmul_k(v[5], w16<INV, 1>());   v[9] = cmul_k(v[9], w16<INV, 2>());   v[13] = cmul_k(v[13], w16<INV, 3>());
-  v[6] = cmul_k(v[6], w16<INV, 2>());   /* v[10]: W16^4 folded into dft4<ROTC> */ v[14] = cmul_k(v[14], w16<INV, 6>());
-  v[7] = cmul_k(v[7], w16<INV, 3>());   v[11] = cmul_k(v[11], w16<INV, 6>()); v[15] = cmul_k(v[15], w16<INV, 9>());
-  dft4<INV, false>(v[0], v[1], v[2], v[3]);
-  dft4<INV, false>(v[4], v[5], v[6], v[7]);
-  dft4<INV, true>(v[8], v[9], v[10], v[11]);
-  dft4<INV, false>(v[12], v[13], v[14], v[15]);                                               // -> X[k0+4k1] at v[4k0+k1]
-}
 
 // v[rev16(k)] *= w^k for k = 1..15, powers built with multiplication depth <= 4 from the table value.
 __device__ __forceinline__ void apply_powers(v2 (&v)[kR], v2 w1) {

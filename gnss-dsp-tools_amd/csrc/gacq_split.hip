@@ -1,0 +1,271 @@
+// Split engines: FFT length N = R * M, a hand-written R-point OUTER DFT over the stride-M dimension fused with the
+// neighbouring element-wise stages, and length-M INNER transforms over contiguous rows.
+//
+//   n = M n1 + n2, k = k1 + R k2:
+//   X[k1 + R k2] = sum_{n2} W_M^{n2 k2} * ( W_N^{n2 k1} * sum_{n1} x[M n1 + n2] W_R^{n1 k1} )
+//
+//   forward : split_outer_forward_kernel (NCO mix + DFT-R over n1 + twiddle W_N^{n2 k1})            K1 + outer
+//             inner forward transforms of length M, batch R*rows  -> spectrum stored as [k1][k2]
+//             (the code spectra use the same order, so the element-wise conj-multiply K2 is unchanged)
+//   inverse : inner inverse transforms of length M, batch R*rows
+//             split_outer_inverse_kernel (twiddle + inverse DFT-R + |.|/N + sum over blocks + max/argmax/sum)  outer + K3
+//
+// R = 31, M = 1980 / 990 (N = 61380 / 30690: the 10.23 Mcps family, acquire-gps-l5i.py:19-24 and 18 more scripts, and
+//   E6, acquire-galileo-e6b.py:19-24).  rocFFT has no radix-31 butterfly and falls back to Bluestein for these lengths
+//   (three transforms of twice the size per FFT); M = 4*5*9*11 is native to it.  The DFT-31 uses the conjugate symmetry
+//   of W_31 (gacq_cplx.h: dft_prime), a quarter of the 31 x 31 complex products.
+// R = 4 / 16, M = 4096 (N = 16384 / 65536: B1I, GLONASS, E1B/E1C): the inner transforms are single-kernel and the
+//   magnitude/reduce stage is fused into the outer inverse DFT, so the correlation workspace is read once less.
+#include "gacq_common.h"
+#include "gacq_cplx.h"
+
+#include <cmath>
+
+using namespace gacq;
+
+namespace {
+
+// ---- forward outer stage ---------------------------------------------------------------------------
+// grid = rows * chunks; thread -> n2.  MIX: multiply by the table NCO (rows = (e,f,d,b)); otherwise plain rows.
+template <int R, bool MIX>
+__global__ __launch_bounds__(kBlock) void split_outer_forward_kernel(const float2* __restrict__ x, size_t epoch_stride,
+                                                                    float2* __restrict__ A, const double* __restrict__ freq,
+                                                                    const float2* __restrict__ nco_tab,
+                                                                    const float2* __restrict__ tw, int n, int M, int FD, int B,
+                                                                    int chunks) {
+  const long blk = blockIdx.x;
+  const int chunk = (int)(blk % chunks);
+  const long row = blk / chunks;
+  const int n2 = chunk * kBlock + threadIdx.x;
+  if (n2 >= M) return;
+  const float2* src;
+  double f = 0.0;
+  if (MIX) {
+    const int b = (int)(row % B);
+    const long r2 = row / B;
+    const int fd = (int)(r2 % FD);
+    const long e = r2 / FD;
+    f = freq[fd];
+    src = x + e * epoch_stride + (size_t)b * n;
+  } else {
+    src = x + row * (long)(R * M);
+  }
+  v2 v[R];
+#pragma unroll
+  for (int n1 = 0; n1 < R; n1++) {
+    const int i = M * n1 + n2;
+    const float2 sf = src[i];
+    v2 sv = {sf.x, sf.y};
+    if (MIX) {
+      // table NCO, index in fp64 exactly as numpy: floor((0 + f*i)*1024) mod 1024   (gnsstools/nco.py:6-9)
+      const long k = (long)floor(__dmul_rn(__dmul_rn(f, (double)i), 1024.0)) & (kNcoTableSize - 1);
+      const float2 wf = nco_tab[k];
+      const v2 wv = {wf.x, wf.y};
+      sv = cmul(sv, wv);
+    }
+    v[n1] = sv;
+  }
+  TwPow tp;
+  {
+    const float2 wf = tw[n2];           // W_N^{n2}
+    const v2 wv = {wf.x, wf.y};
+    tp.init<R - 1>(wv);
+  }
+  float2* dst = A + row * (long)(R * M) + n2;
+  OuterDft<R, false>::run(v, [&](int k1, v2 val) {
+    const v2 o = tp.apply(val, k1);
+    dst[(long)k1 * M] = make_float2(o.x, o.y);
+  });
+}
+
+// ---- inverse outer stage + magnitude + reduce ------------------------------------------------------------
+// Z: [group][b][k1][n2] after the inner inverse transforms (unnormalised).  One workgroup handles 256 values of n2
+// of one group and emits a partial (peak, idx, sum) record; idx = M n1 + n2.
+template <int R, bool TW>
+__global__ __launch_bounds__(kBlock) void split_outer_inverse_kernel(const float2* __restrict__ Z, RowRec* __restrict__ partial,
+                                                                    const float2* __restrict__ tw, int M, int B, int chunks,
+                                                                    float inv_n, float* __restrict__ q_out) {
+  __shared__ float s_peak[kBlock / 64];
+  __shared__ int s_idx[kBlock / 64];
+  __shared__ double s_sum[kBlock / 64];
+  const long blk = blockIdx.x;
+  const int chunk = (int)(blk % chunks);
+  const long g = blk / chunks;
+  const int n2 = chunk * kBlock + threadIdx.x;
+  float peak = -1.0f;
+  int idx = 0x7fffffff;
+  double sum = 0.0;
+  if (n2 < M) {
+    TwPow tp;
+    if (TW) {
+      const float2 wf = tw[n2];
+      const v2 wv = {wf.x, -wf.y};      // conj: W_N^{-n2}
+      tp.init<R - 1>(wv);
+    }
+    float q[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) q[k] = 0.f;
+    for (int b = 0; b < B; b++) {
+      const float2* src = Z + (g * B + b) * (long)(R * M) + n2;
+      v2 v[R];
+#pragma unroll
+      for (int k1 = 0; k1 < R; k1++) {
+        const float2 zf = src[(long)k1 * M];
+        const v2 zv = {zf.x, zf.y};
+        v[k1] = TW ? tp.apply(zv, k1) : zv;
+      }
+      OuterDft<R, true>::run(v, [&](int n1, v2 val) {
+        q[n1] += __builtin_amdgcn_sqrtf(val.x * val.x + val.y * val.y) * inv_n;      // np.absolute(ifft(..)), 1/N folded in
+      });
+    }
+#pragma unroll
+    for (int n1 = 0; n1 < R; n1++) {          // ascending idx = M n1 + n2: strict '>' keeps the first maximum
+      if (q[n1] > peak) { peak = q[n1]; idx = M * n1 + n2; }
+      sum += (double)q[n1];
+      if (q_out) q_out[M * n1 + n2] = q[n1];
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float op = __shfl_down(peak, off);
+    const int oi = __shfl_down(idx, off);
+    const double os = __shfl_down(sum, off);
+    if (op > peak || (op == peak && oi < idx)) { peak = op; idx = oi; }
+    sum += os;
+  }
+  const int t = threadIdx.x;
+  if ((t & 63) == 0) { s_peak[t >> 6] = peak; s_idx[t >> 6] = idx; s_sum[t >> 6] = sum; }
+  __syncthreads();
+  if (t == 0) {
+    for (int w = 1; w < kBlock / 64; w++) {
+      if (s_peak[w] > peak || (s_peak[w] == peak && s_idx[w] < idx)) { peak = s_peak[w]; idx = s_idx[w]; }
+      sum += s_sum[w];
+    }
+    RowRec r;
+    r.peak = peak;
+    r.idx = idx;
+    r.sum = sum;
+    partial[blk] = r;
+  }
+}
+
+// partial[(g, chunk)] -> rows[g0 + g]
+__global__ void split_combine_kernel(const RowRec* __restrict__ partial, RowRec* __restrict__ rows, long g0, long ng, int chunks) {
+  const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ng) return;
+  RowRec best = partial[g * chunks];
+  for (int c = 1; c < chunks; c++) {
+    const RowRec r = partial[g * chunks + c];
+    if (r.peak > best.peak || (r.peak == best.peak && r.idx < best.idx)) { best.peak = r.peak; best.idx = r.idx; }
+    best.sum += r.sum;
+  }
+  rows[g0 + g] = best;
+}
+
+struct TwTable { int N; int device; float2* p; };
+std::vector<TwTable> g_tables;
+
+// W_N^k for k < M (the per-n2 base twiddles of the outer stage)
+int base_twiddles(gacq_ctx* ctx, int N, int M, const float2** out) {
+  for (const TwTable& t : g_tables) if (t.N == N && t.device == ctx->device) { *out = t.p; return GACQ_OK; }
+  std::vector<float2> h(M);
+  for (int k = 0; k < M; k++) {
+    const double a = -2.0 * M_PI * (double)k / (double)N;
+    h[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+  }
+  TwTable t{N, ctx->device, nullptr};
+  GACQ_HIP(ctx, hipMalloc((void**)&t.p, sizeof(float2) * M));
+  GACQ_HIP(ctx, hipMemcpy(t.p, h.data(), sizeof(float2) * M, hipMemcpyHostToDevice));
+  g_tables.push_back(t);
+  *out = t.p;
+  return GACQ_OK;
+}
+
+bool smooth(int m) {
+  for (int p : {2, 3, 5, 7, 11, 13}) while (m % p == 0) m /= p;
+  return m == 1;
+}
+
+template <int R>
+int launch_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, long rows, int n, int M, const double* d_freq, int FD, int B,
+                   const float2* tab, const float2* tw, float2* X, bool mix) {
+  const int chunks = (M + kBlock - 1) / kBlock;
+  if (mix)
+    hipLaunchKernelGGL((split_outer_forward_kernel<R, true>), dim3((unsigned)(rows * chunks)), dim3(kBlock), 0, ctx->stream, x, nsamp,
+                       X, d_freq, tab, tw, n, M, FD, B, chunks);
+  else
+    hipLaunchKernelGGL((split_outer_forward_kernel<R, false>), dim3((unsigned)(rows * chunks)), dim3(kBlock), 0, ctx->stream, x, nsamp,
+                       X, d_freq, tab, tw, n, M, FD, B, chunks);
+  GACQ_HIP(ctx, hipGetLastError());
+  return GACQ_OK;
+}
+
+template <int R>
+int launch_inverse(gacq_ctx* ctx, const float2* Z, RowRec* partial, const float2* tw, int M, int B, long ng, float inv_n,
+                   float* q_out, bool twiddle) {
+  const int chunks = (M + kBlock - 1) / kBlock;
+  if (twiddle)
+    hipLaunchKernelGGL((split_outer_inverse_kernel<R, true>), dim3((unsigned)(ng * chunks)), dim3(kBlock), 0, ctx->stream, Z, partial,
+                       tw, M, B, chunks, inv_n, q_out);
+  else
+    hipLaunchKernelGGL((split_outer_inverse_kernel<R, false>), dim3((unsigned)(ng * chunks)), dim3(kBlock), 0, ctx->stream, Z, partial,
+                       tw, M, B, chunks, inv_n, q_out);
+  GACQ_HIP(ctx, hipGetLastError());
+  return GACQ_OK;
+}
+
+}  // namespace
+
+namespace gacq {
+
+int split_radix(int N) {
+  if (N > 0 && N % 31 == 0 && smooth(N / 31) && N / 31 >= 64) return 31;
+  if (N == 65536) return 16;
+  if (N == 16384) return 4;
+  return 0;
+}
+
+bool pfa_supported(int N) { return split_radix(N) != 0; }
+
+int pfa_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, long rows, int n, int N, const double* d_freq, int FD, int B,
+                const float2* tab, float2* X, bool mix) {
+  const int R = split_radix(N);
+  if (!R) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "split engine: N=%d not supported", N);
+  const int M = N / R;
+  const float2* tw;
+  int rc = base_twiddles(ctx, N, M, &tw);
+  if (rc != GACQ_OK) return rc;
+  switch (R) {
+    case 31: rc = launch_forward<31>(ctx, x, nsamp, rows, n, M, d_freq, FD, B, tab, tw, X, mix); break;
+    case 16: rc = launch_forward<16>(ctx, x, nsamp, rows, n, M, d_freq, FD, B, tab, tw, X, mix); break;
+    default: rc = launch_forward<4>(ctx, x, nsamp, rows, n, M, d_freq, FD, B, tab, tw, X, mix); break;
+  }
+  if (rc != GACQ_OK) return rc;
+  return fft_exec(ctx, M, rows * R, false, X);            // inner transforms, rows contiguous
+}
+
+int pfa_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng, int B, int N, float* q_out) {
+  const int R = split_radix(N);
+  if (!R) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "split engine: N=%d not supported", N);
+  const int M = N / R;
+  const float2* tw;
+  int rc = base_twiddles(ctx, N, M, &tw);
+  if (rc != GACQ_OK) return rc;
+  const int chunks = (M + kBlock - 1) / kBlock;
+  if ((rc = fft_exec(ctx, M, ng * B * R, true, Y)) != GACQ_OK) return rc;
+  if ((rc = ensure(ctx, ctx->partial, sizeof(RowRec) * (size_t)ng * chunks)) != GACQ_OK) return rc;
+  RowRec* partial = (RowRec*)ctx->partial.p;
+  const float inv_n = 1.0f / (float)N;
+  switch (R) {
+    case 31: rc = launch_inverse<31>(ctx, Y, partial, tw, M, B, ng, inv_n, q_out, true); break;
+    case 16: rc = launch_inverse<16>(ctx, Y, partial, tw, M, B, ng, inv_n, q_out, true); break;
+    default: rc = launch_inverse<4>(ctx, Y, partial, tw, M, B, ng, inv_n, q_out, true); break;
+  }
+  if (rc != GACQ_OK) return rc;
+  hipLaunchKernelGGL(split_combine_kernel, dim3((unsigned)((ng + 127) / 128)), dim3(128), 0, ctx->stream, (const RowRec*)partial, rows,
+                     g0, ng, chunks);
+  GACQ_HIP(ctx, hipGetLastError());
+  return GACQ_OK;
+}
+
+}  // namespace gacq

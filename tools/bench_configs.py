@@ -31,6 +31,9 @@ CASES = {
     "cfg4_b2ad_b1": ("beidou-b2ad", list(range(1, 64)), [-7000.0, 7000.0, 200.0], None, 1),   # engine-level B=1
     "cfg5_b1i": ("beidou-b1i", list(range(1, 64)), [-10000.0, 10000.0, 100.0], 10, 1),
     "cfg5_glonass": ("glonass-l1", list(range(-7, 8)), [-10000.0, 10000.0, 100.0], 10, 1),
+    "gps_l1cd": ("gps-l1cd", list(range(1, 33)), [-7000.0, 7000.0, 100.0], 20, 1),
+    "gps_l2cm": ("gps-l2cm", list(range(1, 33)), [-7000.0, 7000.0, 100.0], 60, 1),
+    "gal_e6b": ("galileo-e6b", list(range(1, 51)), [-9000.0, 9000.0, 200.0], 4, 1),
     "cfg5_e1b": ("galileo-e1b", list(range(1, 51)), [-10000.0, 10000.0, 100.0], 10, 1),
 }
 
