@@ -338,7 +338,7 @@ int gacq_use_null_stream(gacq_ctx* ctx) {
 }
 
 int gacq_set_engine(gacq_ctx* ctx, int engine) {
-  if (!ctx || engine < 0 || engine > 3) return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_set_engine: engine must be 0..3");
+  if (!ctx || engine < 0 || engine > 4) return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_set_engine: engine must be 0..4");
   ctx->engine = engine;
   return GACQ_OK;
 }
@@ -425,7 +425,13 @@ static int build_signal(gacq_ctx* ctx, const gacq_sigdesc* desc, const std::vect
     if (rc == GACQ_OK && hipMemcpyAsync(tmp, host.data(), bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
       rc = set_error(ctx, GACQ_ERR_HIP, "replica upload failed");
     if (rc == GACQ_OK) rc = pfa_forward(ctx, tmp, 0, nprn, s->N, s->N, nullptr, 1, 1, nullptr, s->spectra_pfa, false);
-    if (rc == GACQ_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "radix-31 code spectrum failed");
+    if (rc == GACQ_OK && s->N / split_radix(s->N) == 4096) {
+      // split engine with LDS inner transforms (N = R*4096): code spectra as R lane-pair rows per item
+      if (hipMalloc((void**)&s->spectra_lds, bytes) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "hipMalloc for split/LDS spectra failed");
+      if (rc == GACQ_OK) rc = pfa_forward(ctx, tmp, 0, nprn, s->N, s->N, nullptr, 1, 1, nullptr, s->spectra_lds, false, false);
+      if (rc == GACQ_OK) rc = lds_inner_forward(ctx, s->spectra_lds, (long)nprn * split_radix(s->N), false);
+    }
+    if (rc == GACQ_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "split-engine code spectrum failed");
     if (tmp) (void)hipFree(tmp);
   }
   if (rc == GACQ_OK && lds_supported(s->N)) {
@@ -557,9 +563,14 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
   const bool use_lds = (ctx->engine == 2) || (ctx->engine == 0 && lds_supported(N) && !d_qrow);
   if (ctx->engine == 2 && (!lds_supported(N) || d_qrow))
     return set_error(ctx, GACQ_ERR_UNSUPPORTED, "engine 2 (LDS FFT) does not support N=%d%s", N, d_qrow ? " with row dump" : "");
-  const bool use_pfa = (ctx->engine == 3) || (ctx->engine == 0 && pfa_supported(N));
+  const int R = split_radix(N);
+  const bool split_lds_ok = R != 0 && N / R == 4096;
+  const bool use_split_lds = (ctx->engine == 4) || (ctx->engine == 0 && split_lds_ok);
+  if (ctx->engine == 4 && !split_lds_ok)
+    return set_error(ctx, GACQ_ERR_UNSUPPORTED, "engine 4 (split with LDS inner transforms) does not support N=%d", N);
+  const bool use_pfa = use_split_lds || (ctx->engine == 3) || (ctx->engine == 0 && pfa_supported(N));
   if (ctx->engine == 3 && !pfa_supported(N))
-    return set_error(ctx, GACQ_ERR_UNSUPPORTED, "engine 3 (radix-31 split) does not support N=%d", N);
+    return set_error(ctx, GACQ_ERR_UNSUPPORTED, "engine 3 (split with rocFFT inner transforms) does not support N=%d", N);
 
   // epochs per pass so that the forward-spectra buffer respects the workspace limit
   const size_t x_epoch_bytes = sizeof(float2) * (size_t)F * D * B * N;
@@ -586,7 +597,9 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
     } else {
       if (use_pfa) {
         stage_begin(ctx, 0);
-        rc = pfa_forward(ctx, xe, nsamp, rows_x, n, N, (const double*)ctx->freq.p, F * D, B, (const float2*)ctx->tab.p, X, true);
+        rc = pfa_forward(ctx, xe, nsamp, rows_x, n, N, (const double*)ctx->freq.p, F * D, B, (const float2*)ctx->tab.p, X, true,
+                         !use_split_lds);
+        if (rc == GACQ_OK && use_split_lds) rc = lds_inner_forward(ctx, X, rows_x * R, true);
         stage_end(ctx);
         if (rc != GACQ_OK) return rc;
       } else {
@@ -608,6 +621,18 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
       float2* Y = (float2*)ctx->Y.p;
       for (long g0 = 0; g0 < groups; g0 += gc) {
         const long ng = std::min(gc, groups - g0);
+        if (use_split_lds) {
+          stage_begin(ctx, 6);
+          rc = lds_inner_correlate(ctx, X, sig->spectra_lds, (const int*)ctx->items.p, (const int*)ctx->fset.p, g0, ng, P, F, D, B, R,
+                                   N, Y);                                       // K2 + inner inverse FFT + twiddle, fused
+          stage_end(ctx);
+          if (rc != GACQ_OK) return rc;
+          stage_begin(ctx, 4);
+          rc = pfa_inverse_reduce(ctx, Y, rows, g0, ng, B, N, d_qrow, false);   // outer inverse DFT + |.| + reduce
+          stage_end(ctx);
+          if (rc != GACQ_OK) return rc;
+          continue;
+        }
         stage_begin(ctx, 2);
         hipLaunchKernelGGL(conj_mul_kernel, dim3((unsigned)(ng * B * chunksN)), dim3(kBlock), 0, st, X,
                            use_pfa ? sig->spectra_pfa : sig->spectra, Y,
@@ -779,7 +804,7 @@ int gacq_debug_row(gacq_sig* sig, const float* x_iq, size_t nsamp, int item, dou
   GACQ_HIP(ctx, hipMalloc((void**)&d_q, sizeof(float) * sig->N));
   GACQ_HIP(ctx, hipMemcpyAsync(ctx->xstage.p, x_iq, sizeof(float2) * need, hipMemcpyHostToDevice, ctx->stream));
   const int saved = ctx->engine;
-  ctx->engine = (saved == 3) ? 3 : 1;      // row dump exists in the rocFFT pipeline and the radix-31 split
+  ctx->engine = (saved == 3 || saved == 4) ? saved : 1;      // row dump: rocFFT pipeline and the split engines
   rc = launch_search(sig, (const float2*)ctx->xstage.p, need, 1, &item, 1, &doppler, 1, bias_hz != 0.0 ? &bias_hz : nullptr, blocks,
                      (gacq_peak*)ctx->out_peaks.p, d_q);
   ctx->engine = saved;

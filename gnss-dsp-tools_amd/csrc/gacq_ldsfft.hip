@@ -138,6 +138,76 @@ __global__ __launch_bounds__(kBlock) void lds_forward_kernel(const float2* __res
   }
 }
 
+// ---- inner transforms of the split engine (N = R * 4096, gacq_split.hip) -----------------------------
+// In-place forward FFT of natural-order rows (the outer stage's A[k1][n2]); output in the lane-pair layout,
+// conjugated for sample spectra (CONJ) and plain for code spectra.
+template <bool CONJ>
+__global__ __launch_bounds__(kBlock) void lds_inner_forward_kernel(float2* __restrict__ rows, const float2* __restrict__ tw) {
+  __shared__ v2 lds[kLdsElems];
+  const int t = threadIdx.x;
+  float2* row = rows + (long)blockIdx.x * kLdsN;
+  v2 v[kR];
+#pragma unroll
+  for (int j = 0; j < kR; j++) v[j] = ld2(row + t + 256 * j);
+  fft4096<false>(v, lds, ld2(tw + t), ld2(tw + 16 * (t & 15)));
+  // every lane has read its 16 inputs before the first exchange barrier, so the row can be overwritten in place
+#pragma unroll
+  for (int jp = 0; jp < kR / 2; jp++) {
+    const v2 a = v[rev16(2 * jp)], b = v[rev16(2 * jp + 1)];
+    *reinterpret_cast<float4*>(row + jp * 512 + 2 * t) = CONJ ? make_float4(a.x, -a.y, b.x, -b.y) : make_float4(a.x, a.y, b.x, b.y);
+  }
+}
+
+// Z'[(g,b)][k1][n2] = W_N^{-n2 k1} * IFFT_4096( C_p[k1][.] * X[e,f,d,b][k1][.] )[n2]      (K2 + inner inverse + twiddle)
+// one workgroup per (group, block, k1); twn holds W_N^m for m < 256 R.
+__global__ __launch_bounds__(kBlock, 4) void lds_inner_correlate_kernel(const float2* __restrict__ X, const float2* __restrict__ C,
+                                                                        const int* __restrict__ items, const int* __restrict__ fset,
+                                                                        const float2* __restrict__ tw, const float2* __restrict__ twn,
+                                                                        float2* __restrict__ Z, long g0, int P, int F, int D, int B,
+                                                                        int R) {
+  __shared__ v2 lds[kLdsElems];
+  const int t = threadIdx.x;
+  const long ry = blockIdx.x;                  // ((gl*B + b)*R + k1)
+  const int k1 = (int)(ry % R);
+  const long gb = ry / R;
+  const int b = (int)(gb % B);
+  const long g = g0 + gb / B;
+  const int d = (int)(g % D);
+  const long ep = g / D;
+  const int p = (int)(ep % P);
+  const long e = ep / P;
+  const __amdgpu_buffer_rsrc_t xres = row_rsrc(X + ((((e * F + fset[p]) * D + d) * (long)B + b) * R + k1) * kLdsN);
+  const __amdgpu_buffer_rsrc_t cres = row_rsrc(C + ((long)items[p] * R + k1) * kLdsN);
+  const unsigned lane_off = (unsigned)t * 16u;
+  v2 v[kR];
+#pragma unroll
+  for (int jp = 0; jp < kR / 2; jp++) {
+    v2 c0, c1, x0, x1;
+    ld_pair(cres, lane_off, jp, c0, c1);
+    ld_pair(xres, lane_off, jp, x0, x1);
+    v[2 * jp] = cmul(c0, x0);
+    v[2 * jp + 1] = cmul(c1, x1);
+  }
+  fft4096<true>(v, lds, ld2(tw + t), ld2(tw + 16 * (t & 15)));
+  float2* dst = Z + ry * (long)kLdsN + t;
+  if (k1 == 0) {
+#pragma unroll
+    for (int k = 0; k < kR; k++) { const v2 o = v[rev16(k)]; dst[256 * k] = make_float2(o.x, o.y); }
+  } else {
+    // lane holds n2 = t + 256 k: W_N^{-k1 (t + 256 k)} = conj(W_N^{k1 t}) * conj(W_N^{256 k1})^k
+    v2 base = ld2(twn + k1 * t), step = ld2(twn + 256 * k1);
+    base.y = -base.y;
+    step.y = -step.y;
+    TwPow tp;
+    tp.init<15>(step);
+#pragma unroll
+    for (int k = 0; k < kR; k++) {
+      const v2 o = tp.apply(cmul(v[rev16(k)], base), k);
+      dst[256 * k] = make_float2(o.x, o.y);
+    }
+  }
+}
+
 // natural -> lane-pair layout for the code spectra (once per signal)
 __global__ __launch_bounds__(kBlock) void lds_permute_kernel(const float2* __restrict__ nat, float2* __restrict__ perm) {
   const long row = blockIdx.x;
@@ -375,6 +445,50 @@ int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const i
   CorrKernel kern = b1 ? kVariants[variant].b1 : kVariants[variant].bn;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, X, spectra, d_items, d_fset, tw, rows, nepoch,
                      nitems, F, D, B, pch, nchunk);
+  GACQ_HIP(ctx, hipGetLastError());
+  return GACQ_OK;
+}
+
+// ---- inner stages of the split engine (N = R*4096) -------------------------------------------------------
+namespace {
+struct BigTw { int N; int device; float2* p; };
+std::vector<BigTw> g_bigtw;
+// W_N^m for m < 256 R
+int big_twiddles(gacq_ctx* ctx, int N, int R, const float2** out) {
+  for (const BigTw& t : g_bigtw) if (t.N == N && t.device == ctx->device) { *out = t.p; return GACQ_OK; }
+  const int cnt = 256 * R;
+  std::vector<float2> h(cnt);
+  for (int k = 0; k < cnt; k++) {
+    const double a = -2.0 * M_PI * (double)k / (double)N;
+    h[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+  }
+  BigTw t{N, ctx->device, nullptr};
+  GACQ_HIP(ctx, hipMalloc((void**)&t.p, sizeof(float2) * cnt));
+  GACQ_HIP(ctx, hipMemcpy(t.p, h.data(), sizeof(float2) * cnt, hipMemcpyHostToDevice));
+  g_bigtw.push_back(t);
+  *out = t.p;
+  return GACQ_OK;
+}
+}  // namespace
+
+int lds_inner_forward(gacq_ctx* ctx, float2* rows, long nrows, bool conj) {
+  const float2* tw;
+  int rc = twiddle_table(ctx, &tw);
+  if (rc != GACQ_OK) return rc;
+  if (conj) hipLaunchKernelGGL(lds_inner_forward_kernel<true>, dim3((unsigned)nrows), dim3(kBlock), 0, ctx->stream, rows, tw);
+  else hipLaunchKernelGGL(lds_inner_forward_kernel<false>, dim3((unsigned)nrows), dim3(kBlock), 0, ctx->stream, rows, tw);
+  GACQ_HIP(ctx, hipGetLastError());
+  return GACQ_OK;
+}
+
+int lds_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const int* d_items, const int* d_fset, long g0,
+                        long ng, int P, int F, int D, int B, int R, int N, float2* Z) {
+  const float2 *tw, *twn;
+  int rc = twiddle_table(ctx, &tw);
+  if (rc != GACQ_OK) return rc;
+  if ((rc = big_twiddles(ctx, N, R, &twn)) != GACQ_OK) return rc;
+  hipLaunchKernelGGL(lds_inner_correlate_kernel, dim3((unsigned)(ng * B * R)), dim3(kBlock), 0, ctx->stream, X, spectra, d_items,
+                     d_fset, tw, twn, Z, g0, P, F, D, B, R);
   GACQ_HIP(ctx, hipGetLastError());
   return GACQ_OK;
 }

@@ -228,7 +228,7 @@ int split_radix(int N) {
 bool pfa_supported(int N) { return split_radix(N) != 0; }
 
 int pfa_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, long rows, int n, int N, const double* d_freq, int FD, int B,
-                const float2* tab, float2* X, bool mix) {
+                const float2* tab, float2* X, bool mix, bool inner) {
   const int R = split_radix(N);
   if (!R) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "split engine: N=%d not supported", N);
   const int M = N / R;
@@ -241,10 +241,11 @@ int pfa_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, long rows, int n, 
     default: rc = launch_forward<4>(ctx, x, nsamp, rows, n, M, d_freq, FD, B, tab, tw, X, mix); break;
   }
   if (rc != GACQ_OK) return rc;
+  if (!inner) return GACQ_OK;
   return fft_exec(ctx, M, rows * R, false, X);            // inner transforms, rows contiguous
 }
 
-int pfa_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng, int B, int N, float* q_out) {
+int pfa_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng, int B, int N, float* q_out, bool inner) {
   const int R = split_radix(N);
   if (!R) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "split engine: N=%d not supported", N);
   const int M = N / R;
@@ -252,14 +253,14 @@ int pfa_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng,
   int rc = base_twiddles(ctx, N, M, &tw);
   if (rc != GACQ_OK) return rc;
   const int chunks = (M + kBlock - 1) / kBlock;
-  if ((rc = fft_exec(ctx, M, ng * B * R, true, Y)) != GACQ_OK) return rc;
+  if (inner && (rc = fft_exec(ctx, M, ng * B * R, true, Y)) != GACQ_OK) return rc;
   if ((rc = ensure(ctx, ctx->partial, sizeof(RowRec) * (size_t)ng * chunks)) != GACQ_OK) return rc;
   RowRec* partial = (RowRec*)ctx->partial.p;
   const float inv_n = 1.0f / (float)N;
   switch (R) {
-    case 31: rc = launch_inverse<31>(ctx, Y, partial, tw, M, B, ng, inv_n, q_out, true); break;
-    case 16: rc = launch_inverse<16>(ctx, Y, partial, tw, M, B, ng, inv_n, q_out, true); break;
-    default: rc = launch_inverse<4>(ctx, Y, partial, tw, M, B, ng, inv_n, q_out, true); break;
+    case 31: rc = launch_inverse<31>(ctx, Y, partial, tw, M, B, ng, inv_n, q_out, inner); break;
+    case 16: rc = launch_inverse<16>(ctx, Y, partial, tw, M, B, ng, inv_n, q_out, inner); break;
+    default: rc = launch_inverse<4>(ctx, Y, partial, tw, M, B, ng, inv_n, q_out, inner); break;
   }
   if (rc != GACQ_OK) return rc;
   hipLaunchKernelGGL(split_combine_kernel, dim3((unsigned)((ng + 127) / 128)), dim3(128), 0, ctx->stream, (const RowRec*)partial, rows,

@@ -94,7 +94,8 @@ int gacq_set_stream(gacq_ctx* ctx, void* hip_stream);
  * entered a stream context; needed so that work is ordered with collectives issued on that stream. */
 int gacq_use_null_stream(gacq_ctx* ctx);
 /* Engine selection: 0 = auto, 1 = rocFFT pipeline (any N), 2 = LDS-resident FFT kernels (N = 4096),
- * 3 = radix-31 split (N = 31*M: 61380, 30690) with rocFFT inner transforms. */
+ * 3 = split engine, outer radix 31/16/4 + rocFFT inner transforms (N = 61380, 30690, 65536, 16384),
+ * 4 = split engine with the inner transforms on the LDS FFT kernels (N = 65536, 16384). */
 int gacq_set_engine(gacq_ctx* ctx, int engine);
 /* Upper bound for the library-owned correlation workspace in bytes (default 4 GiB). */
 int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes);

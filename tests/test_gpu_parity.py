@@ -333,3 +333,38 @@ def test_radix31_code_spectrum_is_a_permutation_of_the_natural_one(engine):
     for a, b in zip(res[1], res[3]):
         assert a[1] == b[1] and a[2] == b[2]
         assert float(a[0]) == pytest.approx(float(b[0]), rel=5e-6)
+
+
+SPLIT_LDS_CASES = ["cfg3_e1b_subset", "cfg3_e1c_subset", "e1b_ms12", "cfg5_b1i_ms10", "b2i_ms2", "cfg5_glonass_l1", "glonass_l2"]
+
+
+@pytest.mark.parametrize("cid", SPLIT_LDS_CASES)
+@pytest.mark.parametrize("eng", [1, 3, 4])
+def test_split_engines_match_reference_golden_pow2(engine, golden_cases, cid, eng):
+    """N = 65536 / 16384: rocFFT pipeline (1), split with rocFFT inner (3), split with fused LDS inner transforms (4)."""
+    case = golden_cases[cid]
+    x = case_iq(case)
+    engine.set_engine(eng)
+    try:
+        got = engine.search_all(case["script"], x, case["items"], case["doppler_search"], case["ms"])
+    finally:
+        engine.set_engine(0)
+    _assert_results(got, case["results"], case)
+
+
+def test_split_lds_rows_match_reference_rows(engine, golden_cases, golden_rows):
+    """Row-level check of engine 4 against the reference's q rows (B1I N=16384 B=10, GLONASS N=16384 with channel bias)."""
+    from gnss_dsp_tools_amd import signals
+    for key, want in golden_rows.items():
+        cid, item, dop = key.split("|")
+        case = golden_cases[cid]
+        sig = signals.get(case["script"])
+        if sig.nfft != 16384:
+            continue
+        engine.set_engine(4)
+        try:
+            q = engine.debug_row(sig, case_iq(case), int(item), float(dop), sig.blocks(case["ms"]))
+        finally:
+            engine.set_engine(0)
+        assert int(np.argmax(q)) == int(np.argmax(want)), key
+        assert np.max(np.abs(q.astype(np.float64) - want)) / np.max(want) < 5e-6, key
