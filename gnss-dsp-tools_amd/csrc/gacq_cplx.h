@@ -174,6 +174,77 @@ template <bool INV> struct OuterDft<16, INV> {
   }
 };
 
+
+// cos/sin(2 pi m / R) over the full period for the composite outer radices 20 = 4*5 and 40 = 8*5
+template <int R> struct TrigN;
+template <> struct TrigN<8> {
+  static constexpr float c[8] = {1.f, 0.707106781f, 0.f, -0.707106781f, -1.f, -0.707106781f, 0.f, 0.707106781f};
+  static constexpr float s[8] = {0.f, 0.707106781f, 1.f, 0.707106781f, 0.f, -0.707106781f, -1.f, -0.707106781f};
+};
+template <> struct TrigN<20> {
+  static constexpr float c[20] = {1.f, 0.951056516f, 0.809016994f, 0.587785252f, 0.309016994f, 0.f, -0.309016994f, -0.587785252f, -0.809016994f, -0.951056516f, -1.f, -0.951056516f, -0.809016994f, -0.587785252f, -0.309016994f, 0.f, 0.309016994f, 0.587785252f, 0.809016994f, 0.951056516f};
+  static constexpr float s[20] = {0.f, 0.309016994f, 0.587785252f, 0.809016994f, 0.951056516f, 1.f, 0.951056516f, 0.809016994f, 0.587785252f, 0.309016994f, 0.f, -0.309016994f, -0.587785252f, -0.809016994f, -0.951056516f, -1.f, -0.951056516f, -0.809016994f, -0.587785252f, -0.309016994f};
+};
+template <> struct TrigN<40> {
+  static constexpr float c[40] = {1.f, 0.987688341f, 0.951056516f, 0.891006524f, 0.809016994f, 0.707106781f, 0.587785252f, 0.4539905f, 0.309016994f, 0.156434465f, 0.f, -0.156434465f, -0.309016994f, -0.4539905f, -0.587785252f, -0.707106781f, -0.809016994f, -0.891006524f, -0.951056516f, -0.987688341f, -1.f, -0.987688341f, -0.951056516f, -0.891006524f, -0.809016994f, -0.707106781f, -0.587785252f, -0.4539905f, -0.309016994f, -0.156434465f, 0.f, 0.156434465f, 0.309016994f, 0.4539905f, 0.587785252f, 0.707106781f, 0.809016994f, 0.891006524f, 0.951056516f, 0.987688341f};
+  static constexpr float s[40] = {0.f, 0.156434465f, 0.309016994f, 0.4539905f, 0.587785252f, 0.707106781f, 0.809016994f, 0.891006524f, 0.951056516f, 0.987688341f, 1.f, 0.987688341f, 0.951056516f, 0.891006524f, 0.809016994f, 0.707106781f, 0.587785252f, 0.4539905f, 0.309016994f, 0.156434465f, 0.f, -0.156434465f, -0.309016994f, -0.4539905f, -0.587785252f, -0.707106781f, -0.809016994f, -0.891006524f, -0.951056516f, -0.987688341f, -1.f, -0.987688341f, -0.951056516f, -0.891006524f, -0.809016994f, -0.707106781f, -0.587785252f, -0.4539905f, -0.309016994f, -0.156434465f};
+};
+
+// W_R^m as an SGPR-pair constant (forward exp(-2 pi i m/R); INV: conjugate)
+template <int R, bool INV> __device__ __forceinline__ v2 wconst(int m) {
+  const v2 w = {TrigN<R>::c[m % R], INV ? TrigN<R>::s[m % R] : -TrigN<R>::s[m % R]};
+  return w;
+}
+
+// 8-point DFT, natural order in and out (two DFT4 + W8 combine)
+template <bool INV> __device__ __forceinline__ void dft8(v2 (&x)[8]) {
+  v2 e0 = x[0], e1 = x[2], e2 = x[4], e3 = x[6], o0 = x[1], o1 = x[3], o2 = x[5], o3 = x[7];
+  dft4<INV, false>(e0, e1, e2, e3);
+  dft4<INV, false>(o0, o1, o2, o3);
+  o1 = cmul_k(o1, wconst<8, INV>(1));
+  o3 = cmul_k(o3, wconst<8, INV>(3));
+  x[0] = e0 + o0;  x[4] = e0 - o0;
+  x[1] = e1 + o1;  x[5] = e1 - o1;
+  x[2] = INV ? add_i(e2, o2) : sub_i(e2, o2);      // W8^2 = -/+ i
+  x[6] = INV ? sub_i(e2, o2) : add_i(e2, o2);
+  x[3] = e3 + o3;  x[7] = e3 - o3;
+}
+
+// R = RA * 5 (RA = 4 or 8): n = 5 a + b, k = ka + RA kb:
+//   X[ka + RA kb] = sum_b W5^{b kb} ( W_R^{b ka} sum_a x[5a + b] W_RA^{a ka} )
+template <int RA, bool INV, class Sink> __device__ __forceinline__ void dft_ra5(v2 (&x)[RA * 5], Sink&& sink) {
+  constexpr int R = RA * 5;
+#pragma unroll
+  for (int b = 0; b < 5; b++) {
+    if (RA == 4) {
+      dft4<INV, false>(x[b], x[5 + b], x[10 + b], x[15 + b]);                    // T[b][ka] left at x[5 ka + b]
+    } else {
+      v2 t[8];
+#pragma unroll
+      for (int a = 0; a < 8; a++) t[a] = x[5 * a + b];
+      dft8<INV>(t);
+#pragma unroll
+      for (int a = 0; a < 8; a++) x[5 * a + b] = t[a];
+    }
+    if (b > 0) {
+#pragma unroll
+      for (int ka = 1; ka < RA; ka++) x[5 * ka + b] = cmul_k(x[5 * ka + b], wconst<R, INV>(b * ka));
+    }
+  }
+#pragma unroll
+  for (int ka = 0; ka < RA; ka++) {
+    const v2 col[5] = {x[5 * ka], x[5 * ka + 1], x[5 * ka + 2], x[5 * ka + 3], x[5 * ka + 4]};
+    dft_prime<5, INV>(col, [&](int kb, v2 val) { sink(ka + RA * kb, val); });
+  }
+}
+
+template <bool INV> struct OuterDft<20, INV> {
+  template <class Sink> static __device__ __forceinline__ void run(v2 (&x)[20], Sink&& sink) { dft_ra5<4, INV>(x, sink); }
+};
+template <bool INV> struct OuterDft<40, INV> {
+  template <class Sink> static __device__ __forceinline__ void run(v2 (&x)[40], Sink&& sink) { dft_ra5<8, INV>(x, sink); }
+};
+
 // w^k for k = 0..43 from base-4 digits: w^k = p[k & 3] * q[k >> 2], p[a] = w^a, q[b] = w^(4b); multiplication depth <= 5
 struct TwPow {
   v2 p[4], q[11];

@@ -14,7 +14,7 @@
 //   E6, acquire-galileo-e6b.py:19-24).  rocFFT has no radix-31 butterfly and falls back to Bluestein for these lengths
 //   (three transforms of twice the size per FFT); M = 4*5*9*11 is native to it.  The DFT-31 uses the conjugate symmetry
 //   of W_31 (gacq_cplx.h: dft_prime), a quarter of the 31 x 31 complex products.
-// R = 4 / 16, M = 4096 (N = 16384 / 65536: B1I, GLONASS, E1B/E1C): the inner transforms are single-kernel and the
+// R = 4 / 16 / 20 / 40, M = 4096 (N = 16384 / 65536 / 81920 / 163840: B1I, GLONASS, E1B/E1C, L1C, B1C, L2CM): the inner transforms are single-kernel and the
 //   magnitude/reduce stage is fused into the outer inverse DFT, so the correlation workspace is read once less.
 #include "gacq_common.h"
 #include "gacq_cplx.h"
@@ -220,6 +220,8 @@ namespace gacq {
 
 int split_radix(int N) {
   if (N > 0 && N % 31 == 0 && smooth(N / 31) && N / 31 >= 64) return 31;
+  if (N == 163840) return 40;
+  if (N == 81920) return 20;
   if (N == 65536) return 16;
   if (N == 16384) return 4;
   return 0;
@@ -237,6 +239,8 @@ int pfa_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, long rows, int n, 
   if (rc != GACQ_OK) return rc;
   switch (R) {
     case 31: rc = launch_forward<31>(ctx, x, nsamp, rows, n, M, d_freq, FD, B, tab, tw, X, mix); break;
+    case 40: rc = launch_forward<40>(ctx, x, nsamp, rows, n, M, d_freq, FD, B, tab, tw, X, mix); break;
+    case 20: rc = launch_forward<20>(ctx, x, nsamp, rows, n, M, d_freq, FD, B, tab, tw, X, mix); break;
     case 16: rc = launch_forward<16>(ctx, x, nsamp, rows, n, M, d_freq, FD, B, tab, tw, X, mix); break;
     default: rc = launch_forward<4>(ctx, x, nsamp, rows, n, M, d_freq, FD, B, tab, tw, X, mix); break;
   }
@@ -259,6 +263,8 @@ int pfa_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng,
   const float inv_n = 1.0f / (float)N;
   switch (R) {
     case 31: rc = launch_inverse<31>(ctx, Y, partial, tw, M, B, ng, inv_n, q_out, inner); break;
+    case 40: rc = launch_inverse<40>(ctx, Y, partial, tw, M, B, ng, inv_n, q_out, inner); break;
+    case 20: rc = launch_inverse<20>(ctx, Y, partial, tw, M, B, ng, inv_n, q_out, inner); break;
     case 16: rc = launch_inverse<16>(ctx, Y, partial, tw, M, B, ng, inv_n, q_out, inner); break;
     default: rc = launch_inverse<4>(ctx, Y, partial, tw, M, B, ng, inv_n, q_out, inner); break;
   }

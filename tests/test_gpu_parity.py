@@ -335,13 +335,15 @@ def test_radix31_code_spectrum_is_a_permutation_of_the_natural_one(engine):
         assert float(a[0]) == pytest.approx(float(b[0]), rel=5e-6)
 
 
-SPLIT_LDS_CASES = ["cfg3_e1b_subset", "cfg3_e1c_subset", "e1b_ms12", "cfg5_b1i_ms10", "b2i_ms2", "cfg5_glonass_l1", "glonass_l2"]
+SPLIT_LDS_CASES = ["cfg3_e1b_subset", "cfg3_e1c_subset", "e1b_ms12", "cfg5_b1i_ms10", "b2i_ms2", "cfg5_glonass_l1", "glonass_l2",
+                   "gps_l1cd", "bds_b1cp", "gps_l2cm"]
 
 
 @pytest.mark.parametrize("cid", SPLIT_LDS_CASES)
 @pytest.mark.parametrize("eng", [1, 3, 4])
 def test_split_engines_match_reference_golden_pow2(engine, golden_cases, cid, eng):
-    """N = 65536 / 16384: rocFFT pipeline (1), split with rocFFT inner (3), split with fused LDS inner transforms (4)."""
+    """N = 65536 / 16384 / 81920 / 163840 (outer radix 16 / 4 / 20 / 40): rocFFT pipeline (1), split with rocFFT inner
+    transforms (3), split with fused LDS inner transforms (4)."""
     case = golden_cases[cid]
     x = case_iq(case)
     engine.set_engine(eng)
