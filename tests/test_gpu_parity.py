@@ -370,3 +370,43 @@ def test_split_lds_rows_match_reference_rows(engine, golden_cases, golden_rows):
             engine.set_engine(0)
         assert int(np.argmax(q)) == int(np.argmax(want)), key
         assert np.max(np.abs(q.astype(np.float64) - want)) / np.max(want) < 5e-6, key
+
+
+@pytest.mark.parametrize("name,items,ds,ms", [
+    ("gps-l1", [3, 4, 11, 28], [-1500.0, 2000.0, 250.0], 3),            # LDS engine: epochs/items chunking irrelevant, rows buffer only
+    ("beidou-b1i", [6, 7, 33], [1000.0, 2000.0, 250.0], 4),              # split + LDS inner, B = 4
+    ("gps-l5i", [7, 8], [1200.0, 2000.0, 200.0], 2),                     # split radix 31 + rocFFT inner
+    ("galileo-e1b", [5, 24], [1000.0, 1750.0, 250.0], 8),                # split radix 16
+])
+def test_tiny_workspace_forces_chunking_same_results(name, items, ds, ms):
+    """Workspace limit of 1 MiB (< one correlation row for the big lengths): the group / epoch chunk loops must give the
+    same answers as one pass."""
+    from gnss_dsp_tools_amd import acquire, signals, synth
+    sig = signals.get(name)
+    x = synth.make_iq(sig, sig.blocks(ms), 606, [(items[0], 0.4, 1537.0, 1201)])
+    big = acquire.Engine(0)
+    small = acquire.Engine(0, workspace_bytes=1 << 20)
+    try:
+        want = big.search_all(sig, x, items, ds, ms)
+        for eng in (0, 1):
+            small.set_engine(eng)
+            got = small.search_all(sig, x, items, ds, ms)
+            for g, w in zip(got, want):
+                assert g[1] == w[1] and g[2] == w[2]
+                assert float(g[0]) == pytest.approx(float(w[0]), rel=5e-6)
+    finally:
+        big.close()
+        small.close()
+
+
+def test_maximum_default_integration_time_gps_l1(engine):
+    """The CLI default --time 80 (80 non-coherent blocks, acquire-gps-l1.py:67) on the default Doppler grid, vs the oracle."""
+    from gnss_dsp_tools_amd import signals, synth
+    from oracle import acq_oracle
+    sig = signals.get("gps-l1")
+    items = [3, 11, 19, 30]
+    ds = [-7000.0, 7000.0, 200.0]
+    x = synth.make_iq(sig, 80, 8080, [(11, 0.05, 1537.0, 1201), (19, 0.03, -3262.0, 77)])
+    got = engine.search_all(sig, x, items, ds, 80)
+    want = [acq_oracle.search_script("gps-l1", x.astype(np.complex128), it, ds, 80) for it in items]
+    _assert_results(got, [[float(v) for v in w] for w in want], {"id": "gps-l1 ms=80", "items": items})
