@@ -83,6 +83,9 @@ SYMBOLS = {
                                             ctypes.c_void_p]),
     "gacq_finalize": (ctypes.c_int, [ctypes.POINTER(SigDesc), ctypes.POINTER(Peak), ctypes.c_int, c_int_p, ctypes.c_int,
                                      c_double_p, ctypes.c_int, ctypes.POINTER(Result)]),
+    "gacq_firwin_hann": (ctypes.c_int, [ctypes.c_int, ctypes.c_double, c_double_p]),
+    "gacq_frontend_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_double, ctypes.c_double,
+                                         c_double_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t, ctypes.c_void_p]),
     "gacq_set_profiling": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "gacq_get_stage_time": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, ctypes.POINTER(ctypes.c_long)]),
     "gacq_reset_stage_times": (ctypes.c_int, [ctypes.c_void_p]),

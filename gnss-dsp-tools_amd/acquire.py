@@ -233,6 +233,25 @@ class Engine:
     def finalize(self, name, items, peaks, dopplers, shard_d0=None):
         return finalize(name, items, peaks, dopplers, shard_d0)
 
+    # -- front-end on the GPU (acquire-gps-l1.py:87-96) ---------------------------------------------------
+    def frontend_dev(self, name, iq_int8, fs, coffset, ms_pad):
+        """iq_int8: numpy int8 array [n, 2] (or flat interleaved) or a torch int8 CUDA tensor; returns a torch complex64
+        CUDA tensor with ms_pad ms of samples at the signal's internal rate, ready for search_batch_dev."""
+        import torch
+        sig = _signals.get(name) if isinstance(name, str) else name
+        if not torch.is_tensor(iq_int8):
+            iq_int8 = torch.from_numpy(np.array(iq_int8, dtype=np.int8, copy=True)).to("cuda:%d" % self.device)
+        iq_int8 = iq_int8.contiguous().view(-1)
+        n_in = iq_int8.numel() // 2
+        per_ms = int(round(sig.fs * 0.001))
+        n_out = int(ms_pad) * per_ms
+        taps = firwin_hann(161, sig.fir_cutoff / (fs / 2))
+        out = torch.empty(n_out, dtype=torch.complex64, device=iq_int8.device)
+        nat.check(nat.lib.gacq_frontend_dev(self._ctx, ctypes.c_void_p(iq_int8.data_ptr()), n_in, float(fs), float(coffset),
+                                            taps.ctypes.data_as(nat.c_double_p), len(taps), sig.fs, n_out,
+                                            ctypes.c_void_p(out.data_ptr())), self._ctx)
+        return out
+
     def merge_peaks_dev(self, gathered, shard_d0, out=None):
         """gathered: torch float64 CUDA tensor [nshard, ..., 2] of gacq_peak records (all_gather output);
         returns the merged [..., 2] tensor with global Doppler indices (device-side, asynchronous)."""
@@ -245,6 +264,13 @@ class Engine:
         nat.check(nat.lib.gacq_merge_peaks_dev(self._ctx, ctypes.c_void_p(gathered.data_ptr()), nshard,
                                                d0.ctypes.data_as(nat.c_int_p), n, ctypes.c_void_p(out.data_ptr())), self._ctx)
         return out
+
+
+def firwin_hann(ntaps, cutoff_norm):
+    """scipy.signal.firwin(ntaps, cutoff_norm, window='hann') from the native library (host)."""
+    taps = np.empty(int(ntaps), dtype=np.float64)
+    nat.check(nat.lib.gacq_firwin_hann(int(ntaps), float(cutoff_norm), taps.ctypes.data_as(nat.c_double_p)))
+    return taps
 
 
 def descriptor(name):

@@ -54,13 +54,22 @@ def run(name, argv, out=sys.stdout):
     ms_pad = ms + 5                             # acquire-gps-l1.py:80
     n = int(args.sample_rate * 0.001 * ms_pad)
     with open(args.input_filename, "rb") as fp:
-        x = frontend.read_iq_int8(fp, n)
-    if x is None:
-        raise SystemExit("input file too short: need %d complex int8 samples" % n)
-    x = frontend.condition(x, args.sample_rate, args.carrier_offset, sig, ms_pad)
+        raw = fp.read(2 * n)
+    if len(raw) != 2 * n:
+        raise SystemExit("input file too short: need %d complex int8 samples" % n)     # gnsstools/io.py:5-6 returns None here
+    import numpy as np
+    import torch
     eng = acquire.Engine(args.device)
     try:
-        results = eng.search_all(sig, x, items, doppler_search, ms)
+        # file bytes -> GPU once; front-end and search stay device-resident
+        eng.use_torch_stream()
+        iq = np.frombuffer(raw, dtype=np.int8)
+        x_dev = eng.frontend_dev(sig, iq, args.sample_rate, args.carrier_offset, ms_pad)
+        dop = acquire.doppler_grid(doppler_search)
+        blocks = max(sig.blocks(ms), 0)
+        peaks = eng.search_batch_dev(sig, x_dev.view(1, -1), items, dop, blocks)
+        torch.cuda.synchronize()
+        results = acquire.finalize(sig, items, peaks.cpu().numpy().view(acquire.PEAK_DTYPE).reshape(len(items)), dop)
     finally:
         eng.close()
     lines = [acquire.format_result(sig, it, r) for it, r in zip(items, results)]

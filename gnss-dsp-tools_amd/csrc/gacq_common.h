@@ -48,7 +48,7 @@ struct gacq_ctx {
   int engine = 0;
   size_t ws_limit = (size_t)4 << 30;
   std::map<std::pair<long, long>, gacq::FftPlan> plans;   // (N * 2 + inverse, batch)
-  gacq::DevBuf tab, xstage, X, Y, rows, freq, fset, items, out_peaks, d0, partial;
+  gacq::DevBuf tab, xstage, X, Y, rows, freq, fset, items, out_peaks, d0, partial, fe_a, fe_b, fe_taps;
   bool profiling = false;
   double stage_ms[GACQ_NSTAGES] = {0};
   long stage_n[GACQ_NSTAGES] = {0};

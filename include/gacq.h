@@ -144,6 +144,18 @@ int gacq_merge_peaks_dev(gacq_ctx* ctx, const void* d_peaks, int nshard, const i
 int gacq_finalize(const gacq_sigdesc* desc, const gacq_peak* peaks, int nshard, const int* shard_d0,
                   int nitems, const double* dopplers, int nd, gacq_result* out);
 
+/* ---------------------------------------------------------------------------------------------
+ * Front-end (SURVEY.md section 8f "next #1"): what every acquire script does to the file before search().
+ * Replaces acquire-gps-l1.py:87-96: nco.mix (fixed-point table NCO, gnsstools/nco.py:30-41),
+ * scipy.signal.filtfilt(h,[1],x) with a firwin(161, cutoff, 'hann') low-pass, np.interp resample.
+ * ------------------------------------------------------------------------------------------- */
+/* scipy.signal.firwin(ntaps, cutoff_norm, window='hann'); cutoff_norm = cutoff_hz / (fs/2). Host only. */
+int gacq_firwin_hann(int ntaps, double cutoff_norm, double* taps);
+/* d_iq_int8: interleaved signed 8-bit I/Q on the device (nsamp_in complex samples at fs_in);
+ * d_out: complex64 [nsamp_out] at fs_out, directly consumable by gacq_search_batch_dev. Asynchronous. */
+int gacq_frontend_dev(gacq_ctx* ctx, const void* d_iq_int8, size_t nsamp_in, double fs_in, double carrier_offset_hz,
+                      const double* taps, int ntaps, double fs_out, size_t nsamp_out, void* d_out);
+
 /* Per-stage GPU time from HIP events recorded on the launch stream (profiling aid for bench.py).
  * Stages: 0 mix/forward, 1 forward FFT (rocFFT), 2 conj-multiply, 3 inverse FFT (rocFFT),
  *         4 magnitude/peak reduce, 5 best-over-Doppler, 6 fused correlate kernel (LDS FFT). */
