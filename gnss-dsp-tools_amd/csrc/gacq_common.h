@@ -56,6 +56,7 @@ struct gacq_ctx {
   // last grid uploaded to freq/fset/items (skip the H2D + sync when a call repeats it, as batched loops do)
   std::vector<double> up_freq;
   std::vector<int> up_fset, up_items, up_d0;
+  std::vector<float> up_taps;
 };
 
 struct gacq_sig {

@@ -45,35 +45,67 @@ __device__ __forceinline__ float2 odd_ext_at(const float2* __restrict__ x, long 
 
 // PASS 1 (forward):  y1[j] = sum_k h[k] * e[j-k],  e = odd extension, e[m<0] := e[0];   j in [0, L), L = n + 2p
 // PASS 2 (backward): y2[j] = sum_k h[k] * y1[j+k], y1[m>=L] := y1[L-1];                 j in [p, p+n) -> out[j-p]
+// Each thread produces kOut adjacent outputs from a sliding register window: one LDS read feeds kOut taps' worth of
+// FMAs.  The tile is stored with one pad element per 32 (phys = i + i/32) so the stride-kOut lane pattern is
+// bank-conflict free; the taps are wave-uniform scalar loads.
+constexpr int kOut = 4;
+constexpr int kTile = kFeBlock * kOut;
+__device__ __forceinline__ int phys(int i) { return i + (i >> 5); }
+
 template <int PASS>
 __global__ __launch_bounds__(kFeBlock) void fe_fir_kernel(const float2* __restrict__ in, float2* __restrict__ out, long n, int p,
                                                            const float* __restrict__ taps, int ntaps) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* s_h = reinterpret_cast<float*>(smem);
-  float2* s_x = reinterpret_cast<float2*>(smem + sizeof(float) * kMaxTaps);
+  float2* s_x = reinterpret_cast<float2*>(smem);
   const long L = n + 2 * (long)p;
-  const long j0 = (long)blockIdx.x * kFeBlock + (PASS == 1 ? 0 : p);      // first output index of this tile (extended coords)
-  for (int k = threadIdx.x; k < ntaps; k += kFeBlock) s_h[k] = taps[k];
+  const long j0 = (long)blockIdx.x * kTile + (PASS == 1 ? 0 : p);      // first output index of this tile (extended coords)
   const int halo = ntaps - 1;
-  // tile of inputs: PASS 1 needs e[j0-halo .. j0+255], PASS 2 needs y1[j0 .. j0+255+halo]
-  for (int m = threadIdx.x; m < kFeBlock + halo; m += kFeBlock) {
+  // tile of inputs: PASS 1 needs e[j0-halo .. j0+kTile-1], PASS 2 needs y1[j0 .. j0+kTile-1+halo]
+  for (int m = threadIdx.x; m < kTile + halo; m += kFeBlock) {
     const long idx = (PASS == 1) ? (j0 - halo + m) : (j0 + m);
     float2 v;
     if (PASS == 1) v = odd_ext_at(in, n, p, idx < 0 ? 0 : (idx >= L ? L - 1 : idx));
     else v = in[idx >= L ? L - 1 : idx];
-    s_x[m] = v;
+    s_x[phys(m)] = v;
   }
   __syncthreads();
-  const long j = j0 + threadIdx.x;
-  const long jend = (PASS == 1) ? L : (long)p + n;
-  if (j >= jend) return;
-  float ar = 0.f, ai = 0.f;
+  const int r = threadIdx.x * kOut;
+  float ar[kOut], ai[kOut];
+#pragma unroll
+  for (int c = 0; c < kOut; c++) { ar[c] = 0.f; ai[c] = 0.f; }
+  float2 w[kOut];
   if (PASS == 1) {
-    for (int k = 0; k < ntaps; k++) { const float2 v = s_x[threadIdx.x + halo - k]; ar = fmaf(s_h[k], v.x, ar); ai = fmaf(s_h[k], v.y, ai); }
-    out[j] = make_float2(ar, ai);
+    // out_c = sum_k h[k] * s[r + c + halo - k]; window w[c] = s[r + c + halo - k]
+#pragma unroll
+    for (int c = 0; c < kOut; c++) w[c] = s_x[phys(r + c + halo)];
+    for (int k = 0; k < ntaps; k++) {
+      const float hk = taps[k];
+#pragma unroll
+      for (int c = 0; c < kOut; c++) { ar[c] = fmaf(hk, w[c].x, ar[c]); ai[c] = fmaf(hk, w[c].y, ai[c]); }
+#pragma unroll
+      for (int c = kOut - 1; c > 0; c--) w[c] = w[c - 1];                 // next k: every index moves down by one
+      const int nxt = r + halo - (k + 1);
+      w[0] = s_x[phys(nxt < 0 ? 0 : nxt)];
+    }
   } else {
-    for (int k = 0; k < ntaps; k++) { const float2 v = s_x[threadIdx.x + k]; ar = fmaf(s_h[k], v.x, ar); ai = fmaf(s_h[k], v.y, ai); }
-    out[j - p] = make_float2(ar, ai);
+    // out_c = sum_k h[k] * s[r + c + k]; window w[c] = s[r + c + k]
+#pragma unroll
+    for (int c = 0; c < kOut; c++) w[c] = s_x[phys(r + c)];
+    for (int k = 0; k < ntaps; k++) {
+      const float hk = taps[k];
+#pragma unroll
+      for (int c = 0; c < kOut; c++) { ar[c] = fmaf(hk, w[c].x, ar[c]); ai[c] = fmaf(hk, w[c].y, ai[c]); }
+#pragma unroll
+      for (int c = 0; c < kOut - 1; c++) w[c] = w[c + 1];
+      const int nxt = r + kOut + k;                                        // = r + (kOut-1) + (k+1)
+      w[kOut - 1] = s_x[phys(nxt > kTile + halo - 1 ? kTile + halo - 1 : nxt)];
+    }
+  }
+  const long jend = (PASS == 1) ? L : (long)p + n;
+#pragma unroll
+  for (int c = 0; c < kOut; c++) {
+    const long j = j0 + r + c;
+    if (j < jend) out[PASS == 1 ? j : j - p] = make_float2(ar[c], ai[c]);
   }
 }
 
@@ -132,8 +164,11 @@ int gacq_frontend_dev(gacq_ctx* ctx, const void* d_iq_int8, size_t nsamp_in, dou
   if ((rc = ensure(ctx, ctx->fe_taps, sizeof(float) * kMaxTaps)) != GACQ_OK) return rc;
   std::vector<float> h(ntaps);
   for (int i = 0; i < ntaps; i++) h[i] = (float)taps[i];
-  GACQ_HIP(ctx, hipMemcpyAsync(ctx->fe_taps.p, h.data(), sizeof(float) * ntaps, hipMemcpyHostToDevice, st));
-  GACQ_HIP(ctx, hipStreamSynchronize(st));              // h dies with this frame
+  if (h != ctx->up_taps) {
+    GACQ_HIP(ctx, hipMemcpyAsync(ctx->fe_taps.p, h.data(), sizeof(float) * ntaps, hipMemcpyHostToDevice, st));
+    GACQ_HIP(ctx, hipStreamSynchronize(st));            // h dies with this frame; a repeated filter skips copy and sync
+    ctx->up_taps = h;
+  }
   // nco.mix(x, -coffset/fs, 0): dp = floor(p*NT*2^50) = 0, df = floor(f*NT*2^50)        gnsstools/nco.py:33-34
   const double f = -carrier_offset_hz / fs_in;
   const long long df = (long long)std::floor(f * (double)kNcoTableSize * (double)(1LL << 50));
@@ -142,11 +177,12 @@ int gacq_frontend_dev(gacq_ctx* ctx, const void* d_iq_int8, size_t nsamp_in, dou
   hipLaunchKernelGGL(fe_mix_kernel, dim3((unsigned)((n + kFeBlock - 1) / kFeBlock)), dim3(kFeBlock), 0, st, (const char2*)d_iq_int8, a, n,
                      0LL, df, (const float2*)ctx->tab.p);
   GACQ_HIP(ctx, hipGetLastError());
-  const size_t smem = sizeof(float) * kMaxTaps + sizeof(float2) * (kFeBlock + ntaps);
-  hipLaunchKernelGGL(fe_fir_kernel<1>, dim3((unsigned)((L + kFeBlock - 1) / kFeBlock)), dim3(kFeBlock), smem, st, (const float2*)a, b, n, p,
+  const int tile_elems = kTile + ntaps;
+  const size_t smem = sizeof(float2) * (size_t)(tile_elems + tile_elems / 32 + 2);
+  hipLaunchKernelGGL(fe_fir_kernel<1>, dim3((unsigned)((L + kTile - 1) / kTile)), dim3(kFeBlock), smem, st, (const float2*)a, b, n, p,
                      (const float*)ctx->fe_taps.p, ntaps);
   GACQ_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(fe_fir_kernel<2>, dim3((unsigned)((n + kFeBlock - 1) / kFeBlock)), dim3(kFeBlock), smem, st, (const float2*)b, a, n, p,
+  hipLaunchKernelGGL(fe_fir_kernel<2>, dim3((unsigned)((n + kTile - 1) / kTile)), dim3(kFeBlock), smem, st, (const float2*)b, a, n, p,
                      (const float*)ctx->fe_taps.p, ntaps);
   GACQ_HIP(ctx, hipGetLastError());
   const double fsr = fs_out / fs_in;                    // acquire-gps-l1.py:91
