@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgacq.so")
+LIB_PATH = os.environ.get("GACQ_LIB") or os.path.join(_HERE, "lib", "libgacq.so")     # GACQ_LIB: profiling builds only
 
 # One HIP runtime per process: when torch is (or will be) in the process its bundled
 # libamdhip64/librocfft (same SONAMEs as /opt/rocm's) must be the ones that get bound, so it

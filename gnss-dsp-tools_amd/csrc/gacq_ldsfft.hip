@@ -29,6 +29,12 @@ constexpr int kLdsN = 4096;            // supported length (this round)
 constexpr int kPitch = 257;            // exchange-2 row pitch in complex elements
 constexpr int kLdsElems = 16 * kPitch; // 4112 complex = 32.9 KB -> 4 workgroups per CU
 
+// Ablation builds for profiling only (tools/ablate.sh): bit 0 drops the LDS traffic, bit 1 the barriers, bit 2 the
+// magnitude/reduce tail, bit 3 the twiddle multiplies.  Results are wrong by construction; never set in the product build.
+#ifndef GACQ_ABL
+#define GACQ_ABL 0
+#endif
+
 // v[rev16(k)] *= w^k for k = 1..15, powers built with multiplication depth <= 4 from the table value.
 __device__ __forceinline__ void apply_powers(v2 (&v)[kR], v2 w1) {
   const v2 w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
@@ -63,25 +69,29 @@ __device__ __forceinline__ void fft4096(v2 (&v)[kR], v2* lds, v2 wa, v2 wb, cons
   const int t = threadIdx.x;
   if (INV && !PRE) { wa.y = -wa.y; wb.y = -wb.y; }
   dft16<INV>(v);
-  if (PRE) apply_table(v, *pa); else apply_powers(v, wa);
+  if (!(GACQ_ABL & 8)) { if (PRE) apply_table(v, *pa); else apply_powers(v, wa); }
   {  // exchange 1: (n0,n1;k0) -> (n0,k0;n1)
     const int wbase = (t & 15) + 256 * (t >> 4);
-#pragma unroll
-    for (int k = 0; k < kR; k++) lds[wbase + 16 * k] = v[rev16(k)];
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < kR; j++) v[j] = lds[t + 256 * j];
+    if (!(GACQ_ABL & 1)) {
+_Pragma("unroll") for (int k = 0; k < kR; k++) lds[wbase + 16 * k] = v[rev16(k)];
+    }
+    if (!(GACQ_ABL & 2)) __syncthreads();
+    if (!(GACQ_ABL & 1)) {
+_Pragma("unroll") for (int j = 0; j < kR; j++) v[j] = lds[t + 256 * j];
+    }
   }
   dft16<INV>(v);
-  if (PRE) apply_table(v, *pb); else apply_powers(v, wb);
-  __syncthreads();   // all exchange-1 reads done before the buffer is reused
+  if (!(GACQ_ABL & 8)) { if (PRE) apply_table(v, *pb); else apply_powers(v, wb); }
+  if (!(GACQ_ABL & 2)) __syncthreads();   // all exchange-1 reads done before the buffer is reused
   {  // exchange 2: (n0,k0;k1) -> (k0,k1;n0)
     const int wbase = (t >> 4) + kPitch * (t & 15);
-#pragma unroll
-    for (int k = 0; k < kR; k++) lds[wbase + 16 * k] = v[rev16(k)];
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < kR; j++) v[j] = lds[t + kPitch * j];
+    if (!(GACQ_ABL & 1)) {
+_Pragma("unroll") for (int k = 0; k < kR; k++) lds[wbase + 16 * k] = v[rev16(k)];
+    }
+    if (!(GACQ_ABL & 2)) __syncthreads();
+    if (!(GACQ_ABL & 1)) {
+_Pragma("unroll") for (int j = 0; j < kR; j++) v[j] = lds[t + kPitch * j];
+    }
   }
   dft16<INV>(v);
 }
