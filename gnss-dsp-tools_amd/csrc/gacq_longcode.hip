@@ -1,0 +1,138 @@
+// Time-domain long-code searches (SURVEY.md section 8f "next #3", component C12): acquire-gps-l2cl.py:15-30 (75 L2CM-period
+// offsets of the 767 250-chip L2CL code) and acquire-glonass-l1-p.py / -l2-p.py:15-33 (1000 C/A-period offsets of the
+// 5.11 M-chip P code), given a prior FFT acquisition.  For every candidate k:
+//     q[k] = sum_block | sum_i x[n*block + i] * (1 - 2*chips[floor(phase0[k][block] + incr*i) mod L]) * w[i] |
+// with w the table NCO restarted per block.  x*w does not depend on k, so it is formed once (longcode_mix_kernel) and every
+// candidate is a +-1 weighted sum over it (longcode_dot_kernel, fp64 accumulation, code indices in fp64 like numpy's).
+#include "gacq_common.h"
+
+#include <cmath>
+#include <cstring>
+
+using namespace gacq;
+
+namespace {
+
+constexpr int kLcBlock = 256;
+constexpr int kLcPer = 16;                       // samples per thread per chunk
+constexpr int kLcChunk = kLcBlock * kLcPer;     // samples per workgroup
+
+// xw[b*n + i] = x[b*n + i] * tab[floor((f*i)*1024) & 1023]      (nco.nco(f,0,n), same w for every block)
+__global__ __launch_bounds__(kLcBlock) void longcode_mix_kernel(const float2* __restrict__ x, float2* __restrict__ xw, long n, int B,
+                                                                 double f, const float2* __restrict__ tab) {
+  const long g = (long)blockIdx.x * kLcBlock + threadIdx.x;
+  if (g >= n * B) return;
+  const long i = g % n;
+  const long k = (long)floor(__dmul_rn(__dmul_rn(f, (double)i), 1024.0)) & (kNcoTableSize - 1);
+  const float2 s = x[g], w = tab[k];
+  xw[g] = make_float2(s.x * w.x - s.y * w.y, s.x * w.y + s.y * w.x);
+}
+
+// partial[(k*B + b)*chunks + c] = sum over the chunk's samples of +-xw
+__global__ __launch_bounds__(kLcBlock) void longcode_dot_kernel(const float2* __restrict__ xw, const uint8_t* __restrict__ chips, long L,
+                                                                 const double* __restrict__ phase0, double incr, long n, int B,
+                                                                 int chunks, double2* __restrict__ partial) {
+  __shared__ double s_re[kLcBlock / 64], s_im[kLcBlock / 64];
+  const long blk = blockIdx.x;
+  const int c = (int)(blk % chunks);
+  const long kb = blk / chunks;                   // k*B + b
+  const int b = (int)(kb % B);
+  const double ph = phase0[kb];
+  const float2* src = xw + (long)b * n;
+  double ar = 0.0, ai = 0.0;
+  const long i0 = (long)c * kLcChunk + threadIdx.x;
+#pragma unroll 4
+  for (int j = 0; j < kLcPer; j++) {
+    const long i = i0 + (long)j * kLcBlock;
+    if (i < n) {
+      // idx = floor((chips % L) + frac + incr*i) mod L, fp64 as numpy does it (gnsstools/gps/l2cl.py:57-61)
+      long idx = (long)floor(ph + __dmul_rn(incr, (double)i));
+      if (idx >= L) { idx -= L; if (idx >= L) idx %= L; }
+      const float2 v = src[i];
+      if (chips[idx]) { ar -= (double)v.x; ai -= (double)v.y; } else { ar += (double)v.x; ai += (double)v.y; }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { ar += __shfl_down(ar, off); ai += __shfl_down(ai, off); }
+  if ((threadIdx.x & 63) == 0) { s_re[threadIdx.x >> 6] = ar; s_im[threadIdx.x >> 6] = ai; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kLcBlock / 64; w++) { ar += s_re[w]; ai += s_im[w]; }
+    partial[blk] = make_double2(ar, ai);
+  }
+}
+
+// q[k] = sum_b | sum_c partial |          (np.absolute(np.sum(p)) accumulated over blocks)
+__global__ void longcode_finish_kernel(const double2* __restrict__ partial, double* __restrict__ q, int K, int B, int chunks) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  double acc = 0.0;
+  for (int b = 0; b < B; b++) {
+    double re = 0.0, im = 0.0;
+    for (int c = 0; c < chunks; c++) { const double2 p = partial[((long)k * B + b) * chunks + c]; re += p.x; im += p.y; }
+    acc += sqrt(re * re + im * im);
+  }
+  q[k] = acc;
+}
+
+struct DevChips { std::string code; int prn; int device; uint8_t* p; long L; };
+std::vector<DevChips> g_chips;
+
+int device_chips(gacq_ctx* ctx, const char* code, int prn, const uint8_t** out, long* L) {
+  for (const DevChips& d : g_chips) if (d.device == ctx->device && d.prn == prn && d.code == code) { *out = d.p; *L = d.L; return GACQ_OK; }
+  const int len = gacq_code_length(code);
+  if (len < 0) return set_error(ctx, GACQ_ERR_UNKNOWN_CODE, "long-code search: unknown code '%s'", code);
+  std::vector<uint8_t> h(len);
+  const int rc = gacq_code_chips(code, prn, h.data(), len);
+  if (rc < 0) return set_error(ctx, rc, "long-code search: no PRN %d in '%s'", prn, code);
+  DevChips d{code, prn, ctx->device, nullptr, len};
+  GACQ_HIP(ctx, hipMalloc((void**)&d.p, (size_t)len));
+  GACQ_HIP(ctx, hipMemcpy(d.p, h.data(), (size_t)len, hipMemcpyHostToDevice));
+  g_chips.push_back(d);
+  *out = d.p;
+  *L = len;
+  return GACQ_OK;
+}
+
+}  // namespace
+
+extern "C" int gacq_longcode_search(gacq_ctx* ctx, const float* x_iq, size_t nsamp, double fs, const char* code, int prn,
+                                    double carrier_hz, const double* phase0, int K, int blocks, int n, double* q_out) {
+  if (!ctx || !x_iq || !code || !phase0 || !q_out || K <= 0 || blocks < 0 || n <= 0 || !(fs > 0.0))
+    return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_longcode_search: bad argument");
+  if (blocks == 0) { memset(q_out, 0, sizeof(double) * K); return GACQ_OK; }
+  if (nsamp < (size_t)blocks * n)
+    return set_error(ctx, GACQ_ERR_SHORT_INPUT, "gacq_longcode_search: %zu samples given, %zu needed", nsamp, (size_t)blocks * n);
+  GACQ_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const uint8_t* d_chips;
+  long L;
+  int rc = device_chips(ctx, code, prn, &d_chips, &L);
+  if (rc != GACQ_OK) return rc;
+  const double chip_rate = gacq_code_chip_rate(code);
+  const double incr = chip_rate / fs;                                   // l2cl.chip_rate/fs  (acquire-gps-l2cl.py:19)
+  const long total = (long)n * blocks;
+  const int chunks = (n + kLcChunk - 1) / kLcChunk;
+  const size_t npart = (size_t)K * blocks * chunks;
+  if ((rc = ensure(ctx, ctx->xstage, sizeof(float2) * (size_t)total)) != GACQ_OK) return rc;
+  if ((rc = ensure(ctx, ctx->fe_a, sizeof(float2) * (size_t)total)) != GACQ_OK) return rc;
+  if ((rc = ensure(ctx, ctx->partial, sizeof(double2) * npart + sizeof(double) * (size_t)K * (blocks + 1))) != GACQ_OK) return rc;
+  double2* d_partial = (double2*)ctx->partial.p;
+  double* d_phase = (double*)(d_partial + npart);
+  double* d_q = d_phase + (size_t)K * blocks;
+  GACQ_HIP(ctx, hipMemcpyAsync(ctx->xstage.p, x_iq, sizeof(float2) * (size_t)total, hipMemcpyHostToDevice, st));
+  GACQ_HIP(ctx, hipMemcpyAsync(d_phase, phase0, sizeof(double) * (size_t)K * blocks, hipMemcpyHostToDevice, st));
+  const double f = -carrier_hz / fs;                                     // nco.nco(-doppler/fs,0,n)  (acquire-gps-l2cl.py:18)
+  hipLaunchKernelGGL(longcode_mix_kernel, dim3((unsigned)((total + kLcBlock - 1) / kLcBlock)), dim3(kLcBlock), 0, st,
+                     (const float2*)ctx->xstage.p, (float2*)ctx->fe_a.p, (long)n, blocks, f, (const float2*)ctx->tab.p);
+  GACQ_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(longcode_dot_kernel, dim3((unsigned)npart), dim3(kLcBlock), 0, st, (const float2*)ctx->fe_a.p, d_chips, L,
+                     (const double*)d_phase, incr, (long)n, blocks, chunks, d_partial);
+  GACQ_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(longcode_finish_kernel, dim3((unsigned)((K + 127) / 128)), dim3(128), 0, st, (const double2*)d_partial, d_q, K, blocks,
+                     chunks);
+  GACQ_HIP(ctx, hipGetLastError());
+  GACQ_HIP(ctx, hipMemcpyAsync(q_out, d_q, sizeof(double) * K, hipMemcpyDeviceToHost, st));
+  GACQ_HIP(ctx, hipStreamSynchronize(st));
+  return GACQ_OK;
+}

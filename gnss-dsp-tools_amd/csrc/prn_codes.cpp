@@ -83,6 +83,16 @@ bool gen_gps_l2cm(int prn, Chips& out) {
   return true;
 }
 
+// ---- GPS L2CL: same 27-bit register as L2CM, 767250 chips (gnsstools/gps/l2cl.py:40-50) ----------
+bool gen_gps_l2cl(int prn, Chips& out) {
+  const PrnRow* r = find_row(T_gps_l2cl, N_gps_l2cl, prn);
+  if (!r) return false;
+  uint32_t x = (uint32_t)r->a;
+  out.resize(767250);
+  for (int i = 0; i < 767250; i++) { out[i] = x & 1u; x = (x >> 1) ^ ((x & 1u) ? 0445112474u : 0u); }
+  return true;
+}
+
 // ---- Weil codes: GPS L1Cd/p (N=10223 + 7-chip insertion), BDS B1Cd/p (N=10243 truncated) -----
 // Legendre sequence: L[i]=1 iff i is a non-zero quadratic residue mod N (gnsstools/gps/l1cd.py:59-62)
 const std::vector<uint8_t>& legendre(int N) {
@@ -174,6 +184,14 @@ bool gen_glo_ca(int /*prn*/, Chips& out) {
   return true;
 }
 
+// ---- GLONASS P: 25-stage register, taps 24 and 2, output stage 9, 5.11 M chips (gnsstools/glonass/p.py:10-21)
+bool gen_glo_p(int /*prn*/, Chips& out) {
+  ShiftReg x(25, 0x1ffffff, {24, 2});
+  out.resize(5110000);
+  for (int i = 0; i < 5110000; i++) { out[i] = x.stage(9); x.shift(); }
+  return true;
+}
+
 // ---- GLONASS L3OC d/p: 14-stage g2 xor 7-stage register seeded MSB-first with n (+64 for pilot)
 bool gen_glo_l3oc(bool pilot, int prn, Chips& out) {
   if (prn < 0 || prn > 63) return false;
@@ -244,6 +262,7 @@ const Family FAMILIES[] = {
   {"gps.l5i", 10230, 10230000, T_gps_l5i, N_gps_l5i, nullptr, 0, 0},
   {"gps.l5q", 10230, 10230000, T_gps_l5q, N_gps_l5q, nullptr, 0, 0},
   {"gps.l2cm", 10230, 511500, T_gps_l2cm, N_gps_l2cm, nullptr, 0, 0},
+  {"gps.l2cl", 767250, 511500, T_gps_l2cl, N_gps_l2cl, nullptr, 0, 0},
   {"gps.l1cd", 10230, 1023000, T_gps_l1cd, N_gps_l1cd, nullptr, 0, 0},
   {"gps.l1cp", 10230, 1023000, T_gps_l1cp, N_gps_l1cp, nullptr, 0, 0},
   {"galileo.e1b", 4092, 1023000, nullptr, 0, "gal_e1b", 0, 0},
@@ -265,6 +284,7 @@ const Family FAMILIES[] = {
   {"beidou.b2bq", 10230, 10230000, nullptr, 0, "bds_b2bq", 0, 0},
   {"beidou.b3i", 10230, 10230000, T_bds_b3i, N_bds_b3i, nullptr, 0, 0},
   {"glonass.ca", 511, 511000, nullptr, 0, nullptr, 0, 0},       // single code; PRN argument ignored (use 0)
+  {"glonass.p", 5110000, 5110000, nullptr, 0, nullptr, 0, 0},      // single code; PRN argument ignored (use 0)
   {"glonass.l3ocd", 10230, 10230000, nullptr, 0, nullptr, 0, 63},
   {"glonass.l3ocp", 10230, 10230000, nullptr, 0, nullptr, 0, 63},
   {"xona.x1p", 1023, 1023000, nullptr, 0, "xona_x1p", 0, 0},
@@ -285,6 +305,8 @@ bool generate(const Family& f, int prn, Chips& out) {
   if (n == "gps.l5i") return gen_gps_l5(T_gps_l5i, N_gps_l5i, false, prn, out);
   if (n == "gps.l5q") return gen_gps_l5(T_gps_l5q, N_gps_l5q, true, prn, out);
   if (n == "gps.l2cm") return gen_gps_l2cm(prn, out);
+  if (n == "gps.l2cl") return gen_gps_l2cl(prn, out);
+  if (n == "glonass.p") return gen_glo_p(prn, out);
   if (n == "gps.l1cd") return gen_weil_gps(T_gps_l1cd, N_gps_l1cd, prn, out);
   if (n == "gps.l1cp") return gen_weil_gps(T_gps_l1cp, N_gps_l1cp, prn, out);
   if (n == "beidou.b1cd") return gen_weil_bds(T_bds_b1cd, N_bds_b1cd, prn, out);

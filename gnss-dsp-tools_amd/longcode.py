@@ -1,0 +1,69 @@
+"""Time-domain long-code searches that follow an FFT acquisition (SURVEY.md section 8f "next #3"):
+
+    acquire-gps-l2cl.py:15-30        search(x, prn, doppler, l2cm_code_phase, ms)  -> (metric, k)     75 candidates
+    acquire-glonass-l1-p.py:15-33    search(x, chan, doppler, ca_code_phase, ms)   -> (metric, k)   1000 candidates
+    acquire-glonass-l2-p.py:15-33    same with 437.5 kHz channel spacing
+
+The reference reads `fs` from a module global; here it is an explicit argument.  Per candidate k and block the start code
+phase is formed on the host in fp64 exactly like the reference's expression, everything per-sample runs on the GPU
+(gacq_longcode_search).  x is the complex input at the file rate after the carrier-offset wipe-off (nco.mix)."""
+import ctypes
+
+import numpy as np
+
+from . import _native as nat
+from . import acquire
+
+L2CL_LENGTH = 767250
+P_LENGTH = 5110000
+
+
+def _run(engine, x, fs, code, prn, carrier_hz, phase0, blocks, n):
+    eng = engine or acquire.default_engine()
+    K = phase0.shape[0]
+    if blocks <= 0:
+        return np.zeros(K)
+    x = np.asarray(x)
+    if len(x) < blocks * n:
+        raise ValueError("operands could not be broadcast together: search needs %d samples, x has %d" % (blocks * n, len(x)))
+    xc = np.ascontiguousarray(x[:blocks * n], dtype=np.complex64)
+    ph = np.ascontiguousarray(phase0, dtype=np.float64)
+    q = np.empty(K, dtype=np.float64)
+    nat.check(nat.lib.gacq_longcode_search(eng._ctx, xc.ctypes.data_as(nat.c_float_p), len(xc), float(fs), code.encode(), int(prn),
+                                           float(carrier_hz), ph.ctypes.data_as(nat.c_double_p), K, int(blocks), int(n),
+                                           q.ctypes.data_as(nat.c_double_p)), eng._ctx)
+    return q
+
+
+def _best(q):
+    """strict '>' scan from (0, 0): first maximum wins, all-zero keeps the initial ints (acquire-gps-l2cl.py:20,27-29)."""
+    m_metric, m_k = 0, 0
+    for k, v in enumerate(q):
+        if v > m_metric:
+            m_metric, m_k = v, k
+    return m_metric, m_k
+
+
+def search_l2cl(x, prn, doppler, l2cm_code_phase, ms, fs, engine=None):
+    blocks = ms // 20
+    n = int(fs * 0.020)
+    phase0 = np.empty((75, max(blocks, 0)), dtype=np.float64)
+    for k in range(75):
+        for block in range(blocks):
+            chips = (k + block) * 10230 + l2cm_code_phase            # acquire-gps-l2cl.py:24
+            phase0[k, block] = (chips % L2CL_LENGTH) + 0             # (chips % code_length) + frac   gps/l2cl.py:59
+    return _best(_run(engine, x, fs, "gps.l2cl", prn, doppler, phase0, blocks, n))
+
+
+def search_glonass_p(x, chan, doppler, ca_code_phase, ms, fs, band="l1", engine=None):
+    spacing = {"l1": 562500, "l2": 437500}[band]                    # acquire-glonass-l1-p.py:18 / -l2-p.py:18
+    blocks = ms // 4
+    n = int(fs * 0.004)
+    incr = 5110000.0 / fs
+    phase0 = np.empty((1000, max(blocks, 0)), dtype=np.float64)
+    for k in range(1000):
+        cp = 5110 * k + 10 * ca_code_phase
+        for block in range(blocks):
+            phase0[k, block] = (0 % P_LENGTH) + cp                   # p.code(0, cp, incr, n): chips = 0, frac = cp
+            cp += n * incr
+    return _best(_run(engine, x, fs, "glonass.p", 0, spacing * chan + doppler, phase0, blocks, n))

@@ -53,3 +53,14 @@ def make_iq(name, blocks, seed, sats, nsamp=None, dtype=np.complex64):
 def make_epochs(name, blocks, seed, sats, nepoch, nsamp=None):
     """[nepoch, nsamp] complex64: independent noise per epoch, same satellites."""
     return np.stack([make_iq(name, blocks, seed + 1000 * e, sats, nsamp) for e in range(nepoch)])
+
+
+def make_longcode_iq(code, prn, chip_rate, L, fs, nsamp, seed, amp, carrier_hz, start_chips):
+    """Input for the time-domain long-code searches: noise + amp * code(start_chips + chip_rate/fs * i) * carrier, complex64."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    x = rng.standard_normal(nsamp) + 1j * rng.standard_normal(nsamp)
+    i = np.arange(nsamp)
+    c = codes.chips(code, prn)
+    idx = np.mod(np.floor(start_chips + (chip_rate / fs) * i).astype(np.int64), L)
+    x += amp * (1.0 - 2.0 * c[idx]) * np.exp(2j * np.pi * carrier_hz * i / fs)
+    return x.astype(np.complex64)

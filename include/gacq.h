@@ -156,6 +156,16 @@ int gacq_firwin_hann(int ntaps, double cutoff_norm, double* taps);
 int gacq_frontend_dev(gacq_ctx* ctx, const void* d_iq_int8, size_t nsamp_in, double fs_in, double carrier_offset_hz,
                       const double* taps, int ntaps, double fs_out, size_t nsamp_out, void* d_out);
 
+/* ---------------------------------------------------------------------------------------------
+ * Time-domain long-code searches (SURVEY.md section 8f "next #3"): acquire-gps-l2cl.py:15-30,
+ * acquire-glonass-l1-p.py / -l2-p.py:15-33.  For candidate k:
+ *   q[k] = sum_block | sum_i x[n*block+i] * code[floor(phase0[k*blocks+block] + (chip_rate/fs)*i) mod L] * nco[i] |
+ * x_iq: host complex64 at the file rate fs (after the carrier-offset wipe-off); carrier_hz = Doppler (+ FDMA channel bias);
+ * phase0: the caller's (chips % L) + frac per (k, block), in chips.  Synchronous; q_out[K] in fp64.
+ * ------------------------------------------------------------------------------------------- */
+int gacq_longcode_search(gacq_ctx* ctx, const float* x_iq, size_t nsamp, double fs, const char* code, int prn,
+                         double carrier_hz, const double* phase0, int K, int blocks, int n, double* q_out);
+
 /* Per-stage GPU time from HIP events recorded on the launch stream (profiling aid for bench.py).
  * Stages: 0 mix/forward, 1 forward FFT (rocFFT), 2 conj-multiply, 3 inverse FFT (rocFFT),
  *         4 magnitude/peak reduce, 5 best-over-Doppler, 6 fused correlate kernel (LDS FFT). */

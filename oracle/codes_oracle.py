@@ -76,6 +76,45 @@ def _gps_l2cm(prn):                                 # gnsstools/gps/l2cm.py:40-5
     return seq
 
 
+def _gps_l2cl(prn):                                 # gnsstools/gps/l2cl.py:40-50
+    (state,) = _row("gps_l2cl", prn)[:1]
+    out = np.empty(767250, dtype=np.uint8)
+    for i in range(767250):
+        out[i] = state & 1
+        state = (state >> 1) ^ ((state & 1) * 0o445112474)
+    return out
+
+
+def _glo_p(_prn):                                   # gnsstools/glonass/p.py:10-21
+    """25-stage register, feedback x[24]^x[2] into stage 0, output stage 9: the feedback sequence obeys
+    u[i] = u[i-25] ^ u[i-3], and over GF(2) also u[i] = u[i-25*2^m] ^ u[i-3*2^m], which lets numpy extend it in
+    ever larger slices instead of 5.11 million Python steps."""
+    n = 5110000 + 64
+    u = np.zeros(n, dtype=np.uint8)
+    reg = [1] * 25
+    hist = []
+    for _ in range(400):                            # plain stepping for the first few hundred chips
+        fb = reg[24] ^ reg[2]
+        hist.append(fb)
+        reg = [fb] + reg[:-1]
+    u[:400] = hist                                  # u[i] = feedback produced at step i
+    have = 400
+    while have < n:
+        m = 0
+        while 25 * (2 << m) <= have:
+            m += 1
+        a, b = 25 << m, 3 << m
+        take = min(b, n - have)
+        u[have:have + take] = u[have - a:have - a + take] ^ u[have - b:have - b + take]
+        have += take
+    # output at step i is stage 9 = feedback of step i-10 (stage j at step i holds the feedback of step i-1-j);
+    # the first 10 outputs come from the all-ones initial fill
+    out = np.empty(5110000, dtype=np.uint8)
+    out[:10] = 1
+    out[10:] = u[:5110000 - 10]
+    return out
+
+
 def l2cm_end_state(prn):
     """State after code_length-1 shifts (the ICD known answer, gnsstools/gps/l2cm.py:128-133)."""
     (state,) = _row("gps_l2cm", prn)[:1]
@@ -218,6 +257,8 @@ _GENERATORS = {
     "gps.l5i": lambda p: _gps_l5("gps_l5i", p),
     "gps.l5q": lambda p: _gps_l5("gps_l5q", p),
     "gps.l2cm": _gps_l2cm,
+    "gps.l2cl": _gps_l2cl,
+    "glonass.p": _glo_p,
     "gps.l1cd": lambda p: _weil_gps("gps_l1cd", p),
     "gps.l1cp": lambda p: _weil_gps("gps_l1cp", p),
     "beidou.b1cd": lambda p: _weil_bds("bds_b1cd", p),

@@ -1,0 +1,62 @@
+"""Time-domain long-code searches (acquire-gps-l2cl.py, acquire-glonass-l1-p.py, acquire-glonass-l2-p.py): oracle vs the
+reference's own search() outputs (CPU), HIP path vs both (GPU)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = json.load(open(os.path.join(GOLD, "longcode_cases.json")))["cases"]
+SPEC = {"gps-l2cl": ("gps.l2cl", 511500.0, 767250, None), "glonass-l1-p": ("glonass.p", 5110000.0, 5110000, 562500),
+        "glonass-l2-p": ("glonass.p", 5110000.0, 5110000, 437500)}
+
+
+def _iq(case):
+    from gnss_dsp_tools_amd import synth
+    code, rate, L, spacing = SPEC[case["script"]]
+    carrier = case["doppler"] + (spacing * case["item"] if spacing else 0.0)
+    x = synth.make_longcode_iq(code, case["item"] if spacing is None else 0, rate, L, case["fs"], case["nsamp"], case["seed"],
+                               case["amp"], carrier, case["start_chips"])
+    assert hashlib.sha256(x.tobytes()).hexdigest() == case["x_sha256"]
+    return x
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["id"] for c in CASES])
+def test_oracle_matches_reference(case):
+    from oracle import longcode_oracle
+    x = _iq(case).astype(np.complex128)
+    if case["script"] == "gps-l2cl":
+        m, k = longcode_oracle.search_l2cl(x, case["item"], case["doppler"], case["code_phase"], case["ms"], case["fs"])
+    else:
+        m, k = longcode_oracle.search_glonass_p(x, case["item"], case["doppler"], case["code_phase"], case["ms"], case["fs"],
+                                                band=case["script"].split("-")[1])
+    assert k == case["k"] and m == pytest.approx(case["metric"], rel=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=[c["id"] for c in CASES])
+def test_gpu_matches_reference(engine, case):
+    from gnss_dsp_tools_amd import longcode
+    x = _iq(case)
+    if case["script"] == "gps-l2cl":
+        m, k = longcode.search_l2cl(x, case["item"], case["doppler"], case["code_phase"], case["ms"], case["fs"], engine=engine)
+        line = '%f %f' % (10230 * k + case["code_phase"], m)
+    else:
+        m, k = longcode.search_glonass_p(x, case["item"], case["doppler"], case["code_phase"], case["ms"], case["fs"],
+                                         band=case["script"].split("-")[1], engine=engine)
+        line = '%f %f' % (5110 * k + 10 * case["code_phase"], m)
+    assert k == case["k"]
+    assert m == pytest.approx(case["metric"], rel=1e-5)            # north_star tolerance
+    assert line.split()[0] == case["line"].split()[0]
+
+
+@pytest.mark.gpu
+def test_gpu_longcode_edge_cases(engine):
+    from gnss_dsp_tools_amd import longcode
+    x = np.zeros(100000, dtype=np.complex64)
+    assert longcode.search_l2cl(x, 1, 0.0, 0.0, 10, 4092000.0, engine=engine) == (0, 0)      # ms//20 == 0 blocks
+    assert longcode.search_l2cl(x, 1, 0.0, 0.0, 20, 4092000.0, engine=engine) == (0, 0)      # all-zero input: nothing beats 0
+    with pytest.raises(ValueError):
+        longcode.search_l2cl(x[:1000], 1, 0.0, 0.0, 20, 4092000.0, engine=engine)

@@ -47,7 +47,7 @@ def test_native_chips_bit_exact_all_prns(golden_chips):
             assert hashlib.sha256(c.tobytes()).hexdigest() == g["sha256"], (code, prn)
             assert "".join(map(str, c[-24:])) == g["tail"]
             total += 1
-    assert total == 2239
+    assert total == 2239 + 115 + 1        # + L2CL PRNs + the GLONASS P code
 
 
 def test_native_chips_equal_oracle_chips():
