@@ -78,13 +78,55 @@ def run(name, argv, out=sys.stdout):
     return lines
 
 
+LONGCODE = {"gps-l2cl": 40, "glonass-l1-p": 80, "glonass-l2-p": 80}        # default --time (acquire-gps-l2cl.py:57)
+
+
+def run_longcode(name, argv, out=sys.stdout):
+    """acquire-gps-l2cl.py / acquire-glonass-l{1,2}-p.py: FILE FS COFFSET ITEM DOPPLER CODE_PHASE [--time MS]."""
+    import numpy as np
+    from . import longcode
+    ap = argparse.ArgumentParser(prog="acquire-%s" % name)
+    ap.add_argument("--time", type=int, default=LONGCODE[name])
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("input_filename")
+    ap.add_argument("sample_rate", type=float)
+    ap.add_argument("carrier_offset", type=float)
+    ap.add_argument("item", type=int)
+    ap.add_argument("doppler", type=float)
+    ap.add_argument("code_phase", type=float)
+    a = ap.parse_args(_join_option_values(list(argv)))
+    ms_pad = a.time + 5
+    n = int(a.sample_rate * 0.001 * ms_pad)
+    with open(a.input_filename, "rb") as fp:
+        x = frontend.read_iq_int8(fp, n)
+    if x is None:
+        raise SystemExit("input file too short: need %d complex int8 samples" % n)
+    x = frontend.mix_fixed_point(x, -a.carrier_offset / a.sample_rate, 0)       # nco.mix(x,-coffset/fs,0)
+    eng = acquire.Engine(a.device)
+    try:
+        if name == "gps-l2cl":
+            metric, k = longcode.search_l2cl(x, a.item, a.doppler, a.code_phase, a.time, a.sample_rate, engine=eng)
+            line = '%f %f' % (10230 * k + a.code_phase, metric)                  # acquire-gps-l2cl.py:76
+        else:
+            metric, k = longcode.search_glonass_p(x, a.item, a.doppler, a.code_phase, a.time, a.sample_rate,
+                                                  band=name.split("-")[1], engine=eng)
+            line = '%f %f' % (5110 * k + 10 * a.code_phase, metric)              # acquire-glonass-l1-p.py:79
+    finally:
+        eng.close()
+    print(line, file=out)
+    return [line]
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     if not argv or argv[0] in ("-h", "--help"):
         print(__doc__)
-        print("signals:", ", ".join(sorted(signals.SIGNALS)))
+        print("signals:", ", ".join(sorted(signals.SIGNALS)), "| long-code:", ", ".join(sorted(LONGCODE)))
         return 0
-    run(argv[0], argv[1:])
+    if argv[0] in LONGCODE:
+        run_longcode(argv[0], argv[1:])
+    else:
+        run(argv[0], argv[1:])
     return 0
 
 
