@@ -94,13 +94,17 @@ bool pfa_supported(int N);
 int pfa_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, long rows, int n, int N, const double* d_freq, int FD, int B,
                 const float2* tab, float2* X, bool mix, bool inner = true);
 int split_radix(int N);
+bool split_inner_fused_supported(int N);
+int split_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* C, const int* d_items, const int* d_fset, long g0, long ng,
+                          int P, int F, int D, int B, int N, float2* Z);
 // inner stages of the split engine on the LDS FFT kernels (M = 4096)
 int lds_inner_forward(gacq_ctx* ctx, float2* rows, long nrows, bool conj);
 int lds_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const int* d_items, const int* d_fset, long g0,
                         long ng, int P, int F, int D, int B, int R, int N, float2* Z);
 // inner inverse transforms on Y (in place), then twiddle + inverse DFT-31 + |.|/N + sum over B + reduce -> rows[g0..g0+ng)
 // inner == false: Y already holds the twiddled inner inverse transforms (LDS inner path)
-int pfa_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng, int B, int N, float* q_out, bool inner = true);
+int pfa_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng, int B, int N, float* q_out, bool inner = true,
+                       bool twiddle_only = false);
 
 #define GACQ_HIP(ctx, call)                                                                         \
   do {                                                                                              \

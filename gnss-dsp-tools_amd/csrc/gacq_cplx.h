@@ -117,6 +117,14 @@ template <> struct Trig<31> {
                                   0.96807711886620429f, 0.89780453957074158f, 0.79077573693769887f, 0.65137248272222226f,
                                   0.48530196253108104f, 0.29936312297335804f, 0.10116832198743272f};
 };
+template <> struct Trig<3> {
+  static constexpr float c[2] = {1.f, -0.5f};
+  static constexpr float s[2] = {0.f, 0.866025404f};
+};
+template <> struct Trig<11> {
+  static constexpr float c[6] = {1.f, 0.841253533f, 0.415415013f, -0.142314838f, -0.654860734f, -0.959492974f};
+  static constexpr float s[6] = {0.f, 0.540640817f, 0.909631995f, 0.989821442f, 0.755749574f, 0.281732557f};
+};
 template <> struct Trig<5> {
   static constexpr float c[3] = {1.f, 0.30901699437494742f, -0.80901699437494742f};
   static constexpr float s[3] = {0.f, 0.95105651629515357f, 0.58778525229247313f};
@@ -181,6 +189,10 @@ template <> struct TrigN<8> {
   static constexpr float c[8] = {1.f, 0.707106781f, 0.f, -0.707106781f, -1.f, -0.707106781f, 0.f, 0.707106781f};
   static constexpr float s[8] = {0.f, 0.707106781f, 1.f, 0.707106781f, 0.f, -0.707106781f, -1.f, -0.707106781f};
 };
+template <> struct TrigN<9> {
+  static constexpr float c[9] = {1.f, 0.766044443f, 0.173648178f, -0.5f, -0.939692621f, -0.939692621f, -0.5f, 0.173648178f, 0.766044443f};
+  static constexpr float s[9] = {0.f, 0.64278761f, 0.984807753f, 0.866025404f, 0.342020143f, -0.342020143f, -0.866025404f, -0.984807753f, -0.64278761f};
+};
 template <> struct TrigN<20> {
   static constexpr float c[20] = {1.f, 0.951056516f, 0.809016994f, 0.587785252f, 0.309016994f, 0.f, -0.309016994f, -0.587785252f, -0.809016994f, -0.951056516f, -1.f, -0.951056516f, -0.809016994f, -0.587785252f, -0.309016994f, 0.f, 0.309016994f, 0.587785252f, 0.809016994f, 0.951056516f};
   static constexpr float s[20] = {0.f, 0.309016994f, 0.587785252f, 0.809016994f, 0.951056516f, 1.f, 0.951056516f, 0.809016994f, 0.587785252f, 0.309016994f, 0.f, -0.309016994f, -0.587785252f, -0.809016994f, -0.951056516f, -1.f, -0.951056516f, -0.809016994f, -0.587785252f, -0.309016994f};
@@ -243,6 +255,37 @@ template <bool INV> struct OuterDft<20, INV> {
 };
 template <bool INV> struct OuterDft<40, INV> {
   template <class Sink> static __device__ __forceinline__ void run(v2 (&x)[40], Sink&& sink) { dft_ra5<8, INV>(x, sink); }
+};
+
+// In-place small DFTs in natural order, the butterflies of the Stockham inner transforms (radices 2, 3, 4, 5, 9, 11)
+template <int R, bool INV> struct SmallDft {
+  static __device__ __forceinline__ void run(v2 (&x)[R]) {            // odd primes through the symmetric form
+    v2 y[R];
+    dft_prime<R, INV>(x, [&](int k, v2 val) { y[k] = val; });
+#pragma unroll
+    for (int k = 0; k < R; k++) x[k] = y[k];
+  }
+};
+template <bool INV> struct SmallDft<2, INV> {
+  static __device__ __forceinline__ void run(v2 (&x)[2]) { const v2 a = x[0] + x[1], b = x[0] - x[1]; x[0] = a; x[1] = b; }
+};
+template <bool INV> struct SmallDft<4, INV> {
+  static __device__ __forceinline__ void run(v2 (&x)[4]) { dft4<INV, false>(x[0], x[1], x[2], x[3]); }
+};
+template <bool INV> struct SmallDft<9, INV> {                          // 9 = 3 x 3: n = 3 n1 + n2, k = k1 + 3 k2
+  static __device__ __forceinline__ void run(v2 (&x)[9]) {
+    v2 t[3][3];                                                          // t[n2][k1]
+#pragma unroll
+    for (int n2 = 0; n2 < 3; n2++) {
+      const v2 col[3] = {x[n2], x[3 + n2], x[6 + n2]};
+      dft_prime<3, INV>(col, [&](int k1, v2 val) { t[n2][k1] = (n2 * k1) ? cmul_k(val, wconst<9, INV>(n2 * k1)) : val; });
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 3; k1++) {
+      const v2 row[3] = {t[0][k1], t[1][k1], t[2][k1]};
+      dft_prime<3, INV>(row, [&](int k2, v2 val) { x[k1 + 3 * k2] = val; });
+    }
+  }
 };
 
 // w^k for k = 0..43 from base-4 digits: w^k = p[k & 3] * q[k >> 2], p[a] = w^a, q[b] = w^(4b); multiplication depth <= 5

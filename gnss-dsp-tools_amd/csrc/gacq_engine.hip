@@ -13,6 +13,7 @@
 
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -629,6 +630,18 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
           if (rc != GACQ_OK) return rc;
           stage_begin(ctx, 4);
           rc = pfa_inverse_reduce(ctx, Y, rows, g0, ng, B, N, d_qrow, false);   // outer inverse DFT + |.| + reduce
+          stage_end(ctx);
+          if (rc != GACQ_OK) return rc;
+          continue;
+        }
+        if (use_pfa && split_inner_fused_supported(N) && !getenv("GACQ_NO_FUSED_INNER")) {
+          stage_begin(ctx, 6);
+          rc = split_inner_correlate(ctx, X, sig->spectra_pfa, (const int*)ctx->items.p, (const int*)ctx->fset.p, g0, ng, P, F, D, B, N,
+                                     Y);                                        // K2 + inner inverse FFTs (Stockham in LDS)
+          stage_end(ctx);
+          if (rc != GACQ_OK) return rc;
+          stage_begin(ctx, 4);
+          rc = pfa_inverse_reduce(ctx, Y, rows, g0, ng, B, N, d_qrow, false, true);   // twiddle + outer DFT-31 + |.| + reduce
           stage_end(ctx);
           if (rc != GACQ_OK) return rc;
           continue;

@@ -149,6 +149,76 @@ __global__ __launch_bounds__(kBlock) void split_outer_inverse_kernel(const float
   }
 }
 
+// ---- inner inverse transforms fused with the conj-multiply (engine 3, M = 1980 / 990) ---------------------------------
+// Z[ry][n2] = IFFT_M( C_p[k1][.] * conj(X[e,f,d,b][k1][.]) )[n2]  (unnormalised), one workgroup per (group, block, k1) row.
+// Stockham autosort in LDS (ping-pong), mixed radices R0*R1*R2*R3 = M; the first pass reads the two spectra from global
+// memory and multiplies them (K2), so the product never exists in HBM; the last pass writes the row.  Thread j of a
+// radix-R pass with Ns = product of the previous radices:  k = j mod Ns; inputs in[j + t M/R] * W_{Ns R}^{-k t};
+// R-point DFT; outputs out[(j div Ns) Ns R + k + t Ns].
+template <int R, bool FIRST, bool LAST>
+__device__ __forceinline__ void stockham_pass(const v2* __restrict__ in, v2* __restrict__ out, const float2* __restrict__ gx,
+                                              const float2* __restrict__ gc, float2* __restrict__ gz, const v2* __restrict__ twm,
+                                              int Ns, int M) {
+  const int nb = M / R;
+  const int step = M / (Ns * R);
+  for (int j = threadIdx.x; j < nb; j += kBlock) {
+    const int k = j % Ns;
+    v2 x[R];
+#pragma unroll
+    for (int t = 0; t < R; t++) {
+      if (FIRST) {
+        const float2 xv = gx[j + t * nb], cv = gc[j + t * nb];
+        x[t] = v2{cv.x * xv.x + cv.y * xv.y, cv.y * xv.x - cv.x * xv.y};      // C * conj(X)   acquire-gps-l1.py:32
+      } else {
+        x[t] = in[j + t * nb];
+      }
+    }
+    if (!FIRST) {
+#pragma unroll
+      for (int t = 1; t < R; t++) x[t] = cmul(x[t], twm[k * t * step]);        // k t step < M
+    }
+    SmallDft<R, true>::run(x);
+    const int j0 = (j / Ns) * Ns * R + k;
+#pragma unroll
+    for (int t = 0; t < R; t++) {
+      if (LAST) gz[j0 + t * Ns] = make_float2(x[t].x, x[t].y);
+      else out[j0 + t * Ns] = x[t];
+    }
+  }
+}
+
+template <int R0, int R1, int R2, int R3>
+__global__ __launch_bounds__(kBlock) void split_inner_corr_kernel(const float2* __restrict__ X, const float2* __restrict__ C,
+                                                                   float2* __restrict__ Z, const int* __restrict__ items,
+                                                                   const int* __restrict__ fset, const float2* __restrict__ twm_g,
+                                                                   long g0, int P, int F, int D, int B, int R) {
+  constexpr int M = R0 * R1 * R2 * R3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v2* buf0 = reinterpret_cast<v2*>(smem);
+  v2* buf1 = buf0 + M;
+  v2* twm = buf1 + M;                              // conj(W_M^k), k < M
+  for (int k = threadIdx.x; k < M; k += kBlock) { const float2 w = twm_g[k]; twm[k] = v2{w.x, -w.y}; }
+  const long ry = blockIdx.x;                      // ((gl*B + b)*R + k1)
+  const int k1 = (int)(ry % R);
+  const long gb = ry / R;
+  const int b = (int)(gb % B);
+  const long g = g0 + gb / B;
+  const int d = (int)(g % D);
+  const long ep = g / D;
+  const int p = (int)(ep % P);
+  const long e = ep / P;
+  const float2* gx = X + ((((e * F + fset[p]) * D + d) * (long)B + b) * R + k1) * (long)M;
+  const float2* gc = C + ((long)items[p] * R + k1) * (long)M;
+  float2* gz = Z + ry * (long)M;
+  stockham_pass<R0, true, false>(nullptr, buf0, gx, gc, nullptr, twm, 1, M);
+  __syncthreads();
+  stockham_pass<R1, false, false>(buf0, buf1, nullptr, nullptr, nullptr, twm, R0, M);
+  __syncthreads();
+  stockham_pass<R2, false, false>(buf1, buf0, nullptr, nullptr, nullptr, twm, R0 * R1, M);
+  __syncthreads();
+  stockham_pass<R3, false, true>(buf0, nullptr, nullptr, nullptr, gz, twm, R0 * R1 * R2, M);
+}
+
 // partial[(g, chunk)] -> rows[g0 + g]
 __global__ void split_combine_kernel(const RowRec* __restrict__ partial, RowRec* __restrict__ rows, long g0, long ng, int chunks) {
   const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -214,9 +284,49 @@ int launch_inverse(gacq_ctx* ctx, const float2* Z, RowRec* partial, const float2
   return GACQ_OK;
 }
 
+struct TwM { int M; int device; float2* p; };
+std::vector<TwM> g_twm;
+int inner_twiddles(gacq_ctx* ctx, int M, const float2** out) {          // W_M^k, k < M
+  for (const TwM& t : g_twm) if (t.M == M && t.device == ctx->device) { *out = t.p; return GACQ_OK; }
+  std::vector<float2> h(M);
+  for (int k = 0; k < M; k++) {
+    const double a = -2.0 * M_PI * (double)k / (double)M;
+    h[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+  }
+  TwM t{M, ctx->device, nullptr};
+  GACQ_HIP(ctx, hipMalloc((void**)&t.p, sizeof(float2) * M));
+  GACQ_HIP(ctx, hipMemcpy(t.p, h.data(), sizeof(float2) * M, hipMemcpyHostToDevice));
+  g_twm.push_back(t);
+  *out = t.p;
+  return GACQ_OK;
+}
+
 }  // namespace
 
 namespace gacq {
+
+bool split_inner_fused_supported(int N) { return N == 61380 || N == 30690; }
+
+// K2 + inner inverse transforms in one kernel (no Y round trip); Z gets the unnormalised, untwiddled inner IFFTs
+int split_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* C, const int* d_items, const int* d_fset, long g0, long ng,
+                          int P, int F, int D, int B, int N, float2* Z) {
+  const int R = 31, M = N / R;
+  const float2* twm;
+  int rc = inner_twiddles(ctx, M, &twm);
+  if (rc != GACQ_OK) return rc;
+  const size_t smem = sizeof(float2) * 3 * (size_t)M;
+  const dim3 grid((unsigned)(ng * B * R));
+  if (M == 1980)
+    hipLaunchKernelGGL((split_inner_corr_kernel<11, 9, 5, 4>), grid, dim3(kBlock), smem, ctx->stream, X, C, Z, d_items, d_fset, twm, g0, P,
+                       F, D, B, R);
+  else if (M == 990)
+    hipLaunchKernelGGL((split_inner_corr_kernel<11, 9, 5, 2>), grid, dim3(kBlock), smem, ctx->stream, X, C, Z, d_items, d_fset, twm, g0, P,
+                       F, D, B, R);
+  else
+    return set_error(ctx, GACQ_ERR_UNSUPPORTED, "fused inner transforms: M=%d not supported", M);
+  GACQ_HIP(ctx, hipGetLastError());
+  return GACQ_OK;
+}
 
 int split_radix(int N) {
   if (N > 0 && N % 31 == 0 && smooth(N / 31) && N / 31 >= 64) return 31;
@@ -249,7 +359,7 @@ int pfa_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, long rows, int n, 
   return fft_exec(ctx, M, rows * R, false, X);            // inner transforms, rows contiguous
 }
 
-int pfa_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng, int B, int N, float* q_out, bool inner) {
+int pfa_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng, int B, int N, float* q_out, bool inner, bool twiddle_only) {
   const int R = split_radix(N);
   if (!R) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "split engine: N=%d not supported", N);
   const int M = N / R;
@@ -257,7 +367,8 @@ int pfa_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng,
   int rc = base_twiddles(ctx, N, M, &tw);
   if (rc != GACQ_OK) return rc;
   const int chunks = (M + kBlock - 1) / kBlock;
-  if (inner && (rc = fft_exec(ctx, M, ng * B * R, true, Y)) != GACQ_OK) return rc;
+  if (inner && !twiddle_only && (rc = fft_exec(ctx, M, ng * B * R, true, Y)) != GACQ_OK) return rc;
+  if (twiddle_only) inner = true;              // Y holds untwiddled inner IFFTs: the outer kernel applies W_N^{-n2 k1}
   if ((rc = ensure(ctx, ctx->partial, sizeof(RowRec) * (size_t)ng * chunks)) != GACQ_OK) return rc;
   RowRec* partial = (RowRec*)ctx->partial.p;
   const float inv_n = 1.0f / (float)N;
