@@ -129,16 +129,19 @@ __global__ __launch_bounds__(kBlock) void lds_forward_kernel(const float2* __res
   const long e = r2 / FD;
   const double f = freq[fd];
   const float2* src = x + e * epoch_stride + (size_t)b * n;
-  v2 v[kR];
+  v2 v[kR], w[kR];
 #pragma unroll
   for (int j = 0; j < kR; j++) {
     const int i = t + 256 * j;
-    const v2 s = ld2(src + i);
+    v[j] = ld2(src + i);
     // table NCO, index in fp64 exactly as numpy: floor((0 + f*i)*1024) mod 1024   (gnsstools/nco.py:6-9)
     const long k = (long)floor(__dmul_rn(__dmul_rn(f, (double)i), 1024.0)) & (kNcoTableSize - 1);
-    v[j] = cmul(s, ld2(nco_tab + k));
+    w[j] = ld2(nco_tab + k);
   }
-  fft4096<false>(v, lds, ld2(tw + t), ld2(tw + 16 * (t & 15)));
+  const v2 twa = ld2(tw + t), twb = ld2(tw + 16 * (t & 15));
+#pragma unroll
+  for (int j = 0; j < kR; j++) v[j] = cmul(v[j], w[j]);
+  fft4096<false>(v, lds, twa, twb);
   float2* dst = X + row * (long)kLdsN;
 #pragma unroll
   for (int jp = 0; jp < kR / 2; jp++) {
@@ -159,7 +162,8 @@ __global__ __launch_bounds__(kBlock) void lds_inner_forward_kernel(float2* __res
   v2 v[kR];
 #pragma unroll
   for (int j = 0; j < kR; j++) v[j] = ld2(row + t + 256 * j);
-  fft4096<false>(v, lds, ld2(tw + t), ld2(tw + 16 * (t & 15)));
+  const v2 twa = ld2(tw + t), twb = ld2(tw + 16 * (t & 15));
+  fft4096<false>(v, lds, twa, twb);
   // every lane has read its 16 inputs before the first exchange barrier, so the row can be overwritten in place
 #pragma unroll
   for (int jp = 0; jp < kR / 2; jp++) {
@@ -189,23 +193,23 @@ __global__ __launch_bounds__(kBlock, 4) void lds_inner_correlate_kernel(const fl
   const __amdgpu_buffer_rsrc_t xres = row_rsrc(X + ((((e * F + fset[p]) * D + d) * (long)B + b) * R + k1) * kLdsN);
   const __amdgpu_buffer_rsrc_t cres = row_rsrc(C + ((long)items[p] * R + k1) * kLdsN);
   const unsigned lane_off = (unsigned)t * 16u;
-  v2 v[kR];
+  v2 v[kR], xv[kR];
 #pragma unroll
-  for (int jp = 0; jp < kR / 2; jp++) {
-    v2 c0, c1, x0, x1;
-    ld_pair(cres, lane_off, jp, c0, c1);
-    ld_pair(xres, lane_off, jp, x0, x1);
-    v[2 * jp] = cmul(c0, x0);
-    v[2 * jp + 1] = cmul(c1, x1);
+  for (int jp = 0; jp < kR / 2; jp++) {          // loads first, asm afterwards (see lds_correlate_kernel)
+    ld_pair(cres, lane_off, jp, v[2 * jp], v[2 * jp + 1]);
+    ld_pair(xres, lane_off, jp, xv[2 * jp], xv[2 * jp + 1]);
   }
-  fft4096<true>(v, lds, ld2(tw + t), ld2(tw + 16 * (t & 15)));
+  const v2 twa = ld2(tw + t), twb = ld2(tw + 16 * (t & 15));
+  v2 base = ld2(twn + k1 * t), step = ld2(twn + 256 * k1);
+#pragma unroll
+  for (int jj = 0; jj < kR; jj++) v[jj] = cmul(v[jj], xv[jj]);
+  fft4096<true>(v, lds, twa, twb);
   float2* dst = Z + ry * (long)kLdsN + t;
   if (k1 == 0) {
 #pragma unroll
     for (int k = 0; k < kR; k++) { const v2 o = v[rev16(k)]; dst[256 * k] = make_float2(o.x, o.y); }
   } else {
     // lane holds n2 = t + 256 k: W_N^{-k1 (t + 256 k)} = conj(W_N^{k1 t}) * conj(W_N^{256 k1})^k
-    v2 base = ld2(twn + k1 * t), step = ld2(twn + 256 * k1);
     base.y = -base.y;
     step.y = -step.y;
     TwPow tp;
@@ -291,24 +295,23 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float
     for (int b = 0; b < nb; b++) {
       if (OPAQUE) asm volatile("" : "+v"(wa.x), "+v"(wa.y), "+v"(wb.x), "+v"(wb.y));
       v2 v[kR];
+      // all loads are issued before the first asm op: the machine scheduler does not move loads across inline asm, so
+      // an interleaved load/cmul loop would wait for every load separately
       if (B1 && CACHEX) {
 #pragma unroll
-        for (int jp = 0; jp < kR / 2; jp++) {
-          v2 c0, c1;
-          ld_pair(cres, lane_off, jp, c0, c1);
-          v[2 * jp] = cmul(c0, xr[2 * jp]);
-          v[2 * jp + 1] = cmul(c1, xr[2 * jp + 1]);
-        }
+        for (int jp = 0; jp < kR / 2; jp++) ld_pair(cres, lane_off, jp, v[2 * jp], v[2 * jp + 1]);
+#pragma unroll
+        for (int jj = 0; jj < kR; jj++) v[jj] = cmul(v[jj], xr[jj]);
       } else {
         const __amdgpu_buffer_rsrc_t xres = row_rsrc(xs + (long)b * kLdsN);
+        v2 xv[kR];
 #pragma unroll
         for (int jp = 0; jp < kR / 2; jp++) {
-          v2 c0, c1, x0, x1;
-          ld_pair(cres, lane_off, jp, c0, c1);
-          ld_pair(xres, lane_off, jp, x0, x1);
-          v[2 * jp] = cmul(c0, x0);
-          v[2 * jp + 1] = cmul(c1, x1);
+          ld_pair(cres, lane_off, jp, v[2 * jp], v[2 * jp + 1]);
+          ld_pair(xres, lane_off, jp, xv[2 * jp], xv[2 * jp + 1]);
         }
+#pragma unroll
+        for (int jj = 0; jj < kR; jj++) v[jj] = cmul(v[jj], xv[jj]);
       }
       if (!B1 && b > 0) __syncthreads();   // previous transform's exchange-2 reads are complete
       if (PRETW) fft4096<true, true>(v, lds, wa, wb, reinterpret_cast<const v2(*)[15]>(pwa), reinterpret_cast<const v2(*)[15]>(pwb));

@@ -50,27 +50,27 @@ __global__ __launch_bounds__(kBlock) void split_outer_forward_kernel(const float
   } else {
     src = x + row * (long)(R * M);
   }
-  v2 v[R];
+  // loads first, asm afterwards: the machine scheduler does not move loads across inline asm
+  v2 v[R], w[MIX ? R : 1];
 #pragma unroll
   for (int n1 = 0; n1 < R; n1++) {
     const int i = M * n1 + n2;
     const float2 sf = src[i];
-    v2 sv = {sf.x, sf.y};
+    v[n1] = v2{sf.x, sf.y};
     if (MIX) {
       // table NCO, index in fp64 exactly as numpy: floor((0 + f*i)*1024) mod 1024   (gnsstools/nco.py:6-9)
       const long k = (long)floor(__dmul_rn(__dmul_rn(f, (double)i), 1024.0)) & (kNcoTableSize - 1);
       const float2 wf = nco_tab[k];
-      const v2 wv = {wf.x, wf.y};
-      sv = cmul(sv, wv);
+      w[n1] = v2{wf.x, wf.y};
     }
-    v[n1] = sv;
+  }
+  const float2 twf = tw[n2];            // W_N^{n2}
+  if (MIX) {
+#pragma unroll
+    for (int n1 = 0; n1 < R; n1++) v[n1] = cmul(v[n1], w[n1]);
   }
   TwPow tp;
-  {
-    const float2 wf = tw[n2];           // W_N^{n2}
-    const v2 wv = {wf.x, wf.y};
-    tp.init<R - 1>(wv);
-  }
+  tp.init<R - 1>(v2{twf.x, twf.y});
   float2* dst = A + row * (long)(R * M) + n2;
   OuterDft<R, false>::run(v, [&](int k1, v2 val) {
     const v2 o = tp.apply(val, k1);
@@ -96,6 +96,13 @@ __global__ __launch_bounds__(kBlock) void split_outer_inverse_kernel(const float
   int idx = 0x7fffffff;
   double sum = 0.0;
   if (n2 < M) {
+    // loads first, asm afterwards: the machine scheduler does not move loads across inline asm
+    v2 v[R];
+    {
+      const float2* src = Z + (g * B) * (long)(R * M) + n2;
+#pragma unroll
+      for (int k1 = 0; k1 < R; k1++) { const float2 zf = src[(long)k1 * M]; v[k1] = v2{zf.x, zf.y}; }
+    }
     TwPow tp;
     if (TW) {
       const float2 wf = tw[n2];
@@ -106,13 +113,14 @@ __global__ __launch_bounds__(kBlock) void split_outer_inverse_kernel(const float
 #pragma unroll
     for (int k = 0; k < R; k++) q[k] = 0.f;
     for (int b = 0; b < B; b++) {
-      const float2* src = Z + (g * B + b) * (long)(R * M) + n2;
-      v2 v[R];
+      if (b > 0) {
+        const float2* src = Z + (g * B + b) * (long)(R * M) + n2;
 #pragma unroll
-      for (int k1 = 0; k1 < R; k1++) {
-        const float2 zf = src[(long)k1 * M];
-        const v2 zv = {zf.x, zf.y};
-        v[k1] = TW ? tp.apply(zv, k1) : zv;
+        for (int k1 = 0; k1 < R; k1++) { const float2 zf = src[(long)k1 * M]; v[k1] = v2{zf.x, zf.y}; }
+      }
+      if (TW) {
+#pragma unroll
+        for (int k1 = 1; k1 < R; k1++) v[k1] = tp.apply(v[k1], k1);
       }
       OuterDft<R, true>::run(v, [&](int n1, v2 val) {
         q[n1] += __builtin_amdgcn_sqrtf(val.x * val.x + val.y * val.y) * inv_n;      // np.absolute(ifft(..)), 1/N folded in
@@ -164,18 +172,19 @@ __device__ __forceinline__ void stockham_pass(const v2* __restrict__ in, v2* __r
   for (int j = threadIdx.x; j < nb; j += kBlock) {
     const int k = j % Ns;
     v2 x[R];
+    if (FIRST) {
+      float2 xv[R], cv[R];
 #pragma unroll
-    for (int t = 0; t < R; t++) {
-      if (FIRST) {
-        const float2 xv = gx[j + t * nb], cv = gc[j + t * nb];
-        x[t] = v2{cv.x * xv.x + cv.y * xv.y, cv.y * xv.x - cv.x * xv.y};      // C * conj(X)   acquire-gps-l1.py:32
-      } else {
-        x[t] = in[j + t * nb];
-      }
-    }
-    if (!FIRST) {
+      for (int t = 0; t < R; t++) { xv[t] = gx[j + t * nb]; cv[t] = gc[j + t * nb]; }
 #pragma unroll
-      for (int t = 1; t < R; t++) x[t] = cmul(x[t], twm[k * t * step]);        // k t step < M
+      for (int t = 0; t < R; t++)
+        x[t] = v2{cv[t].x * xv[t].x + cv[t].y * xv[t].y, cv[t].y * xv[t].x - cv[t].x * xv[t].y};      // C * conj(X)   acquire-gps-l1.py:32
+    } else {
+      v2 wv[R];
+#pragma unroll
+      for (int t = 0; t < R; t++) { x[t] = in[j + t * nb]; if (t) wv[t] = twm[k * t * step]; }          // k t step < M
+#pragma unroll
+      for (int t = 1; t < R; t++) x[t] = cmul(x[t], wv[t]);
     }
     SmallDft<R, true>::run(x);
     const int j0 = (j / Ns) * Ns * R + k;

@@ -42,6 +42,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--engine", type=int, default=0)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--stages", action="store_true", help="also print per-stage HIP-event times")
     ap.add_argument("cases", nargs="*")
     args = ap.parse_args()
     eng = acquire.Engine(0, engine=args.engine)
@@ -65,6 +66,13 @@ def main():
         dt = (time.perf_counter() - t0) / args.reps
         cells = E * len(items) * len(dop) * sig.nfft
         ap_bytes = a_pipe(sig.nfft, len(items), len(dop), B, F) * E
+        if args.stages:
+            eng.set_profiling(True)
+            eng.reset_stage_times()
+            eng.search_batch_dev(sig, xd, items, dop, B)
+            torch.cuda.synchronize()
+            print("   stages:", {k: round(v[0], 4) for k, v in eng.stage_times().items() if v[1]})
+            eng.set_profiling(False)
         print(json.dumps({"case": cid, "signal": name, "P": len(items), "D": len(dop), "B": B, "N": sig.nfft, "epochs": E,
                           "ms": dt * 1e3, "cells_per_s": cells / dt, "cell_blocks_per_s": cells * B / dt,
                           "a_pipe_GBps": ap_bytes / dt / 1e9, "frac_8TBps": ap_bytes / dt / 8e12}))
