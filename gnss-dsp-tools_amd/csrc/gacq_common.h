@@ -57,6 +57,8 @@ struct gacq_ctx {
   std::vector<double> up_freq;
   std::vector<int> up_fset, up_items, up_d0;
   std::vector<float> up_taps;
+  // device-resident constant tables (twiddles, long-code chips), keyed by name; owned by the ctx, freed in gacq_destroy
+  std::map<std::string, gacq::DevBuf> tables;
 };
 
 struct gacq_sig {
@@ -73,6 +75,10 @@ namespace gacq {
 
 int set_error(gacq_ctx* ctx, int code, const char* fmt, ...);
 int ensure(gacq_ctx* ctx, DevBuf& b, size_t bytes);
+// W_N^k = exp(-2 pi i k / N) for k < count, fp64-evaluated and rounded once to fp32; cached per ctx under `key`
+int twiddle_cache(gacq_ctx* ctx, const std::string& key, int N, int count, const float2** out);
+// arbitrary constant bytes cached per ctx under `key` (uploaded on first use)
+int table_cache(gacq_ctx* ctx, const std::string& key, const void* host, size_t bytes, const void** out);
 int fft_exec(gacq_ctx* ctx, int N, long batch, bool inverse, void* data);
 void stage_begin(gacq_ctx* ctx, int stage);
 void stage_end(gacq_ctx* ctx);

@@ -57,6 +57,36 @@ int ensure(gacq_ctx* ctx, DevBuf& b, size_t bytes) {
   return GACQ_OK;
 }
 
+int table_cache(gacq_ctx* ctx, const std::string& key, const void* host, size_t bytes, const void** out) {
+  auto it = ctx->tables.find(key);
+  if (it == ctx->tables.end()) {
+    DevBuf b;
+    GACQ_HIP(ctx, hipMalloc(&b.p, bytes));
+    b.cap = bytes;
+    if (hipMemcpy(b.p, host, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipFree(b.p);
+      return set_error(ctx, GACQ_ERR_HIP, "upload of table '%s' failed", key.c_str());
+    }
+    it = ctx->tables.emplace(key, b).first;
+  }
+  *out = it->second.p;
+  return GACQ_OK;
+}
+
+int twiddle_cache(gacq_ctx* ctx, const std::string& key, int N, int count, const float2** out) {
+  auto it = ctx->tables.find(key);
+  if (it != ctx->tables.end()) { *out = (const float2*)it->second.p; return GACQ_OK; }
+  std::vector<float2> h(count);
+  for (int k = 0; k < count; k++) {
+    const double a = -2.0 * M_PI * (double)k / (double)N;
+    h[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+  }
+  const void* p = nullptr;
+  int rc = table_cache(ctx, key, h.data(), sizeof(float2) * (size_t)count, &p);
+  *out = (const float2*)p;
+  return rc;
+}
+
 int fft_exec(gacq_ctx* ctx, int N, long batch, bool inverse, void* data) {
   auto key = std::make_pair((long)N * 2 + (inverse ? 1 : 0), batch);
   auto it = ctx->plans.find(key);
@@ -322,6 +352,7 @@ void gacq_destroy(gacq_ctx* ctx) {
   for (auto& ev : ctx->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
   DevBuf* bufs[] = {&ctx->tab, &ctx->xstage, &ctx->X, &ctx->Y, &ctx->rows, &ctx->freq, &ctx->fset, &ctx->items, &ctx->out_peaks, &ctx->d0, &ctx->partial, &ctx->fe_a, &ctx->fe_b, &ctx->fe_taps};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
+  for (auto& kv : ctx->tables) if (kv.second.p) (void)hipFree(kv.second.p);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }

@@ -394,23 +394,7 @@ const CorrVariant kVariants[] = {
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 constexpr int kDefaultVariant = 1;   // profiles/r01_ab_variants_*.log: all packed-math variants are within 5 %; this one led twice
 
-DevBuf g_tw[16];   // per-device W_4096 table
-
-int twiddle_table(gacq_ctx* ctx, const float2** out) {
-  DevBuf& b = g_tw[ctx->device & 15];
-  if (!b.p) {
-    std::vector<float2> h(kLdsN);
-    for (int k = 0; k < kLdsN; k++) {
-      const double a = -2.0 * M_PI * (double)k / (double)kLdsN;
-      h[k] = make_float2((float)std::cos(a), (float)std::sin(a));
-    }
-    GACQ_HIP(ctx, hipMalloc(&b.p, sizeof(float2) * kLdsN));
-    b.cap = sizeof(float2) * kLdsN;
-    GACQ_HIP(ctx, hipMemcpy(b.p, h.data(), b.cap, hipMemcpyHostToDevice));
-  }
-  *out = (const float2*)b.p;
-  return GACQ_OK;
-}
+int twiddle_table(gacq_ctx* ctx, const float2** out) { return twiddle_cache(ctx, "W4096", kLdsN, kLdsN, out); }
 
 }  // namespace
 
@@ -464,23 +448,9 @@ int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const i
 
 // ---- inner stages of the split engine (N = R*4096) -------------------------------------------------------
 namespace {
-struct BigTw { int N; int device; float2* p; };
-std::vector<BigTw> g_bigtw;
 // W_N^m for m < 256 R
 int big_twiddles(gacq_ctx* ctx, int N, int R, const float2** out) {
-  for (const BigTw& t : g_bigtw) if (t.N == N && t.device == ctx->device) { *out = t.p; return GACQ_OK; }
-  const int cnt = 256 * R;
-  std::vector<float2> h(cnt);
-  for (int k = 0; k < cnt; k++) {
-    const double a = -2.0 * M_PI * (double)k / (double)N;
-    h[k] = make_float2((float)std::cos(a), (float)std::sin(a));
-  }
-  BigTw t{N, ctx->device, nullptr};
-  GACQ_HIP(ctx, hipMalloc((void**)&t.p, sizeof(float2) * cnt));
-  GACQ_HIP(ctx, hipMemcpy(t.p, h.data(), sizeof(float2) * cnt, hipMemcpyHostToDevice));
-  g_bigtw.push_back(t);
-  *out = t.p;
-  return GACQ_OK;
+  return twiddle_cache(ctx, "WN_lo_" + std::to_string(N), N, 256 * R, out);
 }
 }  // namespace
 

@@ -75,23 +75,20 @@ __global__ void longcode_finish_kernel(const double2* __restrict__ partial, doub
   q[k] = acc;
 }
 
-struct DevChips { std::string code; int prn; int device; uint8_t* p; long L; };
-std::vector<DevChips> g_chips;
-
 int device_chips(gacq_ctx* ctx, const char* code, int prn, const uint8_t** out, long* L) {
-  for (const DevChips& d : g_chips) if (d.device == ctx->device && d.prn == prn && d.code == code) { *out = d.p; *L = d.L; return GACQ_OK; }
   const int len = gacq_code_length(code);
   if (len < 0) return set_error(ctx, GACQ_ERR_UNKNOWN_CODE, "long-code search: unknown code '%s'", code);
+  const std::string key = std::string("chips:") + code + ":" + std::to_string(prn);
+  *L = len;
+  auto it = ctx->tables.find(key);
+  if (it != ctx->tables.end()) { *out = (const uint8_t*)it->second.p; return GACQ_OK; }
   std::vector<uint8_t> h(len);
   const int rc = gacq_code_chips(code, prn, h.data(), len);
   if (rc < 0) return set_error(ctx, rc, "long-code search: no PRN %d in '%s'", prn, code);
-  DevChips d{code, prn, ctx->device, nullptr, len};
-  GACQ_HIP(ctx, hipMalloc((void**)&d.p, (size_t)len));
-  GACQ_HIP(ctx, hipMemcpy(d.p, h.data(), (size_t)len, hipMemcpyHostToDevice));
-  g_chips.push_back(d);
-  *out = d.p;
-  *L = len;
-  return GACQ_OK;
+  const void* p = nullptr;
+  const int rc2 = table_cache(ctx, key, h.data(), (size_t)len, &p);
+  *out = (const uint8_t*)p;
+  return rc2;
 }
 
 }  // namespace

@@ -241,23 +241,9 @@ __global__ void split_combine_kernel(const RowRec* __restrict__ partial, RowRec*
   rows[g0 + g] = best;
 }
 
-struct TwTable { int N; int device; float2* p; };
-std::vector<TwTable> g_tables;
-
 // W_N^k for k < M (the per-n2 base twiddles of the outer stage)
 int base_twiddles(gacq_ctx* ctx, int N, int M, const float2** out) {
-  for (const TwTable& t : g_tables) if (t.N == N && t.device == ctx->device) { *out = t.p; return GACQ_OK; }
-  std::vector<float2> h(M);
-  for (int k = 0; k < M; k++) {
-    const double a = -2.0 * M_PI * (double)k / (double)N;
-    h[k] = make_float2((float)std::cos(a), (float)std::sin(a));
-  }
-  TwTable t{N, ctx->device, nullptr};
-  GACQ_HIP(ctx, hipMalloc((void**)&t.p, sizeof(float2) * M));
-  GACQ_HIP(ctx, hipMemcpy(t.p, h.data(), sizeof(float2) * M, hipMemcpyHostToDevice));
-  g_tables.push_back(t);
-  *out = t.p;
-  return GACQ_OK;
+  return twiddle_cache(ctx, "WN_base_" + std::to_string(N), N, M, out);
 }
 
 bool smooth(int m) {
@@ -293,21 +279,8 @@ int launch_inverse(gacq_ctx* ctx, const float2* Z, RowRec* partial, const float2
   return GACQ_OK;
 }
 
-struct TwM { int M; int device; float2* p; };
-std::vector<TwM> g_twm;
 int inner_twiddles(gacq_ctx* ctx, int M, const float2** out) {          // W_M^k, k < M
-  for (const TwM& t : g_twm) if (t.M == M && t.device == ctx->device) { *out = t.p; return GACQ_OK; }
-  std::vector<float2> h(M);
-  for (int k = 0; k < M; k++) {
-    const double a = -2.0 * M_PI * (double)k / (double)M;
-    h[k] = make_float2((float)std::cos(a), (float)std::sin(a));
-  }
-  TwM t{M, ctx->device, nullptr};
-  GACQ_HIP(ctx, hipMalloc((void**)&t.p, sizeof(float2) * M));
-  GACQ_HIP(ctx, hipMemcpy(t.p, h.data(), sizeof(float2) * M, hipMemcpyHostToDevice));
-  g_twm.push_back(t);
-  *out = t.p;
-  return GACQ_OK;
+  return twiddle_cache(ctx, "WM_" + std::to_string(M), M, M, out);
 }
 
 }  // namespace

@@ -6,5 +6,5 @@ cd "$(dirname "$0")/../gnss-dsp-tools_amd/csrc"
 for a in "$@"; do
   mkdir -p ../build/abl$a
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I/opt/rocm/include -DGACQ_ABL=$a -c gacq_ldsfft.hip -o ../build/abl$a/gacq_ldsfft.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libgacq_abl$a.so ../build/gacq_engine.o ../build/abl$a/gacq_ldsfft.o ../build/gacq_split.o ../build/gacq_frontend.o ../build/prn_codes.o -L/opt/rocm/lib -lrocfft -Wl,-rpath,/opt/rocm/lib
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libgacq_abl$a.so $(ls ../build/*.o | grep -v gacq_ldsfft.o) ../build/abl$a/gacq_ldsfft.o -L/opt/rocm/lib -lrocfft -Wl,-rpath,/opt/rocm/lib
 done
