@@ -58,6 +58,39 @@ class ShardedSearch:
             return self.engine.merge_peaks_dev(gathered, b[:-1])
         return merge_peaks_host(gathered.numpy(), b[:-1])
 
+    def search_jobs(self, jobs):
+        """Cold-start style multi-constellation search (BASELINE config 5): `jobs` is a list of dicts
+        {name, x, items, dopplers, blocks}.  Every job's Doppler grid is sliced over the ranks like search_batch, all
+        local peaks are packed into ONE buffer and exchanged with a single all-gather, then merged per job.
+        Returns the list of merged peak tensors (one per job, [nepoch, nitems, 2])."""
+        import torch
+        locals_, bounds, shapes = [], [], []
+        for job in jobs:
+            dop = np.ascontiguousarray(job["dopplers"], dtype=np.float64)
+            b = doppler_bounds(len(dop), self.world)
+            lo, hi = b[self.rank], b[self.rank + 1]
+            if self.local_fn is not None:
+                loc = self.local_fn(job["name"], job["x"], job["items"], dop[lo:hi], job["blocks"])
+            else:
+                self.engine.use_torch_stream(job["x"].device)
+                loc = self.engine.search_batch_dev(job["name"], job["x"], job["items"], dop[lo:hi], job["blocks"])
+            locals_.append(loc.contiguous())
+            bounds.append(b)
+            shapes.append(tuple(loc.shape))
+        if self.world == 1 and not (self.always_gather and self.dist.is_initialized()):
+            return locals_
+        flat = torch.cat([t.view(-1) for t in locals_])
+        gathered = torch.empty(self.world * flat.numel(), dtype=flat.dtype, device=flat.device)
+        self.dist.all_gather_into_tensor(gathered, flat, group=self.group)                    # the ONE collective
+        gathered = gathered.view(self.world, flat.numel())
+        out, off = [], 0
+        for shp, b in zip(shapes, bounds):
+            cnt = int(np.prod(shp))
+            part = gathered[:, off:off + cnt].contiguous().view((self.world,) + shp)
+            off += cnt
+            out.append(self.engine.merge_peaks_dev(part, b[:-1]) if part.is_cuda else merge_peaks_host(part.numpy(), b[:-1]))
+        return out
+
     def results(self, name, items, merged, dopplers):
         """Merged peaks -> per-epoch lists of the reference's (metric, code, doppler) tuples."""
         pk = merged.cpu().numpy() if hasattr(merged, "cpu") else np.asarray(merged)

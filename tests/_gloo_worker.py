@@ -46,8 +46,18 @@ def main():
         dop = acquire.doppler_grid(ds)
         xs = synth.make_epochs(sig, blocks, 5150, [(items[0], 0.4, 1537.0, 1201)], 2)
         sh = sharded.ShardedSearch(engine=None, local_fn=oracle_local)
-        merged = sh.search_batch(name, torch.from_numpy(xs), items, dop, blocks)
-        res = sh.results(name, items, merged, dop)
+        if os.environ.get("GLOO_JOBS"):
+            # two jobs, one exchange: the same search plus a second Doppler grid
+            dop2 = acquire.doppler_grid([ds[0] + 37.0, ds[1], ds[2] * 2])
+            jobs = [{"name": name, "x": torch.from_numpy(xs), "items": items, "dopplers": dop, "blocks": blocks},
+                    {"name": name, "x": torch.from_numpy(xs), "items": items[:1], "dopplers": dop2, "blocks": blocks}]
+            m1, m2 = sh.search_jobs(jobs)
+            res = sh.results(name, items, m1, dop)
+            res2 = sh.results(name, items[:1], m2, dop2)
+            res = [a + b for a, b in zip(res, res2)]          # per epoch: job-1 results followed by job-2's
+        else:
+            merged = sh.search_batch(name, torch.from_numpy(xs), items, dop, blocks)
+            res = sh.results(name, items, merged, dop)
         if dist.get_rank() == 0:
             with open(out_path, "w") as f:
                 json.dump([[[float(v) for v in r] for r in ep] for ep in res], f)

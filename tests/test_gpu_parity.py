@@ -410,3 +410,26 @@ def test_maximum_default_integration_time_gps_l1(engine):
     got = engine.search_all(sig, x, items, ds, 80)
     want = [acq_oracle.search_script("gps-l1", x.astype(np.complex128), it, ds, 80) for it in items]
     _assert_results(got, [[float(v) for v in w] for w in want], {"id": "gps-l1 ms=80", "items": items})
+
+
+def test_multi_constellation_jobs_single_rank(engine):
+    """search_jobs (config-5 style: several signals in one sharded pass) on one rank == per-signal search_all."""
+    import torch
+    from gnss_dsp_tools_amd import acquire, sharded, signals, synth
+    specs = [("gps-l1", [3, 11, 28], [-2000.0, 2000.0, 250.0], 2), ("beidou-b1i", [6, 33], [1000.0, 2000.0, 250.0], 2),
+             ("glonass-l1", [-7, 3], [1000.0, 2000.0, 250.0], 1)]
+    jobs, want = [], []
+    for name, items, ds, ms in specs:
+        sig = signals.get(name)
+        B = sig.blocks(ms)
+        x = synth.make_iq(sig, B, 9090, [(items[0], 0.4, 1537.0, 1201)])
+        dop = acquire.doppler_grid(ds)
+        jobs.append({"name": sig, "x": torch.from_numpy(x[None, :sig.samples_needed(B)].copy()).cuda(), "items": items, "dopplers": dop, "blocks": B})
+        want.append(engine.search_all(sig, x, items, ds, ms))
+    sh = sharded.ShardedSearch(engine=engine)
+    merged = sh.search_jobs(jobs)
+    torch.cuda.synchronize()
+    for (name, items, ds, ms), m, w in zip(specs, merged, want):
+        got = sh.results(name, items, m, acquire.doppler_grid(ds))[0]
+        assert got == w, name
+    engine.set_stream(None)

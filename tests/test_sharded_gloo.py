@@ -57,6 +57,33 @@ def test_sharded_search_equals_unsharded_oracle(tmp_path, world, name, items, ds
             assert got[0] == pytest.approx(float(want[0]), rel=1e-12)
 
 
+def test_multi_job_search_uses_one_exchange_and_matches_oracle(tmp_path):
+    """search_jobs: two searches sharded over 2 ranks, packed into one all-gather, merged per job."""
+    from gnss_dsp_tools_amd import acquire, signals, synth
+    from oracle import acq_oracle
+    name, items, ds, ms, world = "gps-l1", [3, 9], [1000.0, 2050.0, 150.0], 1, 2
+    out = tmp_path / "res.json"
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_JOBS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gloo_worker.py"), str(out), name,
+                                       ",".join(map(str, items)), ",".join(map(str, ds)), str(ms)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        log, _ = p.communicate(timeout=240)
+        assert p.returncode == 0, log.decode()[-2000:]
+    res = json.load(open(out))
+    sig = signals.get(name)
+    xs = synth.make_epochs(sig, sig.blocks(ms), 5150, [(items[0], 0.4, 1537.0, 1201)], 2)
+    ds2 = [ds[0] + 37.0, ds[1], ds[2] * 2]
+    for e in range(xs.shape[0]):
+        x = xs[e].astype(np.complex128)
+        want = [acq_oracle.search_script(name, x, it, ds, ms) for it in items] + [acq_oracle.search_script(name, x, items[0], ds2, ms)]
+        for got, w in zip(res[e], want):
+            assert got[2] == float(w[2]) and got[1] == float(w[1]) and got[0] == pytest.approx(float(w[0]), rel=1e-12)
+
+
 def test_doppler_bounds_cover_grid():
     from gnss_dsp_tools_amd import sharded
     for nd in (0, 1, 5, 40, 70, 200):
