@@ -68,6 +68,7 @@ struct gacq_sig {
   int N = 0;                 // FFT length: n or 2n
   float2* spectra = nullptr; // [nprn][N] code spectra C_p = fft(replica), complex64, natural order
   float2* spectra_pfa = nullptr;   // same in the radix-31 engine's [k1][k2] order (only when pfa_supported(N))
+  float2* spectra_split = nullptr; // split engine with LDS inner transforms: R lane-pair rows per item (N = R*4096)
   float2* spectra_lds = nullptr;   // same in the LDS engine's lane-pair layout (only when lds_supported(N))
 };
 

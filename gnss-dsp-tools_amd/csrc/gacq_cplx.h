@@ -193,6 +193,10 @@ template <> struct TrigN<9> {
   static constexpr float c[9] = {1.f, 0.766044443f, 0.173648178f, -0.5f, -0.939692621f, -0.939692621f, -0.5f, 0.173648178f, 0.766044443f};
   static constexpr float s[9] = {0.f, 0.64278761f, 0.984807753f, 0.866025404f, 0.342020143f, -0.342020143f, -0.866025404f, -0.984807753f, -0.64278761f};
 };
+template <> struct TrigN<16> {
+  static constexpr float c[16] = {1.f, 0.923879533f, 0.707106781f, 0.382683432f, 0.f, -0.382683432f, -0.707106781f, -0.923879533f, -1.f, -0.923879533f, -0.707106781f, -0.382683432f, 0.f, 0.382683432f, 0.707106781f, 0.923879533f};
+  static constexpr float s[16] = {0.f, 0.382683432f, 0.707106781f, 0.923879533f, 1.f, 0.923879533f, 0.707106781f, 0.382683432f, 0.f, -0.382683432f, -0.707106781f, -0.923879533f, -1.f, -0.923879533f, -0.707106781f, -0.382683432f};
+};
 template <> struct TrigN<20> {
   static constexpr float c[20] = {1.f, 0.951056516f, 0.809016994f, 0.587785252f, 0.309016994f, 0.f, -0.309016994f, -0.587785252f, -0.809016994f, -0.951056516f, -1.f, -0.951056516f, -0.809016994f, -0.587785252f, -0.309016994f, 0.f, 0.309016994f, 0.587785252f, 0.809016994f, 0.951056516f};
   static constexpr float s[20] = {0.f, 0.309016994f, 0.587785252f, 0.809016994f, 0.951056516f, 1.f, 0.951056516f, 0.809016994f, 0.587785252f, 0.309016994f, 0.f, -0.309016994f, -0.587785252f, -0.809016994f, -0.951056516f, -1.f, -0.951056516f, -0.809016994f, -0.587785252f, -0.309016994f};

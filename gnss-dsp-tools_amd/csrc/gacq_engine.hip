@@ -459,9 +459,9 @@ static int build_signal(gacq_ctx* ctx, const gacq_sigdesc* desc, const std::vect
     if (rc == GACQ_OK) rc = pfa_forward(ctx, tmp, 0, nprn, s->N, s->N, nullptr, 1, 1, nullptr, s->spectra_pfa, false);
     if (rc == GACQ_OK && s->N / split_radix(s->N) == 4096) {
       // split engine with LDS inner transforms (N = R*4096): code spectra as R lane-pair rows per item
-      if (hipMalloc((void**)&s->spectra_lds, bytes) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "hipMalloc for split/LDS spectra failed");
-      if (rc == GACQ_OK) rc = pfa_forward(ctx, tmp, 0, nprn, s->N, s->N, nullptr, 1, 1, nullptr, s->spectra_lds, false, false);
-      if (rc == GACQ_OK) rc = lds_inner_forward(ctx, s->spectra_lds, (long)nprn * split_radix(s->N), false);
+      if (hipMalloc((void**)&s->spectra_split, bytes) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "hipMalloc for split/LDS spectra failed");
+      if (rc == GACQ_OK) rc = pfa_forward(ctx, tmp, 0, nprn, s->N, s->N, nullptr, 1, 1, nullptr, s->spectra_split, false, false);
+      if (rc == GACQ_OK) rc = lds_inner_forward(ctx, s->spectra_split, (long)nprn * split_radix(s->N), false);
     }
     if (rc == GACQ_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "split-engine code spectrum failed");
     if (tmp) (void)hipFree(tmp);
@@ -471,7 +471,7 @@ static int build_signal(gacq_ctx* ctx, const gacq_sigdesc* desc, const std::vect
     else rc = lds_prepare_spectra(ctx, s->spectra, s->spectra_lds, nprn, s->N);
   }
   if (rc == GACQ_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "code spectrum FFT failed");
-  if (rc != GACQ_OK) { (void)hipFree(s->spectra); if (s->spectra_lds) (void)hipFree(s->spectra_lds); if (s->spectra_pfa) (void)hipFree(s->spectra_pfa); delete s; return rc; }
+  if (rc != GACQ_OK) { (void)hipFree(s->spectra); if (s->spectra_lds) (void)hipFree(s->spectra_lds); if (s->spectra_pfa) (void)hipFree(s->spectra_pfa); if (s->spectra_split) (void)hipFree(s->spectra_split); delete s; return rc; }
   *out = s;
   return GACQ_OK;
 }
@@ -517,6 +517,7 @@ void gacq_signal_destroy(gacq_sig* sig) {
   if (sig->spectra) (void)hipFree(sig->spectra);
   if (sig->spectra_lds) (void)hipFree(sig->spectra_lds);
   if (sig->spectra_pfa) (void)hipFree(sig->spectra_pfa);
+  if (sig->spectra_split) (void)hipFree(sig->spectra_split);
   delete sig;
 }
 
@@ -592,7 +593,7 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
     ctx->up_items = items_v;
   }
 
-  const bool use_lds = (ctx->engine == 2) || (ctx->engine == 0 && lds_supported(N) && !d_qrow);
+  const bool use_lds = (ctx->engine == 2) || (ctx->engine == 0 && lds_supported(N) && !d_qrow);      // whole transform in one workgroup
   if (ctx->engine == 2 && (!lds_supported(N) || d_qrow))
     return set_error(ctx, GACQ_ERR_UNSUPPORTED, "engine 2 (LDS FFT) does not support N=%d%s", N, d_qrow ? " with row dump" : "");
   const int R = split_radix(N);
@@ -655,7 +656,7 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
         const long ng = std::min(gc, groups - g0);
         if (use_split_lds) {
           stage_begin(ctx, 6);
-          rc = lds_inner_correlate(ctx, X, sig->spectra_lds, (const int*)ctx->items.p, (const int*)ctx->fset.p, g0, ng, P, F, D, B, R,
+          rc = lds_inner_correlate(ctx, X, sig->spectra_split, (const int*)ctx->items.p, (const int*)ctx->fset.p, g0, ng, P, F, D, B, R,
                                    N, Y);                                       // K2 + inner inverse FFT + twiddle, fused
           stage_end(ctx);
           if (rc != GACQ_OK) return rc;

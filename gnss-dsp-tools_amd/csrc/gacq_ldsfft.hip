@@ -65,8 +65,9 @@ __device__ __forceinline__ void apply_table(v2 (&v)[kR], const v2 (&pw)[15]) {
 // Length-4096 transform of the 16 values per lane. In: v[j] = x[t + 256 j]; out: v[rev16(k2)] = X[t + 256 k2].
 // wa = W_4096^t, wb = W_256^(t & 15) (forward values; conjugated here when INV).
 template <bool INV, bool PRE = false>
-__device__ __forceinline__ void fft4096(v2 (&v)[kR], v2* lds, v2 wa, v2 wb, const v2 (*pa)[15] = nullptr, const v2 (*pb)[15] = nullptr) {
-  const int t = threadIdx.x;
+__device__ __forceinline__ void fft4096(v2 (&v)[kR], v2* lds, v2 wa, v2 wb, const v2 (*pa)[15] = nullptr, const v2 (*pb)[15] = nullptr,
+                                        int t = -1) {
+  if (t < 0) t = threadIdx.x;                       // lane index within the 256-lane group that owns this transform
   if (INV && !PRE) { wa.y = -wa.y; wb.y = -wb.y; }
   dft16<INV>(v);
   if (!(GACQ_ABL & 8)) { if (PRE) apply_table(v, *pa); else apply_powers(v, wa); }
@@ -148,6 +149,188 @@ __global__ __launch_bounds__(kBlock) void lds_forward_kernel(const float2* __res
     const v2 a = v[rev16(2 * jp)], b = v[rev16(2 * jp + 1)];
     // store conj(FFT) in the lane-pair layout: np.conj(fft.fft(b))  acquire-gps-l1.py:32
     *reinterpret_cast<float4*>(dst + jp * 512 + 2 * t) = make_float4(a.x, -a.y, b.x, -b.y);
+  }
+}
+
+// ======================================================================================================
+// N = 16384 = 4 x 4096 in ONE 1024-thread workgroup (B1I/B2I padded, GLONASS L1/L2): 16 points per lane,
+//   n = 4096 na + m, k = ka + 4 km:  X[ka + 4 km] = FFT4096_m( W_N^{m ka} * sum_na x[4096 na + m] W_4^{na ka} )[km]
+//   pass 0  lane t holds x[t + 1024 j], j = 4 na + jj (m = t + 1024 jj): four DFT-4 over na, twiddle W_N^{m ka}
+//   exchange 0 through LDS: (ka, m) -> region ka, lane t' = m mod 256 gets m = t' + 256 j
+//   then each 256-lane group runs the 4096-point transform of its region (same code as the N = 4096 engine).
+// LDS: 4 regions x 32.9 KB = 131.6 KB -> one workgroup (16 waves, 4 per SIMD) per CU.  Output: lane (ka, t'') holds
+// X[(ka + 4 t'') + 1024 k2] in register rev16(k2), i.e. exactly the input convention with lane index ka + 4 t''.
+constexpr int kBig = 16384;
+constexpr int kBigThreads = 1024;
+constexpr int kBigLdsBytes = 4 * kLdsElems * (int)sizeof(v2);
+
+template <bool INV>
+__device__ __forceinline__ void fft16k(v2 (&v)[kR], v2* lds, const float2* __restrict__ twn /* W_16384^m, m < 1024 */, v2 base) {
+  const int t = threadIdx.x;
+  const int g = t >> 8, tl = t & 255;
+  // issue the table loads of the inner transform before any asm
+  v2 wa = ld2(twn + 4 * tl), wb = ld2(twn + 64 * (tl & 15));
+  if (INV) base.y = -base.y;
+  const v2 p2 = cmul(base, base), p3 = cmul(p2, base);
+#pragma unroll
+  for (int jj = 0; jj < 4; jj++) {
+    dft4<INV, false>(v[jj], v[jj + 4], v[jj + 8], v[jj + 12]);                 // -> ka at v[jj + 4 ka]
+    v2 a = v[jj + 4], b = v[jj + 8], c = v[jj + 12];
+    if (jj) {                                                                  // W_16^{jj ka} part of W_N^{(t + 1024 jj) ka}
+      a = cmul_k(a, wconst<16, INV>(jj));
+      b = cmul_k(b, wconst<16, INV>(2 * jj));
+      c = cmul_k(c, wconst<16, INV>(3 * jj));
+    }
+    v[jj + 4] = cmul(a, base);
+    v[jj + 8] = cmul(b, p2);
+    v[jj + 12] = cmul(c, p3);
+  }
+#pragma unroll
+  for (int ka = 0; ka < 4; ka++) {
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++) lds[ka * kLdsElems + t + 1024 * jj] = v[jj + 4 * ka];
+  }
+  __syncthreads();
+  v2* region = lds + g * kLdsElems;
+#pragma unroll
+  for (int j = 0; j < kR; j++) v[j] = region[tl + 256 * j];
+  __syncthreads();                                   // exchange-0 reads complete before the regions are reused
+  fft4096<INV>(v, region, wa, wb, nullptr, nullptr, tl);
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t big_rsrc(const float2* row) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, kBig * (int)sizeof(float2), 0x00020000);
+}
+__device__ __forceinline__ void ld_pair_big(__amdgpu_buffer_rsrc_t r, unsigned lane_off, int jp, v2& a, v2& b) {
+  const f4 q = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, (unsigned)jp * 16384u, 0));
+  a = q.xy;
+  b = q.zw;
+}
+
+// forward: one workgroup per (e, f, d, b) row; output conj(FFT) in the 1024-lane pair layout (j>>1)*2048 + 2 lane + (j&1)
+__global__ __launch_bounds__(kBigThreads) void lds16k_forward_kernel(const float2* __restrict__ x, size_t epoch_stride,
+                                                                      float2* __restrict__ X, const double* __restrict__ freq,
+                                                                      const float2* __restrict__ nco_tab,
+                                                                      const float2* __restrict__ twn, int n, int FD, int B) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v2* lds = reinterpret_cast<v2*>(smem);
+  const int t = threadIdx.x;
+  const long row = blockIdx.x;
+  const int b = (int)(row % B);
+  const long r2 = row / B;
+  const int fd = (int)(r2 % FD);
+  const long e = r2 / FD;
+  const double f = freq[fd];
+  const float2* src = x + e * epoch_stride + (size_t)b * n;
+  v2 v[kR], w[kR];
+#pragma unroll
+  for (int j = 0; j < kR; j++) {
+    const int i = t + 1024 * j;
+    v[j] = ld2(src + i);
+    const long k = (long)floor(__dmul_rn(__dmul_rn(f, (double)i), 1024.0)) & (kNcoTableSize - 1);   // gnsstools/nco.py:6-9
+    w[j] = ld2(nco_tab + k);
+  }
+  const v2 base = ld2(twn + t);
+#pragma unroll
+  for (int j = 0; j < kR; j++) v[j] = cmul(v[j], w[j]);
+  fft16k<false>(v, lds, twn, base);
+  const int lane = (t >> 8) + 4 * (t & 255);
+  float2* dst = X + row * (long)kBig;
+#pragma unroll
+  for (int jp = 0; jp < kR / 2; jp++) {
+    const v2 a = v[rev16(2 * jp)], c = v[rev16(2 * jp + 1)];
+    *reinterpret_cast<float4*>(dst + jp * 2048 + 2 * lane) = make_float4(a.x, -a.y, c.x, -c.y);
+  }
+}
+
+__global__ __launch_bounds__(kBigThreads) void lds16k_permute_kernel(const float2* __restrict__ nat, float2* __restrict__ perm) {
+  const long row = blockIdx.x;
+  const int t = threadIdx.x;
+  const float2* src = nat + row * kBig;
+  float2* dst = perm + row * kBig;
+#pragma unroll
+  for (int jp = 0; jp < kR / 2; jp++) {
+    const float2 a = src[t + 1024 * (2 * jp)], b = src[t + 1024 * (2 * jp + 1)];
+    *reinterpret_cast<float4*>(dst + jp * 2048 + 2 * t) = make_float4(a.x, a.y, b.x, b.y);
+  }
+}
+
+// correlate: workgroup = (epoch, Doppler, chunk of items); per item: sum_b |IFFT(C_p * X_b)|/N -> (max, argmax, sum)
+__global__ __launch_bounds__(kBigThreads) void lds16k_correlate_kernel(const float2* __restrict__ X, const float2* __restrict__ C,
+                                                                        const int* __restrict__ items, const int* __restrict__ fset,
+                                                                        const float2* __restrict__ twn, RowRec* __restrict__ rows,
+                                                                        int E, int P, int F, int D, int B, int pch, int nchunk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v2* lds = reinterpret_cast<v2*>(smem);
+  __shared__ float s_peak[kBigThreads / 64];
+  __shared__ int s_idx[kBigThreads / 64];
+  __shared__ double s_sum[kBigThreads / 64];
+  const int t = threadIdx.x;
+  const int xcd = blockIdx.x & 7;
+  const long j = blockIdx.x >> 3;
+  const long u = (j / nchunk) * 8 + xcd;             // (epoch, Doppler) unit -> XCD, as in lds_correlate_kernel
+  if (u >= (long)E * D) return;
+  const long e = u / D;
+  const int d = (int)(u % D);
+  const int p0 = (int)(j % nchunk) * pch;
+  const int p1 = min(P, p0 + pch);
+  const v2 base = ld2(twn + t);
+  const unsigned lane_off = (unsigned)t * 16u;
+  const float inv_n = 1.0f / (float)kBig;
+  const int lag0 = (t >> 8) + 4 * (t & 255);        // lags of this lane: lag0 + 1024 k
+  for (int p = p0; p < p1; p++) {
+    const __amdgpu_buffer_rsrc_t cres = big_rsrc(C + (long)items[p] * kBig);
+    const float2* xs = X + (((e * F + fset[p]) * D + d) * (long)B) * kBig;
+    float q[kR];
+#pragma unroll
+    for (int k = 0; k < kR; k++) q[k] = 0.f;
+    for (int b = 0; b < B; b++) {
+      const __amdgpu_buffer_rsrc_t xres = big_rsrc(xs + (long)b * kBig);
+      v2 v[kR], xv[kR];
+#pragma unroll
+      for (int jp = 0; jp < kR / 2; jp++) {          // loads first, asm afterwards
+        ld_pair_big(cres, lane_off, jp, v[2 * jp], v[2 * jp + 1]);
+        ld_pair_big(xres, lane_off, jp, xv[2 * jp], xv[2 * jp + 1]);
+      }
+#pragma unroll
+      for (int jj = 0; jj < kR; jj++) v[jj] = cmul(v[jj], xv[jj]);
+      if (b > 0 || p > p0) __syncthreads();          // previous transform's last LDS reads are complete
+      fft16k<true>(v, lds, twn, base);
+#pragma unroll
+      for (int k = 0; k < kR; k++) {
+        const v2 r = v[rev16(k)];
+        q[k] += __builtin_amdgcn_sqrtf(r.x * r.x + r.y * r.y) * inv_n;
+      }
+    }
+    float peak = q[0];
+    int idx = lag0;
+    double sum = (double)q[0];
+#pragma unroll
+    for (int k = 1; k < kR; k++) {
+      if (q[k] > peak) { peak = q[k]; idx = lag0 + 1024 * k; }
+      sum += (double)q[k];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float op = __shfl_down(peak, off);
+      const int oi = __shfl_down(idx, off);
+      const double os = __shfl_down(sum, off);
+      if (op > peak || (op == peak && oi < idx)) { peak = op; idx = oi; }
+      sum += os;
+    }
+    if ((t & 63) == 0) { s_peak[t >> 6] = peak; s_idx[t >> 6] = idx; s_sum[t >> 6] = sum; }
+    __syncthreads();
+    if (t == 0) {
+      for (int w = 1; w < kBigThreads / 64; w++) {
+        if (s_peak[w] > peak || (s_peak[w] == peak && s_idx[w] < idx)) { peak = s_peak[w]; idx = s_idx[w]; }
+        sum += s_sum[w];
+      }
+      RowRec r;
+      r.peak = peak;
+      r.idx = idx;
+      r.sum = sum;
+      rows[(e * P + p) * (long)D + d] = r;
+    }
   }
 }
 
@@ -400,10 +583,15 @@ int twiddle_table(gacq_ctx* ctx, const float2** out) { return twiddle_cache(ctx,
 
 namespace gacq {
 
-bool lds_supported(int N) { return N == kLdsN; }
+bool lds_supported(int N) { return N == kLdsN || N == kBig; }
 
 int lds_prepare_spectra(gacq_ctx* ctx, const float2* natural, float2* perm, int nprn, int N) {
   if (!lds_supported(N)) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "LDS FFT engine: N=%d not supported", N);
+  if (N == kBig) {
+    hipLaunchKernelGGL(lds16k_permute_kernel, dim3((unsigned)nprn), dim3(kBigThreads), 0, ctx->stream, natural, perm);
+    GACQ_HIP(ctx, hipGetLastError());
+    return GACQ_OK;
+  }
   hipLaunchKernelGGL(lds_permute_kernel, dim3((unsigned)nprn), dim3(kBlock), 0, ctx->stream, natural, perm);
   GACQ_HIP(ctx, hipGetLastError());
   return GACQ_OK;
@@ -412,6 +600,16 @@ int lds_prepare_spectra(gacq_ctx* ctx, const float2* natural, float2* perm, int 
 int lds_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n, int N, const double* d_freq, int FD,
                 int B, const float2* tab, float2* X) {
   if (!lds_supported(N)) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "LDS FFT engine: N=%d not supported", N);
+  if (N == kBig) {
+    const float2* twn;
+    int rcb = twiddle_cache(ctx, "W16384_lo", kBig, 1024, &twn);
+    if (rcb != GACQ_OK) return rcb;
+    GACQ_HIP(ctx, hipFuncSetAttribute((const void*)lds16k_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes));
+    hipLaunchKernelGGL(lds16k_forward_kernel, dim3((unsigned)((long)nepoch * FD * B)), dim3(kBigThreads), kBigLdsBytes, ctx->stream, x,
+                       nsamp, X, d_freq, tab, twn, n, FD, B);
+    GACQ_HIP(ctx, hipGetLastError());
+    return GACQ_OK;
+  }
   const float2* tw;
   int rc = twiddle_table(ctx, &tw);
   if (rc != GACQ_OK) return rc;
@@ -424,6 +622,22 @@ int lds_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n,
 int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const int* d_items, const int* d_fset, int nepoch,
                   int nitems, int F, int D, int B, int N, RowRec* rows) {
   if (!lds_supported(N)) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "LDS FFT engine: N=%d not supported", N);
+  if (N == kBig) {
+    const float2* twn;
+    int rcb = twiddle_cache(ctx, "W16384_lo", kBig, 1024, &twn);
+    if (rcb != GACQ_OK) return rcb;
+    // one 1024-thread workgroup per CU: keep >= ~1024 workgroups, at most 8 items per group
+    const long rows_total = (long)nepoch * nitems * D;
+    int pch = (int)std::max<long>(1, std::min<long>(8, rows_total / 1024));
+    pch = std::min(pch, nitems);
+    const int nchunk = (nitems + pch - 1) / pch;
+    const long units8 = ((long)nepoch * D + 7) / 8;
+    GACQ_HIP(ctx, hipFuncSetAttribute((const void*)lds16k_correlate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes));
+    hipLaunchKernelGGL(lds16k_correlate_kernel, dim3((unsigned)(8 * units8 * nchunk)), dim3(kBigThreads), kBigLdsBytes, ctx->stream, X,
+                       spectra, d_items, d_fset, twn, rows, nepoch, nitems, F, D, B, pch, nchunk);
+    GACQ_HIP(ctx, hipGetLastError());
+    return GACQ_OK;
+  }
   const float2* tw;
   int rc = twiddle_table(ctx, &tw);
   if (rc != GACQ_OK) return rc;

@@ -93,7 +93,7 @@ int gacq_set_stream(gacq_ctx* ctx, void* hip_stream);
 /* Launch on the legacy default ("null") stream -- what torch.cuda.current_stream() is unless the caller
  * entered a stream context; needed so that work is ordered with collectives issued on that stream. */
 int gacq_use_null_stream(gacq_ctx* ctx);
-/* Engine selection: 0 = auto, 1 = rocFFT pipeline (any N), 2 = LDS-resident FFT kernels (N = 4096),
+/* Engine selection: 0 = auto, 1 = rocFFT pipeline (any N), 2 = LDS-resident FFT kernels (N = 4096, 16384),
  * 3 = split engine, outer radix 31/16/4 + rocFFT inner transforms (N = 61380, 30690, 65536, 16384),
  * 4 = split engine with the inner transforms on the LDS FFT kernels (N = 65536, 16384). */
 int gacq_set_engine(gacq_ctx* ctx, int engine);

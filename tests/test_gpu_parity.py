@@ -339,6 +339,22 @@ SPLIT_LDS_CASES = ["cfg3_e1b_subset", "cfg3_e1c_subset", "e1b_ms12", "cfg5_b1i_m
                    "gps_l1cd", "bds_b1cp", "gps_l2cm"]
 
 
+LDS16K_CASES = ["cfg5_b1i_ms10", "b2i_ms2", "cfg5_glonass_l1", "glonass_l2"]
+
+
+@pytest.mark.parametrize("cid", LDS16K_CASES)
+def test_single_workgroup_16384_engine_matches_reference_golden(engine, golden_cases, cid):
+    """N = 16384 through engine 2: the whole transform in one 1024-thread workgroup (4 x 4096 in LDS)."""
+    case = golden_cases[cid]
+    x = case_iq(case)
+    engine.set_engine(2)
+    try:
+        got = engine.search_all(case["script"], x, case["items"], case["doppler_search"], case["ms"])
+    finally:
+        engine.set_engine(0)
+    _assert_results(got, case["results"], case)
+
+
 @pytest.mark.parametrize("cid", SPLIT_LDS_CASES)
 @pytest.mark.parametrize("eng", [1, 3, 4])
 def test_split_engines_match_reference_golden_pow2(engine, golden_cases, cid, eng):
