@@ -113,6 +113,14 @@ int lds_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, c
 int pfa_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng, int B, int N, float* q_out, bool inner = true,
                        bool twiddle_only = false);
 
+// Table-NCO index of sample i: floor((0 + f*i) * 1024) mod 1024 with the two products rounded to fp64 exactly like numpy's
+// `idx = p + f*np.arange(n); np.floor(idx*NT)` (gnsstools/nco.py:7-9).  |f*i*1024| < 2^31 is checked on the host
+// (nco_range_ok), which lets the floor go through one f64->i32 conversion instead of the multi-instruction f64->i64 one.
+__device__ __forceinline__ int nco_index(double f, int i) {
+  return ((int)floor(__dmul_rn(__dmul_rn(f, (double)i), 1024.0))) & (kNcoTableSize - 1);
+}
+inline bool nco_range_ok(double max_abs_f, long span) { return max_abs_f * (double)span * 1024.0 < 2.0e9; }
+
 #define GACQ_HIP(ctx, call)                                                                         \
   do {                                                                                              \
     hipError_t e_ = (call);                                                                         \

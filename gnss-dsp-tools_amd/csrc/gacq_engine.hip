@@ -159,8 +159,8 @@ __global__ __launch_bounds__(kBlock) void mix_nco_kernel(const float2* __restric
     const int i0 = base + (j * kBlock + threadIdx.x) * 2;
     if (i0 + 1 < span) {
       const float4 s = *reinterpret_cast<const float4*>(src + i0);
-      const long k0 = (long)floor(__dmul_rn(__dmul_rn(f, (double)i0), 1024.0)) & (kNcoTableSize - 1);
-      const long k1 = (long)floor(__dmul_rn(__dmul_rn(f, (double)(i0 + 1)), 1024.0)) & (kNcoTableSize - 1);
+      const int k0 = nco_index(f, (int)i0);
+      const int k1 = nco_index(f, (int)(i0 + 1));
       const float2 w0 = s_tab[k0], w1 = s_tab[k1];
       float4 o;
       o.x = s.x * w0.x - s.y * w0.y;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void mix_nco_kernel(const float2* __restric
       *reinterpret_cast<float4*>(dst + i0) = o;
     } else if (i0 < span) {
       const float2 s = src[i0];
-      const long k0 = (long)floor(__dmul_rn(__dmul_rn(f, (double)i0), 1024.0)) & (kNcoTableSize - 1);
+      const int k0 = nco_index(f, (int)i0);
       const float2 w0 = s_tab[k0];
       dst[i0] = make_float2(s.x * w0.x - s.y * w0.y, s.x * w0.y + s.y * w0.x);
     }
@@ -576,6 +576,10 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
   Grid g = make_grid(ds, nitems, dopplers, nd, bias);
   const int F = g.F;
   int rc;
+  double max_f = 0.0;
+  for (double v : g.freq) max_f = std::max(max_f, std::fabs(v));
+  if (!nco_range_ok(max_f, N))
+    return set_error(ctx, GACQ_ERR_UNSUPPORTED, "NCO frequency %.3g cycles/sample x %d samples exceeds the 32-bit phase-index range", max_f, N);
   const void* before[3] = {ctx->freq.p, ctx->fset.p, ctx->items.p};
   if ((rc = ensure(ctx, ctx->freq, sizeof(double) * g.freq.size())) != GACQ_OK) return rc;
   if ((rc = ensure(ctx, ctx->fset, sizeof(int) * P)) != GACQ_OK) return rc;

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void lds_forward_kernel(const float2* __res
     const int i = t + 256 * j;
     v[j] = ld2(src + i);
     // table NCO, index in fp64 exactly as numpy: floor((0 + f*i)*1024) mod 1024   (gnsstools/nco.py:6-9)
-    const long k = (long)floor(__dmul_rn(__dmul_rn(f, (double)i), 1024.0)) & (kNcoTableSize - 1);
+    const int k = nco_index(f, (int)i);
     w[j] = ld2(nco_tab + k);
   }
   const v2 twa = ld2(tw + t), twb = ld2(tw + 16 * (t & 15));
@@ -227,19 +227,26 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_forward_kernel(const float
   for (int j = 0; j < kR; j++) {
     const int i = t + 1024 * j;
     v[j] = ld2(src + i);
-    const long k = (long)floor(__dmul_rn(__dmul_rn(f, (double)i), 1024.0)) & (kNcoTableSize - 1);   // gnsstools/nco.py:6-9
+    const int k = nco_index(f, (int)i);   // gnsstools/nco.py:6-9
     w[j] = ld2(nco_tab + k);
   }
   const v2 base = ld2(twn + t);
 #pragma unroll
   for (int j = 0; j < kR; j++) v[j] = cmul(v[j], w[j]);
   fft16k<false>(v, lds, twn, base);
+  // lane (ka, t'') holds X[(ka + 4 t'') + 1024 k2]: storing straight from here would write 16-byte pieces at a 64-byte stride
+  // (quarter cache lines).  One more pass through LDS puts lane t back on natural indices t + 1024 j, so every wave stores
+  // full 1 KiB runs of the lane-pair layout.
   const int lane = (t >> 8) + 4 * (t & 255);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kR; k++) lds[lane + 1024 * k] = v[rev16(k)];
+  __syncthreads();
   float2* dst = X + row * (long)kBig;
 #pragma unroll
   for (int jp = 0; jp < kR / 2; jp++) {
-    const v2 a = v[rev16(2 * jp)], c = v[rev16(2 * jp + 1)];
-    *reinterpret_cast<float4*>(dst + jp * 2048 + 2 * lane) = make_float4(a.x, -a.y, c.x, -c.y);
+    const v2 a = lds[t + 1024 * (2 * jp)], c = lds[t + 1024 * (2 * jp + 1)];
+    *reinterpret_cast<float4*>(dst + jp * 2048 + 2 * t) = make_float4(a.x, -a.y, c.x, -c.y);
   }
 }
 

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(kLcBlock) void longcode_mix_kernel(const float2* __
   const long g = (long)blockIdx.x * kLcBlock + threadIdx.x;
   if (g >= n * B) return;
   const long i = g % n;
-  const long k = (long)floor(__dmul_rn(__dmul_rn(f, (double)i), 1024.0)) & (kNcoTableSize - 1);
+  const int k = nco_index(f, (int)i);
   const float2 s = x[g], w = tab[k];
   xw[g] = make_float2(s.x * w.x - s.y * w.y, s.x * w.y + s.y * w.x);
 }
@@ -120,6 +120,7 @@ extern "C" int gacq_longcode_search(gacq_ctx* ctx, const float* x_iq, size_t nsa
   GACQ_HIP(ctx, hipMemcpyAsync(ctx->xstage.p, x_iq, sizeof(float2) * (size_t)total, hipMemcpyHostToDevice, st));
   GACQ_HIP(ctx, hipMemcpyAsync(d_phase, phase0, sizeof(double) * (size_t)K * blocks, hipMemcpyHostToDevice, st));
   const double f = -carrier_hz / fs;                                     // nco.nco(-doppler/fs,0,n)  (acquire-gps-l2cl.py:18)
+  if (!nco_range_ok(std::fabs(f), n)) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "gacq_longcode_search: NCO phase index out of range");
   hipLaunchKernelGGL(longcode_mix_kernel, dim3((unsigned)((total + kLcBlock - 1) / kLcBlock)), dim3(kLcBlock), 0, st,
                      (const float2*)ctx->xstage.p, (float2*)ctx->fe_a.p, (long)n, blocks, f, (const float2*)ctx->tab.p);
   GACQ_HIP(ctx, hipGetLastError());

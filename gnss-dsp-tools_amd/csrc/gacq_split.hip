@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kBlock) void split_outer_forward_kernel(const float
     v[n1] = v2{sf.x, sf.y};
     if (MIX) {
       // table NCO, index in fp64 exactly as numpy: floor((0 + f*i)*1024) mod 1024   (gnsstools/nco.py:6-9)
-      const long k = (long)floor(__dmul_rn(__dmul_rn(f, (double)i), 1024.0)) & (kNcoTableSize - 1);
+      const int k = nco_index(f, (int)i);
       const float2 wf = nco_tab[k];
       w[n1] = v2{wf.x, wf.y};
     }
