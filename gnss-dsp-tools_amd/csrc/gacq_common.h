@@ -67,7 +67,7 @@ struct gacq_sig {
   int nprn = 0;
   int N = 0;                 // FFT length: n or 2n
   float2* spectra = nullptr; // [nprn][N] code spectra C_p = fft(replica), complex64, natural order
-  float2* spectra_pfa = nullptr;   // same in the radix-31 engine's [k1][k2] order (only when pfa_supported(N))
+  float2* spectra_r31 = nullptr;   // same in the radix-31 engine's [k1][k2] order (only when split_supported(N))
   float2* spectra_split = nullptr; // split engine with LDS inner transforms: R lane-pair rows per item (N = R*4096)
   float2* spectra_lds = nullptr;   // same in the LDS engine's lane-pair layout (only when lds_supported(N))
 };
@@ -94,11 +94,11 @@ int lds_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n,
 int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const int* d_items, const int* d_fset,
                   int nepoch, int nitems, int F, int D, int B, int N, RowRec* rows);
 
-// radix-31 split engine (gacq_pfa31.hip): N = 31*M with M handled natively by rocFFT
-bool pfa_supported(int N);
+// split engines (gacq_split.hip): N = R*M, hand-written outer DFT-R, inner length-M transforms (rocFFT, Stockham LDS or the 4096 kernels)
+bool split_supported(int N);
 // outer DFT-31 (+NCO mix when mix) + twiddle, then the inner forward transforms; X in [k1][k2] order
 // inner == false: outer stage only (the caller runs the inner transforms itself)
-int pfa_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, long rows, int n, int N, const double* d_freq, int FD, int B,
+int split_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, long rows, int n, int N, const double* d_freq, int FD, int B,
                 const float2* tab, float2* X, bool mix, bool inner = true);
 int split_radix(int N);
 bool split_inner_fused_supported(int N);
@@ -110,7 +110,7 @@ int lds_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, c
                         long ng, int P, int F, int D, int B, int R, int N, float2* Z);
 // inner inverse transforms on Y (in place), then twiddle + inverse DFT-31 + |.|/N + sum over B + reduce -> rows[g0..g0+ng)
 // inner == false: Y already holds the twiddled inner inverse transforms (LDS inner path)
-int pfa_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng, int B, int N, float* q_out, bool inner = true,
+int split_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng, int B, int N, float* q_out, bool inner = true,
                        bool twiddle_only = false);
 
 // Table-NCO index of sample i: floor((0 + f*i) * 1024) mod 1024 with the two products rounded to fp64 exactly like numpy's

@@ -449,18 +449,18 @@ static int build_signal(gacq_ctx* ctx, const gacq_sigdesc* desc, const std::vect
   if (hipMemcpyAsync(s->spectra, host.data(), bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
     rc = set_error(ctx, GACQ_ERR_HIP, "replica upload failed");
   if (rc == GACQ_OK) rc = fft_exec(ctx, s->N, nprn, false, s->spectra);     // c = fft.fft(c)   acquire-gps-l1.py:24
-  if (rc == GACQ_OK && pfa_supported(s->N)) {
+  if (rc == GACQ_OK && split_supported(s->N)) {
     // the radix-31 engine keeps spectra in [k1][k2] order: transform the (still natural-order) replica with it
     float2* tmp = nullptr;
-    if (hipMalloc((void**)&s->spectra_pfa, bytes) != hipSuccess || hipMalloc((void**)&tmp, bytes) != hipSuccess)
+    if (hipMalloc((void**)&s->spectra_r31, bytes) != hipSuccess || hipMalloc((void**)&tmp, bytes) != hipSuccess)
       rc = set_error(ctx, GACQ_ERR_HIP, "hipMalloc for radix-31 spectra failed");
     if (rc == GACQ_OK && hipMemcpyAsync(tmp, host.data(), bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
       rc = set_error(ctx, GACQ_ERR_HIP, "replica upload failed");
-    if (rc == GACQ_OK) rc = pfa_forward(ctx, tmp, 0, nprn, s->N, s->N, nullptr, 1, 1, nullptr, s->spectra_pfa, false);
+    if (rc == GACQ_OK) rc = split_forward(ctx, tmp, 0, nprn, s->N, s->N, nullptr, 1, 1, nullptr, s->spectra_r31, false);
     if (rc == GACQ_OK && s->N / split_radix(s->N) == 4096) {
       // split engine with LDS inner transforms (N = R*4096): code spectra as R lane-pair rows per item
       if (hipMalloc((void**)&s->spectra_split, bytes) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "hipMalloc for split/LDS spectra failed");
-      if (rc == GACQ_OK) rc = pfa_forward(ctx, tmp, 0, nprn, s->N, s->N, nullptr, 1, 1, nullptr, s->spectra_split, false, false);
+      if (rc == GACQ_OK) rc = split_forward(ctx, tmp, 0, nprn, s->N, s->N, nullptr, 1, 1, nullptr, s->spectra_split, false, false);
       if (rc == GACQ_OK) rc = lds_inner_forward(ctx, s->spectra_split, (long)nprn * split_radix(s->N), false);
     }
     if (rc == GACQ_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "split-engine code spectrum failed");
@@ -471,7 +471,7 @@ static int build_signal(gacq_ctx* ctx, const gacq_sigdesc* desc, const std::vect
     else rc = lds_prepare_spectra(ctx, s->spectra, s->spectra_lds, nprn, s->N);
   }
   if (rc == GACQ_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "code spectrum FFT failed");
-  if (rc != GACQ_OK) { (void)hipFree(s->spectra); if (s->spectra_lds) (void)hipFree(s->spectra_lds); if (s->spectra_pfa) (void)hipFree(s->spectra_pfa); if (s->spectra_split) (void)hipFree(s->spectra_split); delete s; return rc; }
+  if (rc != GACQ_OK) { (void)hipFree(s->spectra); if (s->spectra_lds) (void)hipFree(s->spectra_lds); if (s->spectra_r31) (void)hipFree(s->spectra_r31); if (s->spectra_split) (void)hipFree(s->spectra_split); delete s; return rc; }
   *out = s;
   return GACQ_OK;
 }
@@ -516,7 +516,7 @@ void gacq_signal_destroy(gacq_sig* sig) {
   (void)hipStreamSynchronize(sig->ctx->stream);
   if (sig->spectra) (void)hipFree(sig->spectra);
   if (sig->spectra_lds) (void)hipFree(sig->spectra_lds);
-  if (sig->spectra_pfa) (void)hipFree(sig->spectra_pfa);
+  if (sig->spectra_r31) (void)hipFree(sig->spectra_r31);
   if (sig->spectra_split) (void)hipFree(sig->spectra_split);
   delete sig;
 }
@@ -605,8 +605,8 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
   const bool use_split_lds = (ctx->engine == 4) || (ctx->engine == 0 && split_lds_ok);
   if (ctx->engine == 4 && !split_lds_ok)
     return set_error(ctx, GACQ_ERR_UNSUPPORTED, "engine 4 (split with LDS inner transforms) does not support N=%d", N);
-  const bool use_pfa = use_split_lds || (ctx->engine == 3) || (ctx->engine == 0 && pfa_supported(N));
-  if (ctx->engine == 3 && !pfa_supported(N))
+  const bool use_split = use_split_lds || (ctx->engine == 3) || (ctx->engine == 0 && split_supported(N));
+  if (ctx->engine == 3 && !split_supported(N))
     return set_error(ctx, GACQ_ERR_UNSUPPORTED, "engine 3 (split with rocFFT inner transforms) does not support N=%d", N);
 
   // epochs per pass so that the forward-spectra buffer respects the workspace limit
@@ -632,9 +632,9 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
       stage_end(ctx);
       if (rc != GACQ_OK) return rc;
     } else {
-      if (use_pfa) {
+      if (use_split) {
         stage_begin(ctx, 0);
-        rc = pfa_forward(ctx, xe, nsamp, rows_x, n, N, (const double*)ctx->freq.p, F * D, B, (const float2*)ctx->tab.p, X, true,
+        rc = split_forward(ctx, xe, nsamp, rows_x, n, N, (const double*)ctx->freq.p, F * D, B, (const float2*)ctx->tab.p, X, true,
                          !use_split_lds);
         if (rc == GACQ_OK && use_split_lds) rc = lds_inner_forward(ctx, X, rows_x * R, true);
         stage_end(ctx);
@@ -665,32 +665,32 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
           stage_end(ctx);
           if (rc != GACQ_OK) return rc;
           stage_begin(ctx, 4);
-          rc = pfa_inverse_reduce(ctx, Y, rows, g0, ng, B, N, d_qrow, false);   // outer inverse DFT + |.| + reduce
+          rc = split_inverse_reduce(ctx, Y, rows, g0, ng, B, N, d_qrow, false);   // outer inverse DFT + |.| + reduce
           stage_end(ctx);
           if (rc != GACQ_OK) return rc;
           continue;
         }
-        if (use_pfa && split_inner_fused_supported(N) && !getenv("GACQ_NO_FUSED_INNER")) {
+        if (use_split && split_inner_fused_supported(N) && !getenv("GACQ_NO_FUSED_INNER")) {
           stage_begin(ctx, 6);
-          rc = split_inner_correlate(ctx, X, sig->spectra_pfa, (const int*)ctx->items.p, (const int*)ctx->fset.p, g0, ng, P, F, D, B, N,
+          rc = split_inner_correlate(ctx, X, sig->spectra_r31, (const int*)ctx->items.p, (const int*)ctx->fset.p, g0, ng, P, F, D, B, N,
                                      Y);                                        // K2 + inner inverse FFTs (Stockham in LDS)
           stage_end(ctx);
           if (rc != GACQ_OK) return rc;
           stage_begin(ctx, 4);
-          rc = pfa_inverse_reduce(ctx, Y, rows, g0, ng, B, N, d_qrow, false, true);   // twiddle + outer DFT-31 + |.| + reduce
+          rc = split_inverse_reduce(ctx, Y, rows, g0, ng, B, N, d_qrow, false, true);   // twiddle + outer DFT-31 + |.| + reduce
           stage_end(ctx);
           if (rc != GACQ_OK) return rc;
           continue;
         }
         stage_begin(ctx, 2);
         hipLaunchKernelGGL(conj_mul_kernel, dim3((unsigned)(ng * B * chunksN)), dim3(kBlock), 0, st, X,
-                           use_pfa ? sig->spectra_pfa : sig->spectra, Y,
+                           use_split ? sig->spectra_r31 : sig->spectra, Y,
                            (const int*)ctx->items.p, (const int*)ctx->fset.p, g0, P, F, D, B, N, chunksN);
         stage_end(ctx);
         GACQ_HIP(ctx, hipGetLastError());
-        if (use_pfa) {
+        if (use_split) {
           stage_begin(ctx, 3);
-          rc = pfa_inverse_reduce(ctx, Y, rows, g0, ng, B, N, d_qrow);      // inner inverse FFTs + outer DFT-31 + |.| + reduce
+          rc = split_inverse_reduce(ctx, Y, rows, g0, ng, B, N, d_qrow);      // inner inverse FFTs + outer DFT-31 + |.| + reduce
           stage_end(ctx);
           if (rc != GACQ_OK) return rc;
         } else {

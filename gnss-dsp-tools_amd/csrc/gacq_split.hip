@@ -319,9 +319,9 @@ int split_radix(int N) {
   return 0;
 }
 
-bool pfa_supported(int N) { return split_radix(N) != 0; }
+bool split_supported(int N) { return split_radix(N) != 0; }
 
-int pfa_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, long rows, int n, int N, const double* d_freq, int FD, int B,
+int split_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, long rows, int n, int N, const double* d_freq, int FD, int B,
                 const float2* tab, float2* X, bool mix, bool inner) {
   const int R = split_radix(N);
   if (!R) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "split engine: N=%d not supported", N);
@@ -341,7 +341,7 @@ int pfa_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, long rows, int n, 
   return fft_exec(ctx, M, rows * R, false, X);            // inner transforms, rows contiguous
 }
 
-int pfa_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng, int B, int N, float* q_out, bool inner, bool twiddle_only) {
+int split_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng, int B, int N, float* q_out, bool inner, bool twiddle_only) {
   const int R = split_radix(N);
   if (!R) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "split engine: N=%d not supported", N);
   const int M = N / R;
