@@ -63,6 +63,36 @@ __device__ __forceinline__ v2 mul_hi_neg(v2 x, v2 cs) {
   return r;
 }
 
+// Wave64 reductions on DPP (no LDS, no ds_bpermute): quad_perm xor-1, xor-2, row_half_mirror, row_mirror leave every lane
+// of a 16-lane row with the row's result (4 one-cycle-issue ops), the four rows are read with v_readlane and combined on the
+// scalar unit.  Results are wave-uniform.  s_nop 1 covers the "VALU write -> DPP read" wait states hipcc cannot see in asm.
+#define GACQ_DPP_REDUCE(OP)                                                                                   \
+  asm volatile("s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"           \
+               "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"           \
+               "s_nop 1\n\t" OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"               \
+               "s_nop 1\n\t" OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"                    \
+               "s_nop 1"                                                                                      \
+               : "+v"(x))
+__device__ __forceinline__ unsigned wave_max_u32(unsigned x) {
+  GACQ_DPP_REDUCE("v_max_u32_dpp");
+  const unsigned a = __builtin_amdgcn_readlane(x, 0), b = __builtin_amdgcn_readlane(x, 16);
+  const unsigned c = __builtin_amdgcn_readlane(x, 32), d = __builtin_amdgcn_readlane(x, 48);
+  return max(max(a, b), max(c, d));
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned x) {
+  GACQ_DPP_REDUCE("v_min_u32_dpp");
+  const unsigned a = __builtin_amdgcn_readlane(x, 0), b = __builtin_amdgcn_readlane(x, 16);
+  const unsigned c = __builtin_amdgcn_readlane(x, 32), d = __builtin_amdgcn_readlane(x, 48);
+  return min(min(a, b), min(c, d));
+}
+__device__ __forceinline__ float wave_add_f32(float v) {
+  unsigned x = __builtin_bit_cast(unsigned, v);
+  GACQ_DPP_REDUCE("v_add_f32_dpp");
+  const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 0)), b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 16));
+  const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 32)), d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 48));
+  return (a + b) + (c + d);
+}
+
 // 4-point DFT, forward W4 = -i (INV: +i).  ROTC: input c still needs its -/+i factor (folded into the adds).
 template <bool INV, bool ROTC> __device__ __forceinline__ void dft4(v2& a, v2& b, v2& c, v2& d) {
   v2 s0, d0;

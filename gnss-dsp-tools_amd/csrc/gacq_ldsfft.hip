@@ -311,20 +311,18 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_correlate_kernel(const flo
     }
     float peak = q[0];
     int idx = lag0;
-    double sum = (double)q[0];
+    float sum_f = q[0];
 #pragma unroll
     for (int k = 1; k < kR; k++) {
       if (q[k] > peak) { peak = q[k]; idx = lag0 + 1024 * k; }
-      sum += (double)q[k];
+      sum_f += q[k];
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const float op = __shfl_down(peak, off);
-      const int oi = __shfl_down(idx, off);
-      const double os = __shfl_down(sum, off);
-      if (op > peak || (op == peak && oi < idx)) { peak = op; idx = oi; }
-      sum += os;
-    }
+    // wave64 reduce on DPP (see lds_correlate_kernel): non-negative floats order like their bit patterns, ties -> smallest lag
+    const unsigned pbits = __builtin_bit_cast(unsigned, peak);
+    const unsigned wmax = wave_max_u32(pbits);
+    idx = (int)wave_min_u32(pbits == wmax ? (unsigned)idx : 0xffffffffu);
+    peak = __builtin_bit_cast(float, wmax);
+    double sum = (double)wave_add_f32(sum_f);
     if ((t & 63) == 0) { s_peak[t >> 6] = peak; s_idx[t >> 6] = idx; s_sum[t >> 6] = sum; }
     __syncthreads();
     if (t == 0) {
@@ -507,18 +505,21 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float
       if (PRETW) fft4096<true, true>(v, lds, wa, wb, reinterpret_cast<const v2(*)[15]>(pwa), reinterpret_cast<const v2(*)[15]>(pwb));
       else fft4096<true>(v, lds, wa, wb);
       if (B1) {
-        // (max, first argmax, sum) straight from the transform output; lane holds lags t + 256 k
+        // (max, first argmax, sum) straight from the transform output; lane holds lags t + 256 k.  The 1/N of ifft is a
+        // power of two: it is applied once to the reduced values below instead of to all 16 magnitudes.
         const v2 r0 = v[rev16(0)];
-        peak = __builtin_amdgcn_sqrtf(r0.x * r0.x + r0.y * r0.y) * inv_n;      // np.absolute(ifft(...)), 1/N folded in
+        peak = __builtin_amdgcn_sqrtf(r0.x * r0.x + r0.y * r0.y);              // np.absolute(ifft(...)) * N
         idx = t;
         sum_f = peak;
 #pragma unroll
         for (int k = 1; k < kR; k++) {
           const v2 r = v[rev16(k)];
-          const float m = __builtin_amdgcn_sqrtf(r.x * r.x + r.y * r.y) * inv_n;
+          const float m = __builtin_amdgcn_sqrtf(r.x * r.x + r.y * r.y);
           if (m > peak) { peak = m; idx = t + 256 * k; }
           sum_f += m;
         }
+        peak *= inv_n;
+        sum_f *= inv_n;
       } else {
 #pragma unroll
         for (int k = 0; k < kR; k++) {
@@ -527,38 +528,36 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float
         }
       }
     }
-    double sum;
-    if (B1) {
-      sum = (double)sum_f;                     // 16 addends of equal scale: fp32 partial, fp64 from here on
-    } else {
+    if (!B1) {
       peak = q[0];
       idx = t;
-      sum = (double)q[0];
+      sum_f = q[0];
 #pragma unroll
       for (int k = 1; k < kR; k++) {
         if (q[k] > peak) { peak = q[k]; idx = t + 256 * k; }
-        sum += (double)q[k];
+        sum_f += q[k];
       }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const float op = __shfl_down(peak, off);
-      const int oi = __shfl_down(idx, off);
-      const double os = __shfl_down(sum, off);
-      if (op > peak || (op == peak && oi < idx)) { peak = op; idx = oi; }
-      sum += os;
-    }
-    if ((t & 63) == 0) { s_peak[t >> 6] = peak; s_idx[t >> 6] = idx; s_sum[t >> 6] = sum; }
+    // wave64 reduce on DPP: magnitudes are >= 0, so their bit patterns order like unsigned integers; ties go to the
+    // smallest lag (np.argmax returns the first maximum)
+    const unsigned pbits = __builtin_bit_cast(unsigned, peak);
+    const unsigned wmax = wave_max_u32(pbits);
+    const unsigned widx = wave_min_u32(pbits == wmax ? (unsigned)idx : 0xffffffffu);
+    const float wsum = wave_add_f32(sum_f);
+    if ((t & 63) == 0) { s_peak[t >> 6] = __builtin_bit_cast(float, wmax); s_idx[t >> 6] = (int)widx; s_sum[t >> 6] = (double)wsum; }
     __syncthreads();   // also orders this item's exchange-2 reads before the next item's exchange-1 writes
     if (t == 0) {
+      float bp = s_peak[0];
+      int bi = s_idx[0];
+      double bs = s_sum[0];
       for (int w = 1; w < kBlock / 64; w++) {
-        if (s_peak[w] > peak || (s_peak[w] == peak && s_idx[w] < idx)) { peak = s_peak[w]; idx = s_idx[w]; }
-        sum += s_sum[w];
+        if (s_peak[w] > bp || (s_peak[w] == bp && s_idx[w] < bi)) { bp = s_peak[w]; bi = s_idx[w]; }
+        bs += s_sum[w];
       }
       RowRec r;
-      r.peak = peak;
-      r.idx = idx;
-      r.sum = sum;
+      r.peak = bp;
+      r.idx = bi;
+      r.sum = bs;
       rows[(e * P + p) * (long)D + d] = r;
     }
   }
