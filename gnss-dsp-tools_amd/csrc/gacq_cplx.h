@@ -22,17 +22,23 @@ __device__ __forceinline__ v2 sub_i(v2 a, v2 b) {
   return r;
 }
 // a*b: t = (-a.im*b.im, a.im*b.re); r = (a.re*b.re + t.lo, a.re*b.im + t.hi)
+// (one asm statement for both instructions: hipcc pads an s_nop between adjacent asm statements; the RAW dependency on t
+// is interlocked by the hardware like any VALU->VALU dependency)
 __device__ __forceinline__ v2 cmul(v2 a, v2 b) {
   v2 t, r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]" : "=v"(t) : "v"(a), "v"(b));
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+  asm("v_pk_mul_f32 %0, %2, %3 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]\n\t"
+      "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]"
+      : "=&v"(t), "=v"(r)
+      : "v"(a), "v"(b));
   return r;
 }
 // a*w with w a compile-time constant held in an SGPR pair (one constant-bus operand per instruction)
 __device__ __forceinline__ v2 cmul_k(v2 a, v2 w) {
   v2 t, r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]" : "=v"(t) : "v"(a), "s"(w));
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "s"(w), "v"(t));
+  asm("v_pk_mul_f32 %0, %2, %3 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]\n\t"
+      "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]"
+      : "=&v"(t), "=v"(r)
+      : "v"(a), "s"(w));
   return r;
 }
 // real constant x complex value, constant pair cs = (c, s) in SGPRs, one half broadcast to both lanes:

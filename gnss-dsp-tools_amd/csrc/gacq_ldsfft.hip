@@ -509,15 +509,16 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float
         // power of two: it is applied once to the reduced values below instead of to all 16 magnitudes.
         const v2 r0 = v[rev16(0)];
         peak = __builtin_amdgcn_sqrtf(r0.x * r0.x + r0.y * r0.y);              // np.absolute(ifft(...)) * N
-        idx = t;
+        int bestk = 0;
         sum_f = peak;
 #pragma unroll
         for (int k = 1; k < kR; k++) {
           const v2 r = v[rev16(k)];
           const float m = __builtin_amdgcn_sqrtf(r.x * r.x + r.y * r.y);
-          if (m > peak) { peak = m; idx = t + 256 * k; }
+          if (m > peak) { peak = m; bestk = k; }                                // strict '>' keeps the first maximum
           sum_f += m;
         }
+        idx = t + 256 * bestk;
         peak *= inv_n;
         sum_f *= inv_n;
       } else {
