@@ -229,7 +229,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "complex64 (f32)",
+            "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "GPS L1 C/A all 32 PRNs, 1 ms coherent (B=1), fs=4.096 MS/s, n=N=4096, "
                                    "Doppler arange(-5000,5000,250)=40 bins; %d epochs/step/GPU batched, inputs resident in HBM" % args.epochs,

@@ -43,9 +43,10 @@ def main():
     ap.add_argument("--engine", type=int, default=0)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--stages", action="store_true", help="also print per-stage HIP-event times")
+    ap.add_argument("--ws", type=int, default=0, help="workspace limit in MiB (0 = library default)")
     ap.add_argument("cases", nargs="*")
     args = ap.parse_args()
-    eng = acquire.Engine(0, engine=args.engine)
+    eng = acquire.Engine(0, engine=args.engine, workspace_bytes=(args.ws << 20) if args.ws else None)
     eng.use_torch_stream()
     for cid in (args.cases or list(CASES)):
         name, items, ds, ms, E = CASES[cid]
