@@ -113,6 +113,23 @@ int lds_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, c
 int split_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng, int B, int N, float* q_out, bool inner = true,
                        bool twiddle_only = false);
 
+// Makes ctx's device current for the duration of an entry point and restores the caller's device afterwards
+// (a library must not leave a different current device behind in a multi-GPU process).
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) ok = (hipSetDevice(device) == hipSuccess); else prev = -1;
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define GACQ_DEVICE(ctx)                                                                                  \
+  gacq::DeviceGuard device_guard_((ctx)->device);                                                         \
+  if (!device_guard_.ok) return gacq::set_error((ctx), GACQ_ERR_HIP, "hipSetDevice(%d) failed", (ctx)->device)
+
 // Table-NCO index of sample i: floor((0 + f*i) * 1024) mod 1024 with the two products rounded to fp64 exactly like numpy's
 // `idx = p + f*np.arange(n); np.floor(idx*NT)` (gnsstools/nco.py:7-9).  |f*i*1024| < 2^31 is checked on the host
 // (nco_range_ok), which lets the floor go through one f64->i32 conversion instead of the multi-instruction f64->i64 one.

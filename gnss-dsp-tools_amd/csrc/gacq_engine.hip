@@ -20,7 +20,7 @@
 using namespace gacq;
 
 namespace {
-std::string g_last_error;
+thread_local std::string g_last_error;     // last error of calls made without a ctx, per calling thread
 std::once_flag g_rocfft_once;
 const char* kStageNames[GACQ_NSTAGES] = {"mix_nco", "rocfft_forward", "conj_mul", "rocfft_inverse",
                                          "mag_peak", "best_doppler", "lds_correlate"};
@@ -321,7 +321,8 @@ int gacq_create(int device_id, gacq_ctx** out) {
   std::call_once(g_rocfft_once, [] { rocfft_setup(); });
   gacq_ctx* ctx = new gacq_ctx();
   ctx->device = device_id;
-  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+  DeviceGuard device_guard_(device_id);
+  if (!device_guard_.ok || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
     return set_error(nullptr, GACQ_ERR_HIP, "gacq_create: cannot create stream on device %d", device_id);
   }
@@ -342,7 +343,7 @@ int gacq_create(int device_id, gacq_ctx** out) {
 
 void gacq_destroy(gacq_ctx* ctx) {
   if (!ctx) return;
-  (void)hipSetDevice(ctx->device);
+  DeviceGuard device_guard_(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (auto& kv : ctx->plans) {
     if (kv.second.info) rocfft_execution_info_destroy(kv.second.info);
@@ -430,7 +431,7 @@ static int validate_desc(gacq_ctx* ctx, const gacq_sigdesc* d) {
 }
 
 static int build_signal(gacq_ctx* ctx, const gacq_sigdesc* desc, const std::vector<float>& replicas, int nprn, gacq_sig** out) {
-  GACQ_HIP(ctx, hipSetDevice(ctx->device));
+  GACQ_DEVICE(ctx);
   gacq_sig* s = new gacq_sig();
   s->ctx = ctx;
   s->desc = *desc;
@@ -512,7 +513,7 @@ int gacq_signal_create_chips(gacq_ctx* ctx, const gacq_sigdesc* desc, const uint
 
 void gacq_signal_destroy(gacq_sig* sig) {
   if (!sig) return;
-  (void)hipSetDevice(sig->ctx->device);
+  DeviceGuard device_guard_(sig->ctx->device);
   (void)hipStreamSynchronize(sig->ctx->stream);
   if (sig->spectra) (void)hipFree(sig->spectra);
   if (sig->spectra_lds) (void)hipFree(sig->spectra_lds);
@@ -526,7 +527,7 @@ int gacq_signal_fft_length(const gacq_sig* sig) { return sig ? sig->N : GACQ_ERR
 int gacq_signal_spectrum(gacq_sig* sig, int item, float* out_iq) {
   if (!sig || !out_iq || item < 0 || item >= sig->nprn) return set_error(sig ? sig->ctx : nullptr, GACQ_ERR_BAD_ARG, "gacq_signal_spectrum: bad argument");
   gacq_ctx* ctx = sig->ctx;
-  GACQ_HIP(ctx, hipSetDevice(ctx->device));
+  GACQ_DEVICE(ctx);
   GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   GACQ_HIP(ctx, hipMemcpy(out_iq, sig->spectra + (size_t)item * sig->N, sizeof(float2) * sig->N, hipMemcpyDeviceToHost));
   return GACQ_OK;
@@ -743,7 +744,7 @@ int gacq_search_batch_dev(gacq_sig* sig, const void* d_x, size_t nsamp, int nepo
   int rc = check_search_args(sig, d_x, nsamp, nepoch, items, nitems, dopplers, nd, blocks, d_out);
   if (rc != GACQ_OK) return rc;
   gacq_ctx* ctx = sig->ctx;
-  GACQ_HIP(ctx, hipSetDevice(ctx->device));
+  GACQ_DEVICE(ctx);
   if (nd == 0 || blocks == 0) {
     // empty Doppler grid -> the reference returns its initial (0,0,0) (acquire-gps-l1.py:25,40);
     // zero blocks -> q == 0 everywhere, nothing beats metric 0 either (raw) / NaN never wins (normalised)
@@ -774,7 +775,7 @@ __global__ void merge_peaks_kernel(const gacq_peak* __restrict__ peaks, gacq_pea
 int gacq_merge_peaks_dev(gacq_ctx* ctx, const void* d_peaks, int nshard, const int* shard_d0, long n, void* d_out) {
   if (!ctx || !d_peaks || !d_out || !shard_d0 || nshard <= 0 || nshard > 4096 || n <= 0)
     return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_merge_peaks_dev: bad argument");
-  GACQ_HIP(ctx, hipSetDevice(ctx->device));
+  GACQ_DEVICE(ctx);
   const void* d0_before = ctx->d0.p;
   int rc = ensure(ctx, ctx->d0, sizeof(int) * 4096);
   if (rc != GACQ_OK) return rc;
@@ -824,7 +825,7 @@ int gacq_search(gacq_sig* sig, const float* x_iq, size_t nsamp, const int* items
   int rc = check_search_args(sig, x_iq, nsamp, 1, items, nitems, dopplers, nd, blocks, out);
   if (rc != GACQ_OK) return rc;
   gacq_ctx* ctx = sig->ctx;
-  GACQ_HIP(ctx, hipSetDevice(ctx->device));
+  GACQ_DEVICE(ctx);
   const size_t need = (size_t)(blocks + (sig->desc.pad ? 1 : 0)) * sig->desc.n;
   const size_t take = std::max<size_t>(need, 1);
   if ((rc = ensure(ctx, ctx->xstage, sizeof(float2) * take)) != GACQ_OK) return rc;
@@ -845,7 +846,7 @@ int gacq_debug_row(gacq_sig* sig, const float* x_iq, size_t nsamp, int item, dou
   if (rc != GACQ_OK) return rc;
   if (!q_out || blocks <= 0) return set_error(sig->ctx, GACQ_ERR_BAD_ARG, "gacq_debug_row: bad argument");
   gacq_ctx* ctx = sig->ctx;
-  GACQ_HIP(ctx, hipSetDevice(ctx->device));
+  GACQ_DEVICE(ctx);
   const size_t need = (size_t)(blocks + (sig->desc.pad ? 1 : 0)) * sig->desc.n;
   if ((rc = ensure(ctx, ctx->xstage, sizeof(float2) * need)) != GACQ_OK) return rc;
   if ((rc = ensure(ctx, ctx->out_peaks, sizeof(gacq_peak))) != GACQ_OK) return rc;

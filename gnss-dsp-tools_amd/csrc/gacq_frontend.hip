@@ -155,7 +155,7 @@ int gacq_frontend_dev(gacq_ctx* ctx, const void* d_iq_int8, size_t nsamp_in, dou
   const int p = 3 * ntaps;                              // filtfilt default padlen = 3*max(len(a), len(b))
   if (nsamp_in <= (size_t)p)
     return set_error(ctx, GACQ_ERR_SHORT_INPUT, "gacq_frontend_dev: %zu input samples, filtfilt needs more than %d", nsamp_in, p);
-  GACQ_HIP(ctx, hipSetDevice(ctx->device));
+  GACQ_DEVICE(ctx);
   hipStream_t st = ctx->stream;
   const long n = (long)nsamp_in, L = n + 2L * p;
   int rc;

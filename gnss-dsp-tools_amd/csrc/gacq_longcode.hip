@@ -100,7 +100,7 @@ extern "C" int gacq_longcode_search(gacq_ctx* ctx, const float* x_iq, size_t nsa
   if (blocks == 0) { memset(q_out, 0, sizeof(double) * K); return GACQ_OK; }
   if (nsamp < (size_t)blocks * n)
     return set_error(ctx, GACQ_ERR_SHORT_INPUT, "gacq_longcode_search: %zu samples given, %zu needed", nsamp, (size_t)blocks * n);
-  GACQ_HIP(ctx, hipSetDevice(ctx->device));
+  GACQ_DEVICE(ctx);
   hipStream_t st = ctx->stream;
   const uint8_t* d_chips;
   long L;
