@@ -47,17 +47,26 @@ def doppler_grid(doppler_search):
 class AcqSignal:
     """Code spectra of one signal for a fixed item list, resident on the device."""
 
-    def __init__(self, engine, sig, prns):
+    def __init__(self, engine, sig, prns, chips=None):
+        """chips: optional uint8 array [len(prns), code_length] of {0,1} chips supplied by the caller
+        (gacq_signal_create_chips) instead of the built-in generators."""
         self.engine = engine
         self.sig = sig
         self.prns = list(prns)
         L = nat.check(nat.lib.gacq_code_length(sig.code.encode()))
         self.code_length = L
         self.desc = nat.SigDesc(L, sig.n, int(sig.pad), int(sig.boc), int(sig.normalised), int(sig.fold), sig.fs)
-        arr = (ctypes.c_int * len(self.prns))(*self.prns)
         h = ctypes.c_void_p()
-        nat.check(nat.lib.gacq_signal_create(engine._ctx, ctypes.byref(self.desc), sig.code.encode(), arr,
-                                             len(self.prns), ctypes.byref(h)), engine._ctx)
+        if chips is None:
+            arr = (ctypes.c_int * len(self.prns))(*self.prns)
+            nat.check(nat.lib.gacq_signal_create(engine._ctx, ctypes.byref(self.desc), sig.code.encode(), arr,
+                                                 len(self.prns), ctypes.byref(h)), engine._ctx)
+        else:
+            c = np.ascontiguousarray(chips, dtype=np.uint8)
+            if c.shape != (len(self.prns), L):
+                raise ValueError("chips must have shape (%d, %d)" % (len(self.prns), L))
+            nat.check(nat.lib.gacq_signal_create_chips(engine._ctx, ctypes.byref(self.desc), c.ctypes.data_as(nat.c_uint8_p),
+                                                       len(self.prns), ctypes.byref(h)), engine._ctx)
         self._h = h
         self._index = {p: i for i, p in enumerate(self.prns)}
 
@@ -142,10 +151,16 @@ class Engine:
             pass
 
     # -- signals -----------------------------------------------------------------------------
-    def signal(self, name, prns):
+    def signal(self, name, prns, chips=None):
+        """Device-resident code spectra for `prns` (cached).  With `chips` the caller's own {0,1} chip rows are used and the
+        entry replaces any cached one for the same (signal, prns)."""
         sig = _signals.get(name) if isinstance(name, str) else name
         key = (sig.name, tuple(prns))
-        if key not in self._signals:
+        if chips is not None:
+            if key in self._signals:
+                self._signals.pop(key).close()
+            self._signals[key] = AcqSignal(self, sig, prns, chips)
+        elif key not in self._signals:
             self._signals[key] = AcqSignal(self, sig, prns)
         return self._signals[key]
 

@@ -449,3 +449,60 @@ def test_multi_constellation_jobs_single_rank(engine):
         got = sh.results(name, items, m, acquire.doppler_grid(ds))[0]
         assert got == w, name
     engine.set_stream(None)
+
+
+def test_caller_supplied_chips_equal_builtin_generators():
+    """gacq_signal_create_chips: same spectra / results as the built-in generators; a wrong chip flips the result."""
+    from gnss_dsp_tools_amd import acquire, codes, signals, synth
+    sig = signals.get("galileo-e1b")               # BOC + padded: the chips path must apply both itself
+    prns = [5, 24]
+    x = synth.make_iq(sig, 1, 4321, [(5, 0.4, 1537.0, 1201)])
+    ds = [1000.0, 2000.0, 125.0]
+    a = acquire.Engine(0)
+    b = acquire.Engine(0)
+    try:
+        want = a.search_all(sig, x, prns, ds, 8)
+        rows = np.stack([codes.chips(sig.code, p) for p in prns])
+        b.signal(sig, prns, chips=rows)
+        assert b.search_all(sig, x, prns, ds, 8) == want
+        np.testing.assert_array_equal(a.signal(sig, prns).spectrum(5), b.signal(sig, prns).spectrum(5))
+        bad = rows.copy()
+        bad[0] ^= 1                                 # inverted code: same magnitude spectrum -> same peak location, opposite sign is invisible
+        b.signal(sig, prns, chips=bad)
+        assert b.search_all(sig, x, prns, ds, 8)[0][1] == want[0][1]
+        bad[0, ::2] ^= 1                            # scrambled code: the satellite is no longer found at its delay
+        b.signal(sig, prns, chips=bad)
+        assert b.search_all(sig, x, prns, ds, 8)[0][1] != want[0][1]
+        with pytest.raises(ValueError):
+            b.signal(sig, prns, chips=rows[:, :100])
+    finally:
+        a.close()
+        b.close()
+
+
+def test_epoch_chunking_with_small_workspace():
+    """Several epochs with a workspace smaller than one epoch's forward spectra: the epoch loop must chunk correctly."""
+    import torch
+    from gnss_dsp_tools_amd import acquire, signals, synth
+    sig = signals.get("gps-l1")
+    items = list(range(1, 9))
+    dop = acquire.doppler_grid([-2500.0, 2500.0, 250.0])
+    xs = synth.make_epochs(sig, 2, 1717, synth.default_sats(items), 5, nsamp=2 * 4096)
+    xd = torch.from_numpy(xs).cuda()
+    big = acquire.Engine(0)
+    small = acquire.Engine(0, workspace_bytes=1 << 20)
+    try:
+        for eng_id in (0, 1):
+            big.set_engine(eng_id)
+            small.set_engine(eng_id)
+            a = big.search_batch_dev(sig, xd, items, dop, 2)
+            b = small.search_batch_dev(sig, xd, items, dop, 2)
+            torch.cuda.synchronize()
+            pa = a.cpu().numpy().view(acquire.PEAK_DTYPE)
+            pb = b.cpu().numpy().view(acquire.PEAK_DTYPE)
+            np.testing.assert_array_equal(pa["idx"], pb["idx"])
+            np.testing.assert_array_equal(pa["d_index"], pb["d_index"])
+            np.testing.assert_allclose(pa["metric"], pb["metric"], rtol=1e-6)
+    finally:
+        big.close()
+        small.close()
