@@ -1,0 +1,50 @@
+"""Batched code correlators for the tracking hand-off (SURVEY.md section 8f "next #4").
+
+Mirror of the reference's per-signal ``<module>.correlate(x, prn, chips, frac, incr, c[, boc11])``
+(gnsstools/gps/ca.py:120-128 and the BOC / CBOC / TMBOC / RZ variants), evaluated for many (PRN, start phase,
+rate) triples over one block of samples in a single launch -- e.g. early/prompt/late of every tracked satellite.
+The feedback loops themselves (track-*.py) are sequential and are not part of this package."""
+import numpy as np
+
+from . import _native as nat
+from . import acquire
+
+# which subcarrier the reference's correlate() of each code module applies
+KIND = {"gps.l1cd": 1, "beidou.b1cd": 1, "beidou.b1cp": 1,          # boc11[int(bp)]           gps/l1cd.py:101-112
+        "galileo.e1b": 2, "galileo.e1c": 2,                          # CBOC                      galileo/e1b.py:45-58
+        "gps.l1cp": 3,                                               # TMBOC                     gps/l1cp.py:210-228
+        "gps.l2cm": 4, "gps.l2cl": 5}                                # RZ [1,0] / [0,1]          gps/l2cm.py:81-92, l2cl.py
+
+
+def correlate_batch(code, x, prns, chips, frac, incr, engine=None):
+    """K correlators over the same block x: returns complex128[K].  prns/chips/frac/incr broadcast to a common length."""
+    eng = engine or acquire.default_engine()
+    prns, chips, frac, incr = np.broadcast_arrays(np.atleast_1d(prns), np.atleast_1d(chips), np.atleast_1d(frac), np.atleast_1d(incr))
+    K = len(prns)
+    xc = np.ascontiguousarray(x, dtype=np.complex64)
+    p = np.ascontiguousarray(prns, dtype=np.int32)
+    c = np.ascontiguousarray(chips, dtype=np.float64)
+    f = np.ascontiguousarray(frac, dtype=np.float64)
+    r = np.ascontiguousarray(incr, dtype=np.float64)
+    out = np.empty(K, dtype=np.complex128)
+    nat.check(nat.lib.gacq_correlate_batch(eng._ctx, xc.ctypes.data_as(nat.c_float_p), len(xc), code.encode(), KIND.get(code, 0),
+                                           p.ctypes.data_as(nat.c_int_p), c.ctypes.data_as(nat.c_double_p),
+                                           f.ctypes.data_as(nat.c_double_p), r.ctypes.data_as(nat.c_double_p), K,
+                                           out.ctypes.data_as(nat.c_double_p)), eng._ctx)
+    return out
+
+
+def correlate(code, x, prn, chips, frac, incr, engine=None):
+    """One correlator, the reference's argument order: <module>.correlate(x, prn, chips, frac, incr, ...)."""
+    return complex(correlate_batch(code, x, [prn], [chips], [frac], [incr], engine)[0])
+
+
+def early_prompt_late(code, x, prns, code_p, cf, spacing, engine=None):
+    """E/P/L of several satellites in one launch: the three correlate() calls of track-gps-l1.py:48-50 (spacing 0.05),
+    track-galileo-e1b.py:41-43 (0.2), track-gps-l2cm.py:41-43 (0.5).  Returns complex128[len(prns), 3]."""
+    prns = np.atleast_1d(prns)
+    code_p = np.broadcast_to(np.asarray(code_p, dtype=np.float64), prns.shape)
+    cf = np.broadcast_to(np.asarray(cf, dtype=np.float64), prns.shape)
+    off = np.array([-spacing, 0.0, spacing])
+    out = correlate_batch(code, x, np.repeat(prns, 3), 0.0, (code_p[:, None] + off[None, :]).ravel(), np.repeat(cf, 3), engine)
+    return out.reshape(len(prns), 3)

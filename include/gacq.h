@@ -166,6 +166,16 @@ int gacq_frontend_dev(gacq_ctx* ctx, const void* d_iq_int8, size_t nsamp_in, dou
 int gacq_longcode_search(gacq_ctx* ctx, const float* x_iq, size_t nsamp, double fs, const char* code, int prn,
                          double carrier_hz, const double* phase0, int K, int blocks, int n, double* q_out);
 
+/* ---------------------------------------------------------------------------------------------
+ * Batched code correlators for the tracking hand-off (SURVEY.md section 8f "next #4"): the reference's
+ * <module>.correlate(x, prn, chips, frac, incr, c[, boc11]) (gnsstools/gps/ca.py:120-128 and its BOC / CBOC / TMBOC /
+ * RZ variants) for K (PRN, start phase, rate) triples over one block of n samples in one launch.
+ * kind: 0 plain, 1 BOC(1,1), 2 CBOC (e1b/e1c), 3 TMBOC (l1cp), 4 RZ first half chip (l2cm), 5 RZ second half (l2cl).
+ * out_iq: K interleaved complex128 sums.  Synchronous; x_iq is a host buffer.
+ * ------------------------------------------------------------------------------------------- */
+int gacq_correlate_batch(gacq_ctx* ctx, const float* x_iq, size_t n, const char* code, int kind, const int* prns,
+                         const double* chips, const double* frac, const double* incr, int K, double* out_iq);
+
 /* Per-stage GPU time from HIP events recorded on the launch stream (profiling aid for bench.py).
  * Stages: 0 mix/forward, 1 forward FFT (rocFFT), 2 conj-multiply, 3 inverse FFT (rocFFT),
  *         4 magnitude/peak reduce, 5 best-over-Doppler, 6 fused correlate kernel (LDS FFT). */
