@@ -58,6 +58,26 @@ class ShardedSearch:
             return self.engine.merge_peaks_dev(gathered, b[:-1])
         return merge_peaks_host(gathered.numpy(), b[:-1])
 
+    def search_batch_async(self, name, x, items, dopplers, blocks):
+        """Like search_batch, but the all-gather is issued asynchronously (RCCL runs it on its own stream once the local
+        kernels are done) and the merge is deferred to PendingSearch.wait().  Launching the next search before waiting on
+        the previous one overlaps the exchange of step i with the compute of step i+1."""
+        import torch
+        dopplers = np.ascontiguousarray(dopplers, dtype=np.float64)
+        b = doppler_bounds(len(dopplers), self.world)
+        lo, hi = b[self.rank], b[self.rank + 1]
+        if self.local_fn is not None:
+            local = self.local_fn(name, x, items, dopplers[lo:hi], blocks)
+        else:
+            self.engine.use_torch_stream(x.device)
+            local = self.engine.search_batch_dev(name, x, items, dopplers[lo:hi], blocks)
+        if self.world == 1 and not (self.always_gather and self.dist.is_initialized()):
+            return PendingSearch(self, local, None, None, b)
+        flat = local.contiguous().view(-1)
+        gathered = torch.empty(self.world * flat.numel(), dtype=local.dtype, device=local.device)
+        work = self.dist.all_gather_into_tensor(gathered, flat, group=self.group, async_op=True)     # the ONE collective
+        return PendingSearch(self, local, gathered.view((self.world,) + tuple(local.shape)), work, b)
+
     def search_jobs(self, jobs):
         """Cold-start style multi-constellation search (BASELINE config 5): `jobs` is a list of dicts
         {name, x, items, dopplers, blocks}.  Every job's Doppler grid is sliced over the ranks like search_batch, all
@@ -96,6 +116,24 @@ class ShardedSearch:
         pk = merged.cpu().numpy() if hasattr(merged, "cpu") else np.asarray(merged)
         pk = pk.view(acquire.PEAK_DTYPE).reshape(-1, len(items))
         return [acquire.finalize(name, items, pk[e], dopplers) for e in range(pk.shape[0])]
+
+
+class PendingSearch:
+    """A sharded search whose exchange may still be in flight (ShardedSearch.search_batch_async)."""
+
+    def __init__(self, owner, local, gathered, work, bounds):
+        self.owner, self.local, self.gathered, self.work, self.bounds = owner, local, gathered, work, bounds
+
+    def wait(self):
+        """Merged peaks [nepoch, nitems, 2].  For RCCL, Work.wait() orders the current stream after the collective
+        (it does not block the host), so the merge kernel can be queued right away."""
+        if self.gathered is None:
+            return self.local
+        if self.work is not None:
+            self.work.wait()
+        if self.gathered.is_cuda:
+            return self.owner.engine.merge_peaks_dev(self.gathered, self.bounds[:-1])
+        return merge_peaks_host(self.gathered.numpy(), self.bounds[:-1])
 
 
 def merge_peaks_host(gathered, shard_d0):

@@ -55,6 +55,11 @@ def main():
             res = sh.results(name, items, m1, dop)
             res2 = sh.results(name, items[:1], m2, dop2)
             res = [a + b for a, b in zip(res, res2)]          # per epoch: job-1 results followed by job-2's
+        elif os.environ.get("GLOO_ASYNC"):
+            p1 = sh.search_batch_async(name, torch.from_numpy(xs), items, dop, blocks)
+            p2 = sh.search_batch_async(name, torch.from_numpy(xs), items, dop, blocks)      # second search in flight before the first merge
+            res = sh.results(name, items, p1.wait(), dop)
+            assert sh.results(name, items, p2.wait(), dop) == res
         else:
             merged = sh.search_batch(name, torch.from_numpy(xs), items, dop, blocks)
             res = sh.results(name, items, merged, dop)

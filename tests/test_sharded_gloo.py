@@ -23,12 +23,13 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,name,items,ds,ms", [
-    (2, "gps-l1", [3, 4, 28], [-2000.0, 2500.0, 500.0], 1),
-    (3, "gps-l1", [3, 9], [1000.0, 2050.0, 150.0], 2),
-    (2, "glonass-l1", [-2, 5], [1200.0, 1900.0, 100.0], 1),
+@pytest.mark.parametrize("world,name,items,ds,ms,mode", [
+    (2, "gps-l1", [3, 4, 28], [-2000.0, 2500.0, 500.0], 1, ""),
+    (3, "gps-l1", [3, 9], [1000.0, 2050.0, 150.0], 2, ""),
+    (2, "glonass-l1", [-2, 5], [1200.0, 1900.0, 100.0], 1, ""),
+    (2, "gps-l1", [3, 9], [1000.0, 2050.0, 150.0], 1, "GLOO_ASYNC"),
 ])
-def test_sharded_search_equals_unsharded_oracle(tmp_path, world, name, items, ds, ms):
+def test_sharded_search_equals_unsharded_oracle(tmp_path, world, name, items, ds, ms, mode):
     from gnss_dsp_tools_amd import signals, synth
     from oracle import acq_oracle
     out = tmp_path / "res.json"
@@ -36,6 +37,8 @@ def test_sharded_search_equals_unsharded_oracle(tmp_path, world, name, items, ds
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        if mode:
+            env[mode] = "1"
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gloo_worker.py"), str(out), name,
                                        ",".join(map(str, items)), ",".join(map(str, ds)), str(ms)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
