@@ -142,13 +142,13 @@ __global__ __launch_bounds__(kBlock) void mix_nco_kernel(const float2* __restric
   __shared__ float2 s_tab[kNcoTableSize];
   for (int i = threadIdx.x; i < kNcoTableSize; i += kBlock) s_tab[i] = tab[i];
   __syncthreads();
-  const long blk = blockIdx.x;
-  const int chunk = (int)(blk % chunks);
-  const long row = blk / chunks;            // ((e*FD + fd)*B + b)
-  const int b = (int)(row % B);
-  const long t = row / B;
-  const int fd = (int)(t % FD);
-  const long e = t / FD;
+  const unsigned blk = blockIdx.x;          // 32-bit index math (64-bit divisions are ~100 scalar ops each)
+  const int chunk = (int)(blk % (unsigned)chunks);
+  const unsigned row = blk / (unsigned)chunks;            // ((e*FD + fd)*B + b)
+  const int b = (int)(row % (unsigned)B);
+  const unsigned t = row / (unsigned)B;
+  const int fd = (int)(t % (unsigned)FD);
+  const long e = t / (unsigned)FD;
   const double f = freq[fd];
   const float2* src = x + e * epoch_stride + (size_t)b * n;
   float2* dst = y + row * (long)span;
@@ -182,15 +182,15 @@ __global__ __launch_bounds__(kBlock) void conj_mul_kernel(const float2* __restri
                                                            float2* __restrict__ Y, const int* __restrict__ items,
                                                            const int* __restrict__ fset, long g0, int P, int F, int D,
                                                            int B, int N, int chunks) {
-  const long blk = blockIdx.x;
-  const int chunk = (int)(blk % chunks);
-  const long ry = blk / chunks;
-  const int b = (int)(ry % B);
-  const long g = g0 + ry / B;
-  const int d = (int)(g % D);
-  const long ep = g / D;
-  const int p = (int)(ep % P);
-  const long e = ep / P;
+  const unsigned blk = blockIdx.x;
+  const int chunk = (int)(blk % (unsigned)chunks);
+  const unsigned ry = blk / (unsigned)chunks;
+  const int b = (int)(ry % (unsigned)B);
+  const unsigned g = (unsigned)g0 + ry / (unsigned)B;          // E*P*D < 2^31 (checked by the launcher)
+  const int d = (int)(g % (unsigned)D);
+  const unsigned ep = g / (unsigned)D;
+  const int p = (int)(ep % (unsigned)P);
+  const long e = ep / (unsigned)P;
   const float2* xs = X + (((e * F + fset[p]) * D + d) * (long)B + b) * (long)N;
   const float2* cs = C + (long)items[p] * N;
   float2* ys = Y + ry * (long)N;
@@ -279,22 +279,35 @@ __global__ __launch_bounds__(kBlock) void mag_peak_kernel(const float2* __restri
 }
 
 // K4: per (e,p): scan Doppler bins in order, strict '>' against the running best that starts at 0.
-__global__ void best_doppler_kernel(const RowRec* __restrict__ rows, gacq_peak* __restrict__ out, long nep, int D, int N,
-                                    int normalised) {
-  const long ep = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per (epoch, item): lane l scans bins l, l+64, ... in ascending order with strict '>', then the 64 lane results
+// are combined keeping the larger metric and, on equal metrics, the lower bin -- the same winner as the serial scan of
+// acquire-gps-l1.py:36-39 (initial (0,0,0): a row that never exceeds 0 reports idx = d_index = -1, mapped to 0 by finalize).
+__global__ __launch_bounds__(256) void best_doppler_kernel(const RowRec* __restrict__ rows, gacq_peak* __restrict__ out, long nep,
+                                                           int D, int N, int normalised) {
+  const long ep = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (ep >= nep) return;
+  const int lane = threadIdx.x & 63;
   double best = 0.0;
-  int bidx = -1, bd = -1;
-  for (int d = 0; d < D; d++) {
+  int bidx = -1, bd = 0x7fffffff;
+  for (int d = lane; d < D; d += 64) {
     const RowRec r = rows[ep * D + d];
     const double m = normalised ? (double)r.peak / (r.sum / (double)N) : (double)r.peak;
     if (m > best) { best = m; bidx = r.idx; bd = d; }
   }
-  gacq_peak o;
-  o.metric = best;
-  o.idx = bidx;
-  o.d_index = bd;
-  out[ep] = o;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double om = __shfl_down(best, off);
+    const int oi = __shfl_down(bidx, off);
+    const int od = __shfl_down(bd, off);
+    if (om > best || (om == best && od < bd)) { best = om; bidx = oi; bd = od; }
+  }
+  if (lane == 0) {
+    gacq_peak o;
+    o.metric = best;
+    o.idx = bidx;
+    o.d_index = bidx < 0 ? -1 : bd;
+    out[ep] = o;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -579,6 +592,8 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
   int rc;
   double max_f = 0.0;
   for (double v : g.freq) max_f = std::max(max_f, std::fabs(v));
+  if ((long)nepoch * P * D * std::max(1, F) >= (1L << 31))
+    return set_error(ctx, GACQ_ERR_UNSUPPORTED, "%d epochs x %d items x %d Doppler bins exceeds the 2^31 rows one call can index", nepoch, P, D);
   if (!nco_range_ok(max_f, N))
     return set_error(ctx, GACQ_ERR_UNSUPPORTED, "NCO frequency %.3g cycles/sample x %d samples exceeds the 32-bit phase-index range", max_f, N);
   const void* before[3] = {ctx->freq.p, ctx->fset.p, ctx->items.p};
@@ -708,7 +723,7 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
     }
     const long nep = (long)ne * P;
     stage_begin(ctx, 5);
-    hipLaunchKernelGGL(best_doppler_kernel, dim3((unsigned)((nep + 127) / 128)), dim3(128), 0, st, rows,
+    hipLaunchKernelGGL(best_doppler_kernel, dim3((unsigned)((nep + 3) / 4)), dim3(256), 0, st, rows,
                        d_out + (size_t)e0 * P, nep, D, N, ds.metric_mode);
     stage_end(ctx);
     GACQ_HIP(ctx, hipGetLastError());

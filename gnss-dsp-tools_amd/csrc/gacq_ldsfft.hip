@@ -123,11 +123,11 @@ __global__ __launch_bounds__(kBlock) void lds_forward_kernel(const float2* __res
                                                               const float2* __restrict__ tw, int n, int FD, int B) {
   __shared__ v2 lds[kLdsElems];
   const int t = threadIdx.x;
-  const long row = blockIdx.x;            // ((e*FD + fd)*B + b)
-  const int b = (int)(row % B);
-  const long r2 = row / B;
-  const int fd = (int)(r2 % FD);
-  const long e = r2 / FD;
+  const unsigned row = blockIdx.x;        // ((e*FD + fd)*B + b); 32-bit index math (64-bit divisions are ~100 scalar ops)
+  const int b = (int)(row % (unsigned)B);
+  const unsigned r2 = row / (unsigned)B;
+  const int fd = (int)(r2 % (unsigned)FD);
+  const long e = r2 / (unsigned)FD;
   const double f = freq[fd];
   const float2* src = x + e * epoch_stride + (size_t)b * n;
   v2 v[kR], w[kR];
@@ -215,11 +215,11 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_forward_kernel(const float
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v2* lds = reinterpret_cast<v2*>(smem);
   const int t = threadIdx.x;
-  const long row = blockIdx.x;
-  const int b = (int)(row % B);
-  const long r2 = row / B;
-  const int fd = (int)(r2 % FD);
-  const long e = r2 / FD;
+  const unsigned row = blockIdx.x;
+  const int b = (int)(row % (unsigned)B);
+  const unsigned r2 = row / (unsigned)B;
+  const int fd = (int)(r2 % (unsigned)FD);
+  const long e = r2 / (unsigned)FD;
   const double f = freq[fd];
   const float2* src = x + e * epoch_stride + (size_t)b * n;
   v2 v[kR], w[kR];
@@ -274,12 +274,12 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_correlate_kernel(const flo
   __shared__ double s_sum[kBigThreads / 64];
   const int t = threadIdx.x;
   const int xcd = blockIdx.x & 7;
-  const long j = blockIdx.x >> 3;
-  const long u = (j / nchunk) * 8 + xcd;             // (epoch, Doppler) unit -> XCD, as in lds_correlate_kernel
-  if (u >= (long)E * D) return;
-  const long e = u / D;
-  const int d = (int)(u % D);
-  const int p0 = (int)(j % nchunk) * pch;
+  const unsigned j = blockIdx.x >> 3;
+  const unsigned u = (j / (unsigned)nchunk) * 8 + xcd;             // (epoch, Doppler) unit -> XCD, as in lds_correlate_kernel
+  if (u >= (unsigned)E * (unsigned)D) return;
+  const long e = u / (unsigned)D;
+  const int d = (int)(u % (unsigned)D);
+  const int p0 = (int)(j % (unsigned)nchunk) * pch;
   const int p1 = min(P, p0 + pch);
   const v2 base = ld2(twn + t);
   const unsigned lane_off = (unsigned)t * 16u;
@@ -369,15 +369,15 @@ __global__ __launch_bounds__(kBlock, 4) void lds_inner_correlate_kernel(const fl
                                                                         int R) {
   __shared__ v2 lds[kLdsElems];
   const int t = threadIdx.x;
-  const long ry = blockIdx.x;                  // ((gl*B + b)*R + k1)
-  const int k1 = (int)(ry % R);
-  const long gb = ry / R;
-  const int b = (int)(gb % B);
-  const long g = g0 + gb / B;
-  const int d = (int)(g % D);
-  const long ep = g / D;
-  const int p = (int)(ep % P);
-  const long e = ep / P;
+  const unsigned ry = blockIdx.x;              // ((gl*B + b)*R + k1)
+  const int k1 = (int)(ry % (unsigned)R);
+  const unsigned gb = ry / (unsigned)R;
+  const int b = (int)(gb % (unsigned)B);
+  const unsigned g = (unsigned)g0 + gb / (unsigned)B;          // E*P*D < 2^31 (checked by the launcher)
+  const int d = (int)(g % (unsigned)D);
+  const unsigned ep = g / (unsigned)D;
+  const int p = (int)(ep % (unsigned)P);
+  const long e = ep / (unsigned)P;
   const __amdgpu_buffer_rsrc_t xres = row_rsrc(X + ((((e * F + fset[p]) * D + d) * (long)B + b) * R + k1) * kLdsN);
   const __amdgpu_buffer_rsrc_t cres = row_rsrc(C + ((long)items[p] * R + k1) * kLdsN);
   const unsigned lane_off = (unsigned)t * 16u;
@@ -446,12 +446,12 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float
   // of that unit, so they are all placed on XCD u%8 and share that XCD's L2; the code spectra (P*32 KB) end
   // up resident in every XCD's 4 MB L2.  Works for any E (a single-epoch search still fills all 8 XCDs).
   const int xcd = blockIdx.x & 7;
-  const long j = blockIdx.x >> 3;
-  const long u = (j / nchunk) * 8 + xcd;
-  if (u >= (long)E * D) return;
-  const long e = u / D;
-  const int d = (int)(u % D);
-  const int p0 = (int)(j % nchunk) * pch;
+  const unsigned j = blockIdx.x >> 3;
+  const unsigned u = (j / (unsigned)nchunk) * 8 + xcd;
+  if (u >= (unsigned)E * (unsigned)D) return;
+  const long e = u / (unsigned)D;
+  const int d = (int)(u % (unsigned)D);
+  const int p0 = (int)(j % (unsigned)nchunk) * pch;
   const int p1 = min(P, p0 + pch);
   v2 wa = ld2(tw + t), wb = ld2(tw + 16 * (t & 15));
   v2 pwa[PRETW ? 15 : 1], pwb[PRETW ? 15 : 1];

@@ -33,18 +33,18 @@ __global__ __launch_bounds__(kBlock) void split_outer_forward_kernel(const float
                                                                     const float2* __restrict__ nco_tab,
                                                                     const float2* __restrict__ tw, int n, int M, int FD, int B,
                                                                     int chunks) {
-  const long blk = blockIdx.x;
-  const int chunk = (int)(blk % chunks);
-  const long row = blk / chunks;
+  const unsigned blk = blockIdx.x;                 // 32-bit index math throughout: a 64-bit division is ~100 scalar ops
+  const int chunk = (int)(blk % (unsigned)chunks);
+  const unsigned row = blk / (unsigned)chunks;
   const int n2 = chunk * kBlock + threadIdx.x;
   if (n2 >= M) return;
   const float2* src;
   double f = 0.0;
   if (MIX) {
-    const int b = (int)(row % B);
-    const long r2 = row / B;
-    const int fd = (int)(r2 % FD);
-    const long e = r2 / FD;
+    const int b = (int)(row % (unsigned)B);
+    const unsigned r2 = row / (unsigned)B;
+    const int fd = (int)(r2 % (unsigned)FD);
+    const long e = r2 / (unsigned)FD;
     f = freq[fd];
     src = x + e * epoch_stride + (size_t)b * n;
   } else {
@@ -88,9 +88,9 @@ __global__ __launch_bounds__(kBlock) void split_outer_inverse_kernel(const float
   __shared__ float s_peak[kBlock / 64];
   __shared__ int s_idx[kBlock / 64];
   __shared__ double s_sum[kBlock / 64];
-  const long blk = blockIdx.x;
-  const int chunk = (int)(blk % chunks);
-  const long g = blk / chunks;
+  const unsigned blk = blockIdx.x;
+  const int chunk = (int)(blk % (unsigned)chunks);
+  const long g = blk / (unsigned)chunks;
   const int n2 = chunk * kBlock + threadIdx.x;
   float peak = -1.0f;
   int idx = 0x7fffffff;
@@ -163,29 +163,18 @@ __global__ __launch_bounds__(kBlock) void split_outer_inverse_kernel(const float
 // memory and multiplies them (K2), so the product never exists in HBM; the last pass writes the row.  Thread j of a
 // radix-R pass with Ns = product of the previous radices:  k = j mod Ns; inputs in[j + t M/R] * W_{Ns R}^{-k t};
 // R-point DFT; outputs out[(j div Ns) Ns R + k + t Ns].
-template <int R, bool FIRST, bool LAST>
-__device__ __forceinline__ void stockham_pass(const v2* __restrict__ in, v2* __restrict__ out, const float2* __restrict__ gx,
-                                              const float2* __restrict__ gc, float2* __restrict__ gz, const v2* __restrict__ twm,
-                                              int Ns, int M) {
+template <int R, bool LAST>
+__device__ __forceinline__ void stockham_pass(const v2* __restrict__ in, v2* __restrict__ out, float2* __restrict__ gz,
+                                              const v2* __restrict__ twm, int Ns, int M) {
   const int nb = M / R;
   const int step = M / (Ns * R);
   for (int j = threadIdx.x; j < nb; j += kBlock) {
     const int k = j % Ns;
-    v2 x[R];
-    if (FIRST) {
-      float2 xv[R], cv[R];
+    v2 x[R], wv[R];
 #pragma unroll
-      for (int t = 0; t < R; t++) { xv[t] = gx[j + t * nb]; cv[t] = gc[j + t * nb]; }
+    for (int t = 0; t < R; t++) { x[t] = in[j + t * nb]; if (t) wv[t] = twm[k * t * step]; }          // k t step < M
 #pragma unroll
-      for (int t = 0; t < R; t++)
-        x[t] = v2{cv[t].x * xv[t].x + cv[t].y * xv[t].y, cv[t].y * xv[t].x - cv[t].x * xv[t].y};      // C * conj(X)   acquire-gps-l1.py:32
-    } else {
-      v2 wv[R];
-#pragma unroll
-      for (int t = 0; t < R; t++) { x[t] = in[j + t * nb]; if (t) wv[t] = twm[k * t * step]; }          // k t step < M
-#pragma unroll
-      for (int t = 1; t < R; t++) x[t] = cmul(x[t], wv[t]);
-    }
+    for (int t = 1; t < R; t++) x[t] = cmul(x[t], wv[t]);
     SmallDft<R, true>::run(x);
     const int j0 = (j / Ns) * Ns * R + k;
 #pragma unroll
@@ -196,36 +185,71 @@ __device__ __forceinline__ void stockham_pass(const v2* __restrict__ in, v2* __r
   }
 }
 
+// Workgroup = (k1, chunk of pch consecutive (epoch, item) pairs, Doppler bin, block): the twiddle table is staged into LDS
+// once and the first-pass operands of X[e,f,d,b][k1][.] stay in registers while the items change (they are reloaded only when
+// the row pointer changes, i.e. across an epoch or frequency-set boundary).  Consecutive workgroups share k1 and the item
+// chunk, so the pch code-spectrum rows they read stay in every XCD's L2.  [g0, g0+ng) is the range of (e,p,d) groups whose
+// Z rows exist in this workspace pass; anything outside is skipped.
 template <int R0, int R1, int R2, int R3>
 __global__ __launch_bounds__(kBlock) void split_inner_corr_kernel(const float2* __restrict__ X, const float2* __restrict__ C,
                                                                    float2* __restrict__ Z, const int* __restrict__ items,
                                                                    const int* __restrict__ fset, const float2* __restrict__ twm_g,
-                                                                   long g0, int P, int F, int D, int B, int R) {
+                                                                   long g0, long ng, long ep_first, int nblk_ep, int pch, int P, int F,
+                                                                   int D, int B, int R) {
   constexpr int M = R0 * R1 * R2 * R3;
+  constexpr int nb0 = M / R0;
+  static_assert(nb0 <= kBlock, "first pass: one radix-R0 butterfly per thread");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v2* buf0 = reinterpret_cast<v2*>(smem);
   v2* buf1 = buf0 + M;
   v2* twm = buf1 + M;                              // conj(W_M^k), k < M
   for (int k = threadIdx.x; k < M; k += kBlock) { const float2 w = twm_g[k]; twm[k] = v2{w.x, -w.y}; }
-  const long ry = blockIdx.x;                      // ((gl*B + b)*R + k1)
-  const int k1 = (int)(ry % R);
-  const long gb = ry / R;
-  const int b = (int)(gb % B);
-  const long g = g0 + gb / B;
-  const int d = (int)(g % D);
-  const long ep = g / D;
-  const int p = (int)(ep % P);
-  const long e = ep / P;
-  const float2* gx = X + ((((e * F + fset[p]) * D + d) * (long)B + b) * R + k1) * (long)M;
-  const float2* gc = C + ((long)items[p] * R + k1) * (long)M;
-  float2* gz = Z + ry * (long)M;
-  stockham_pass<R0, true, false>(nullptr, buf0, gx, gc, nullptr, twm, 1, M);
-  __syncthreads();
-  stockham_pass<R1, false, false>(buf0, buf1, nullptr, nullptr, nullptr, twm, R0, M);
-  __syncthreads();
-  stockham_pass<R2, false, false>(buf1, buf0, nullptr, nullptr, nullptr, twm, R0 * R1, M);
-  __syncthreads();
-  stockham_pass<R3, false, true>(buf0, nullptr, nullptr, nullptr, gz, twm, R0 * R1 * R2, M);
+  unsigned blk = blockIdx.x;                       // 32-bit index math: 64-bit divisions cost ~100 scalar ops each
+  const int b = (int)(blk % (unsigned)B);
+  blk /= (unsigned)B;
+  const int d = (int)(blk % (unsigned)D);
+  blk /= (unsigned)D;
+  const unsigned epc = blk % (unsigned)nblk_ep;
+  const int k1 = (int)(blk / (unsigned)nblk_ep);
+  const int j = threadIdx.x;
+  const bool act = j < nb0;
+  const float2* have = nullptr;
+  float2 xv[R0];
+  const long ep0 = ep_first + (long)epc * pch;
+  long e = ep0 / P;
+  int p = (int)(ep0 - e * P) - 1;
+  for (int i = 0; i < pch; i++) {
+    if (++p == P) { p = 0; e++; }
+    const long g = (ep0 + i) * D + d;
+    if (g < g0 || g >= g0 + ng) continue;          // uniform over the workgroup
+    const float2* gx = X + ((((e * F + fset[p]) * D + d) * (long)B + b) * R + k1) * (long)M;
+    const float2* gc = C + ((long)items[p] * R + k1) * (long)M;
+    float2* gz = Z + (((g - g0) * B + b) * R + k1) * (long)M;
+    if (act) {
+      float2 cv[R0];
+#pragma unroll
+      for (int t = 0; t < R0; t++) cv[t] = gc[j + t * nb0];
+      if (gx != have) {
+#pragma unroll
+        for (int t = 0; t < R0; t++) xv[t] = gx[j + t * nb0];
+      }
+      v2 x[R0];
+#pragma unroll
+      for (int t = 0; t < R0; t++)
+        x[t] = v2{cv[t].x * xv[t].x + cv[t].y * xv[t].y, cv[t].y * xv[t].x - cv[t].x * xv[t].y};      // C * conj(X)   acquire-gps-l1.py:32
+      SmallDft<R0, true>::run(x);
+#pragma unroll
+      for (int t = 0; t < R0; t++) buf0[j * R0 + t] = x[t];                                             // Ns = 1: k = 0, no twiddles
+    }
+    have = gx;
+    __syncthreads();
+    stockham_pass<R1, false>(buf0, buf1, nullptr, twm, R0, M);
+    __syncthreads();
+    stockham_pass<R2, false>(buf1, buf0, nullptr, twm, R0 * R1, M);
+    __syncthreads();
+    stockham_pass<R3, true>(buf0, nullptr, gz, twm, R0 * R1 * R2, M);
+    __syncthreads();                               // buf0 is rewritten by the next item's first pass
+  }
 }
 
 // partial[(g, chunk)] -> rows[g0 + g]
@@ -297,13 +321,19 @@ int split_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* C, const
   int rc = inner_twiddles(ctx, M, &twm);
   if (rc != GACQ_OK) return rc;
   const size_t smem = sizeof(float2) * 3 * (size_t)M;
-  const dim3 grid((unsigned)(ng * B * R));
+  // (epoch, item) rows touched by this pass, cut into chunks of pch per workgroup; >= ~2048 workgroups, <= 8 items each
+  const long ep_first = g0 / D, ep_last = (g0 + ng - 1) / D;
+  const long nep = ep_last - ep_first + 1;
+  int pch = (int)std::max<long>(1, std::min<long>(8, nep * D * B * R / 2048));
+  if (const char* ev = getenv("GACQ_SPLIT_PCH")) { const int k = atoi(ev); if (k >= 1) pch = k; }
+  const int nblk_ep = (int)((nep + pch - 1) / pch);
+  const dim3 grid((unsigned)((long)R * nblk_ep * D * B));
   if (M == 1980)
-    hipLaunchKernelGGL((split_inner_corr_kernel<11, 9, 5, 4>), grid, dim3(kBlock), smem, ctx->stream, X, C, Z, d_items, d_fset, twm, g0, P,
-                       F, D, B, R);
+    hipLaunchKernelGGL((split_inner_corr_kernel<11, 9, 5, 4>), grid, dim3(kBlock), smem, ctx->stream, X, C, Z, d_items, d_fset, twm, g0, ng,
+                       ep_first, nblk_ep, pch, P, F, D, B, R);
   else if (M == 990)
-    hipLaunchKernelGGL((split_inner_corr_kernel<11, 9, 5, 2>), grid, dim3(kBlock), smem, ctx->stream, X, C, Z, d_items, d_fset, twm, g0, P,
-                       F, D, B, R);
+    hipLaunchKernelGGL((split_inner_corr_kernel<11, 9, 5, 2>), grid, dim3(kBlock), smem, ctx->stream, X, C, Z, d_items, d_fset, twm, g0, ng,
+                       ep_first, nblk_ep, pch, P, F, D, B, R);
   else
     return set_error(ctx, GACQ_ERR_UNSUPPORTED, "fused inner transforms: M=%d not supported", M);
   GACQ_HIP(ctx, hipGetLastError());
