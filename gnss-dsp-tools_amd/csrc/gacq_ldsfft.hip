@@ -361,52 +361,68 @@ __global__ __launch_bounds__(kBlock) void lds_inner_forward_kernel(float2* __res
 }
 
 // Z'[(g,b)][k1][n2] = W_N^{-n2 k1} * IFFT_4096( C_p[k1][.] * X[e,f,d,b][k1][.] )[n2]      (K2 + inner inverse + twiddle)
-// one workgroup per (group, block, k1); twn holds W_N^m for m < 256 R.
+// Workgroup = (k1, chunk of pch consecutive (epoch, item) pairs, Doppler bin, block).  The X row and the W_N twiddle powers
+// depend only on the workgroup, so they stay in registers while the items change (X is reloaded only when its row pointer
+// changes: epoch or frequency-set boundary inside the chunk).  Consecutive workgroups share (k1, item chunk), so those pch
+// code-spectrum rows are hot in every XCD's L2.  [g0, g0+ng) = (e,p,d) groups whose Z rows exist in this workspace pass.
+// twn holds W_N^m for m < 256 R.
 __global__ __launch_bounds__(kBlock, 4) void lds_inner_correlate_kernel(const float2* __restrict__ X, const float2* __restrict__ C,
                                                                         const int* __restrict__ items, const int* __restrict__ fset,
                                                                         const float2* __restrict__ tw, const float2* __restrict__ twn,
-                                                                        float2* __restrict__ Z, long g0, int P, int F, int D, int B,
-                                                                        int R) {
+                                                                        float2* __restrict__ Z, long g0, long ng, long ep_first,
+                                                                        int nblk_ep, int pch, int P, int F, int D, int B, int R) {
   __shared__ v2 lds[kLdsElems];
   const int t = threadIdx.x;
-  const unsigned ry = blockIdx.x;              // ((gl*B + b)*R + k1)
-  const int k1 = (int)(ry % (unsigned)R);
-  const unsigned gb = ry / (unsigned)R;
-  const int b = (int)(gb % (unsigned)B);
-  const unsigned g = (unsigned)g0 + gb / (unsigned)B;          // E*P*D < 2^31 (checked by the launcher)
-  const int d = (int)(g % (unsigned)D);
-  const unsigned ep = g / (unsigned)D;
-  const int p = (int)(ep % (unsigned)P);
-  const long e = ep / (unsigned)P;
-  const __amdgpu_buffer_rsrc_t xres = row_rsrc(X + ((((e * F + fset[p]) * D + d) * (long)B + b) * R + k1) * kLdsN);
-  const __amdgpu_buffer_rsrc_t cres = row_rsrc(C + ((long)items[p] * R + k1) * kLdsN);
+  unsigned blk = blockIdx.x;                   // 32-bit index math (64-bit divisions are ~100 scalar ops each)
+  const int b = (int)(blk % (unsigned)B);
+  blk /= (unsigned)B;
+  const int d = (int)(blk % (unsigned)D);
+  blk /= (unsigned)D;
+  const unsigned epc = blk % (unsigned)nblk_ep;
+  const int k1 = (int)(blk / (unsigned)nblk_ep);
+  const long ep0 = ep_first + (long)epc * pch;
+  long e = ep0 / P;
+  int p = (int)(ep0 - e * P) - 1;
   const unsigned lane_off = (unsigned)t * 16u;
-  v2 v[kR], xv[kR];
-#pragma unroll
-  for (int jp = 0; jp < kR / 2; jp++) {          // loads first, asm afterwards (see lds_correlate_kernel)
-    ld_pair(cres, lane_off, jp, v[2 * jp], v[2 * jp + 1]);
-    ld_pair(xres, lane_off, jp, xv[2 * jp], xv[2 * jp + 1]);
-  }
   const v2 twa = ld2(tw + t), twb = ld2(tw + 16 * (t & 15));
+  // lane holds n2 = t + 256 k: W_N^{-k1 (t + 256 k)} = conj(W_N^{k1 t}) * conj(W_N^{256 k1})^k
   v2 base = ld2(twn + k1 * t), step = ld2(twn + 256 * k1);
+  base.y = -base.y;
+  step.y = -step.y;
+  TwPow tp;
+  tp.init<15>(step);
+  const float2* have = nullptr;
+  v2 xr[kR];
+  for (int i = 0; i < pch; i++) {
+    if (++p == P) { p = 0; e++; }
+    const long g = (ep0 + i) * D + d;
+    if (g < g0 || g >= g0 + ng) continue;      // uniform over the workgroup
+    const float2* xrow = X + ((((e * F + fset[p]) * D + d) * (long)B + b) * R + k1) * kLdsN;
+    const __amdgpu_buffer_rsrc_t cres = row_rsrc(C + ((long)items[p] * R + k1) * kLdsN);
+    v2 v[kR];
 #pragma unroll
-  for (int jj = 0; jj < kR; jj++) v[jj] = cmul(v[jj], xv[jj]);
-  fft4096<true>(v, lds, twa, twb);
-  float2* dst = Z + ry * (long)kLdsN + t;
-  if (k1 == 0) {
+    for (int jp = 0; jp < kR / 2; jp++) ld_pair(cres, lane_off, jp, v[2 * jp], v[2 * jp + 1]);      // loads first, asm afterwards
+    if (xrow != have) {
+      const __amdgpu_buffer_rsrc_t xres = row_rsrc(xrow);
 #pragma unroll
-    for (int k = 0; k < kR; k++) { const v2 o = v[rev16(k)]; dst[256 * k] = make_float2(o.x, o.y); }
-  } else {
-    // lane holds n2 = t + 256 k: W_N^{-k1 (t + 256 k)} = conj(W_N^{k1 t}) * conj(W_N^{256 k1})^k
-    base.y = -base.y;
-    step.y = -step.y;
-    TwPow tp;
-    tp.init<15>(step);
-#pragma unroll
-    for (int k = 0; k < kR; k++) {
-      const v2 o = tp.apply(cmul(v[rev16(k)], base), k);
-      dst[256 * k] = make_float2(o.x, o.y);
+      for (int jp = 0; jp < kR / 2; jp++) ld_pair(xres, lane_off, jp, xr[2 * jp], xr[2 * jp + 1]);
+      have = xrow;
     }
+#pragma unroll
+    for (int jj = 0; jj < kR; jj++) v[jj] = cmul(v[jj], xr[jj]);
+    fft4096<true>(v, lds, twa, twb);
+    float2* dst = Z + (((g - g0) * B + b) * R + k1) * (long)kLdsN + t;
+    if (k1 == 0) {
+#pragma unroll
+      for (int k = 0; k < kR; k++) { const v2 o = v[rev16(k)]; dst[256 * k] = make_float2(o.x, o.y); }
+    } else {
+#pragma unroll
+      for (int k = 0; k < kR; k++) {
+        const v2 o = tp.apply(cmul(v[rev16(k)], base), k);
+        dst[256 * k] = make_float2(o.x, o.y);
+      }
+    }
+    __syncthreads();                           // exchange-2 reads done before the next item's exchange-1 writes
   }
 }
 
@@ -691,8 +707,14 @@ int lds_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, c
   int rc = twiddle_table(ctx, &tw);
   if (rc != GACQ_OK) return rc;
   if ((rc = big_twiddles(ctx, N, R, &twn)) != GACQ_OK) return rc;
-  hipLaunchKernelGGL(lds_inner_correlate_kernel, dim3((unsigned)(ng * B * R)), dim3(kBlock), 0, ctx->stream, X, spectra, d_items,
-                     d_fset, tw, twn, Z, g0, P, F, D, B, R);
+  // (epoch, item) rows touched by this pass, cut into chunks of pch per workgroup; >= ~2048 workgroups, <= 8 items each
+  const long ep_first = g0 / D, ep_last = (g0 + ng - 1) / D;
+  const long nep = ep_last - ep_first + 1;
+  int pch = (int)std::max<long>(1, std::min<long>(8, nep * D * B * R / 2048));
+  if (const char* ev = getenv("GACQ_SPLIT_PCH")) { const int k = atoi(ev); if (k >= 1) pch = k; }
+  const int nblk_ep = (int)((nep + pch - 1) / pch);
+  hipLaunchKernelGGL(lds_inner_correlate_kernel, dim3((unsigned)((long)R * nblk_ep * D * B)), dim3(kBlock), 0, ctx->stream, X, spectra,
+                     d_items, d_fset, tw, twn, Z, g0, ng, ep_first, nblk_ep, pch, P, F, D, B, R);
   GACQ_HIP(ctx, hipGetLastError());
   return GACQ_OK;
 }

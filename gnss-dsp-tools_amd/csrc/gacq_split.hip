@@ -159,28 +159,55 @@ __global__ __launch_bounds__(kBlock) void split_outer_inverse_kernel(const float
 
 // ---- inner inverse transforms fused with the conj-multiply (engine 3, M = 1980 / 990) ---------------------------------
 // Z[ry][n2] = IFFT_M( C_p[k1][.] * conj(X[e,f,d,b][k1][.]) )[n2]  (unnormalised), one workgroup per (group, block, k1) row.
-// Stockham autosort in LDS (ping-pong), mixed radices R0*R1*R2*R3 = M; the first pass reads the two spectra from global
+// Stockham autosort in LDS (one buffer, see stockham_pass), mixed radices R0*R1*R2*R3 = M; the first pass reads the two spectra from global
 // memory and multiplies them (K2), so the product never exists in HBM; the last pass writes the row.  Thread j of a
 // radix-R pass with Ns = product of the previous radices:  k = j mod Ns; inputs in[j + t M/R] * W_{Ns R}^{-k t};
 // R-point DFT; outputs out[(j div Ns) Ns R + k + t Ns].
-template <int R, bool LAST>
-__device__ __forceinline__ void stockham_pass(const v2* __restrict__ in, v2* __restrict__ out, float2* __restrict__ gz,
-                                              const v2* __restrict__ twm, int Ns, int M) {
-  const int nb = M / R;
+// Twiddles of the pass with (Ns, R) live in their own LDS table twp[(t-1) Ns + k] = conj(W_{Ns R}^{k t}), k < Ns: consecutive
+// lanes read consecutive words (indexing one shared W_M table by k t M/(Ns R) put up to 32 lanes on one bank).
+template <int R, int NT>
+__device__ __forceinline__ void fill_pass_twiddles(v2* __restrict__ twp, const float2* __restrict__ twm_g, int Ns, int M) {
   const int step = M / (Ns * R);
-  for (int j = threadIdx.x; j < nb; j += kBlock) {
-    const int k = j % Ns;
-    v2 x[R], wv[R];
+  for (int q = threadIdx.x; q < (R - 1) * Ns; q += NT) {
+    const int t = q / Ns + 1, k = q - (t - 1) * Ns;
+    const float2 w = twm_g[k * t * step];          // k t step < M
+    twp[q] = v2{w.x, -w.y};
+  }
+}
+
+// One radix-R pass, in place: every thread pulls its butterflies' inputs into registers, the workgroup synchronises, then the
+// outputs overwrite the same buffer (autosort order).  One buffer instead of a ping-pong pair keeps the workgroup at
+// 2 M complex of LDS (row + twiddles) so five of them fit a CU.  LAST writes the row to global memory instead.
+template <int R, bool LAST, int M, int NT>
+__device__ __forceinline__ void stockham_pass(v2* __restrict__ buf, float2* __restrict__ gz, const v2* __restrict__ twp, int Ns) {
+  constexpr int nb = M / R;
+  constexpr int iters = (nb + NT - 1) / NT;
+  v2 x[iters][R];
 #pragma unroll
-    for (int t = 0; t < R; t++) { x[t] = in[j + t * nb]; if (t) wv[t] = twm[k * t * step]; }          // k t step < M
+  for (int it = 0; it < iters; it++) {
+    const int j = threadIdx.x + it * NT;
+    if (j < nb) {
+      const int k = j % Ns;
+      v2 wv[R];
 #pragma unroll
-    for (int t = 1; t < R; t++) x[t] = cmul(x[t], wv[t]);
-    SmallDft<R, true>::run(x);
-    const int j0 = (j / Ns) * Ns * R + k;
+      for (int t = 0; t < R; t++) { x[it][t] = buf[j + t * nb]; if (t) wv[t] = twp[(t - 1) * Ns + k]; }      // conj(W_{Ns R}^{k t})
 #pragma unroll
-    for (int t = 0; t < R; t++) {
-      if (LAST) gz[j0 + t * Ns] = make_float2(x[t].x, x[t].y);
-      else out[j0 + t * Ns] = x[t];
+      for (int t = 1; t < R; t++) x[it][t] = cmul(x[it][t], wv[t]);
+      SmallDft<R, true>::run(x[it]);
+    }
+  }
+  if (!LAST) __syncthreads();                      // all inputs are in registers
+#pragma unroll
+  for (int it = 0; it < iters; it++) {
+    const int j = threadIdx.x + it * NT;
+    if (j < nb) {
+      const int k = j % Ns;
+      const int j0 = (j / Ns) * Ns * R + k;
+#pragma unroll
+      for (int t = 0; t < R; t++) {
+        if (LAST) gz[j0 + t * Ns] = make_float2(x[it][t].x, x[it][t].y);
+        else buf[j0 + t * Ns] = x[it][t];
+      }
     }
   }
 }
@@ -190,20 +217,24 @@ __device__ __forceinline__ void stockham_pass(const v2* __restrict__ in, v2* __r
 // the row pointer changes, i.e. across an epoch or frequency-set boundary).  Consecutive workgroups share k1 and the item
 // chunk, so the pch code-spectrum rows they read stay in every XCD's L2.  [g0, g0+ng) is the range of (e,p,d) groups whose
 // Z rows exist in this workspace pass; anything outside is skipped.
-template <int R0, int R1, int R2, int R3>
-__global__ __launch_bounds__(kBlock) void split_inner_corr_kernel(const float2* __restrict__ X, const float2* __restrict__ C,
+// NT threads per workgroup: 256 for M = 1980 (180..495 butterflies per pass), 128 for M = 990 (90..495).
+template <int R0, int R1, int R2, int R3, int NT>
+__global__ __launch_bounds__(NT) void split_inner_corr_kernel(const float2* __restrict__ X, const float2* __restrict__ C,
                                                                    float2* __restrict__ Z, const int* __restrict__ items,
                                                                    const int* __restrict__ fset, const float2* __restrict__ twm_g,
                                                                    long g0, long ng, long ep_first, int nblk_ep, int pch, int P, int F,
                                                                    int D, int B, int R) {
   constexpr int M = R0 * R1 * R2 * R3;
   constexpr int nb0 = M / R0;
-  static_assert(nb0 <= kBlock, "first pass: one radix-R0 butterfly per thread");
+  static_assert(nb0 <= NT, "first pass: one radix-R0 butterfly per thread");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v2* buf0 = reinterpret_cast<v2*>(smem);
-  v2* buf1 = buf0 + M;
-  v2* twm = buf1 + M;                              // conj(W_M^k), k < M
-  for (int k = threadIdx.x; k < M; k += kBlock) { const float2 w = twm_g[k]; twm[k] = v2{w.x, -w.y}; }
+  v2* tw1 = buf0 + M;                              // per-pass twiddle tables, M - R0 entries in all
+  v2* tw2 = tw1 + (R1 - 1) * R0;
+  v2* tw3 = tw2 + (R2 - 1) * R0 * R1;
+  fill_pass_twiddles<R1, NT>(tw1, twm_g, R0, M);
+  fill_pass_twiddles<R2, NT>(tw2, twm_g, R0 * R1, M);
+  fill_pass_twiddles<R3, NT>(tw3, twm_g, R0 * R1 * R2, M);
   unsigned blk = blockIdx.x;                       // 32-bit index math: 64-bit divisions cost ~100 scalar ops each
   const int b = (int)(blk % (unsigned)B);
   blk /= (unsigned)B;
@@ -243,11 +274,11 @@ __global__ __launch_bounds__(kBlock) void split_inner_corr_kernel(const float2* 
     }
     have = gx;
     __syncthreads();
-    stockham_pass<R1, false>(buf0, buf1, nullptr, twm, R0, M);
+    stockham_pass<R1, false, M, NT>(buf0, nullptr, tw1, R0);
     __syncthreads();
-    stockham_pass<R2, false>(buf1, buf0, nullptr, twm, R0 * R1, M);
+    stockham_pass<R2, false, M, NT>(buf0, nullptr, tw2, R0 * R1);
     __syncthreads();
-    stockham_pass<R3, true>(buf0, nullptr, gz, twm, R0 * R1 * R2, M);
+    stockham_pass<R3, true, M, NT>(buf0, gz, tw3, R0 * R1 * R2);
     __syncthreads();                               // buf0 is rewritten by the next item's first pass
   }
 }
@@ -320,7 +351,7 @@ int split_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* C, const
   const float2* twm;
   int rc = inner_twiddles(ctx, M, &twm);
   if (rc != GACQ_OK) return rc;
-  const size_t smem = sizeof(float2) * 3 * (size_t)M;
+  const size_t smem = sizeof(float2) * 2 * (size_t)M;
   // (epoch, item) rows touched by this pass, cut into chunks of pch per workgroup; >= ~2048 workgroups, <= 8 items each
   const long ep_first = g0 / D, ep_last = (g0 + ng - 1) / D;
   const long nep = ep_last - ep_first + 1;
@@ -329,10 +360,10 @@ int split_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* C, const
   const int nblk_ep = (int)((nep + pch - 1) / pch);
   const dim3 grid((unsigned)((long)R * nblk_ep * D * B));
   if (M == 1980)
-    hipLaunchKernelGGL((split_inner_corr_kernel<11, 9, 5, 4>), grid, dim3(kBlock), smem, ctx->stream, X, C, Z, d_items, d_fset, twm, g0, ng,
+    hipLaunchKernelGGL((split_inner_corr_kernel<11, 9, 5, 4, 256>), grid, dim3(256), smem, ctx->stream, X, C, Z, d_items, d_fset, twm, g0, ng,
                        ep_first, nblk_ep, pch, P, F, D, B, R);
   else if (M == 990)
-    hipLaunchKernelGGL((split_inner_corr_kernel<11, 9, 5, 2>), grid, dim3(kBlock), smem, ctx->stream, X, C, Z, d_items, d_fset, twm, g0, ng,
+    hipLaunchKernelGGL((split_inner_corr_kernel<11, 9, 5, 2, 128>), grid, dim3(128), smem, ctx->stream, X, C, Z, d_items, d_fset, twm, g0, ng,
                        ep_first, nblk_ep, pch, P, F, D, B, R);
   else
     return set_error(ctx, GACQ_ERR_UNSUPPORTED, "fused inner transforms: M=%d not supported", M);
