@@ -91,6 +91,10 @@ int lds_prepare_spectra(gacq_ctx* ctx, const float2* natural, float2* perm, int 
 int lds_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n, int N, const double* d_freq,
                 int FD, int B, const float2* tab, float2* X);
 // rows[(e*P + p)*D + d] = reduce_k sum_b | IFFT_N(C_p * X[e,f(p),d,b]) | / N
+// N = 16384 with one carrier per item (F == P): forward + correlate in one kernel, no X buffer
+bool lds_fused_supported(int N, int P, int F);
+int lds_fused_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n, int N, const float2* spectra, const int* d_items,
+                     const int* d_fset, const double* d_freq, const float2* tab, int nitems, int D, int B, RowRec* rows);
 int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const int* d_items, const int* d_fset,
                   int nepoch, int nitems, int F, int D, int B, int N, RowRec* rows);
 

@@ -626,9 +626,10 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
     return set_error(ctx, GACQ_ERR_UNSUPPORTED, "engine 3 (split with rocFFT inner transforms) does not support N=%d", N);
 
   // epochs per pass so that the forward-spectra buffer respects the workspace limit
+  const bool fused16k = use_lds && lds_fused_supported(N, P, F);      // one carrier per item: no forward-spectra buffer at all
   const size_t x_epoch_bytes = sizeof(float2) * (size_t)F * D * B * N;
   int Ec = (int)std::max<size_t>(1, std::min<size_t>((size_t)nepoch, ctx->ws_limit / std::max<size_t>(1, x_epoch_bytes)));
-  if ((rc = ensure(ctx, ctx->X, x_epoch_bytes * Ec)) != GACQ_OK) return rc;
+  if (!fused16k && (rc = ensure(ctx, ctx->X, x_epoch_bytes * Ec)) != GACQ_OK) return rc;
   if ((rc = ensure(ctx, ctx->rows, sizeof(RowRec) * (size_t)Ec * P * D)) != GACQ_OK) return rc;
 
   const int chunksN = (N + kBlock * 8 - 1) / (kBlock * 8);
@@ -638,7 +639,13 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
     float2* X = (float2*)ctx->X.p;
     RowRec* rows = (RowRec*)ctx->rows.p;
     const long rows_x = (long)ne * F * D * B;
-    if (use_lds) {
+    if (fused16k) {
+      stage_begin(ctx, 6);
+      rc = lds_fused_search(ctx, xe, nsamp, ne, n, N, sig->spectra_lds, (const int*)ctx->items.p, (const int*)ctx->fset.p,
+                            (const double*)ctx->freq.p, (const float2*)ctx->tab.p, P, D, B, rows);
+      stage_end(ctx);
+      if (rc != GACQ_OK) return rc;
+    } else if (use_lds) {
       stage_begin(ctx, 0);
       rc = lds_forward(ctx, xe, nsamp, ne, n, N, (const double*)ctx->freq.p, F * D, B, (const float2*)ctx->tab.p, X);
       stage_end(ctx);

@@ -339,6 +339,97 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_correlate_kernel(const flo
   }
 }
 
+// Fused search for item lists in which every item has its own carrier (F == P: the GLONASS FDMA channels, or a single
+// item): the forward spectrum of (e, f, d, b) is used by exactly one item, so writing it to HBM and reading it back
+// (8 N bytes each way per row) buys nothing.  Workgroup = (epoch, Doppler bin, item); per block b: mix + forward FFT,
+// one LDS pass back to natural lane order, conj * C_p, inverse FFT, |.| accumulated in registers.  Same arithmetic in the
+// same order as lds16k_forward_kernel + lds16k_correlate_kernel.
+__global__ __launch_bounds__(kBigThreads) void lds16k_fused_kernel(const float2* __restrict__ x, size_t epoch_stride,
+                                                                    const float2* __restrict__ C, const int* __restrict__ items,
+                                                                    const int* __restrict__ fset, const double* __restrict__ freq,
+                                                                    const float2* __restrict__ nco_tab,
+                                                                    const float2* __restrict__ twn, RowRec* __restrict__ rows, int n,
+                                                                    int P, int D, int B) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v2* lds = reinterpret_cast<v2*>(smem);
+  __shared__ float s_peak[kBigThreads / 64];
+  __shared__ int s_idx[kBigThreads / 64];
+  __shared__ double s_sum[kBigThreads / 64];
+  const int t = threadIdx.x;
+  unsigned blk = blockIdx.x;                          // ((e*D + d)*P + p): the P items of one (e, d) run side by side
+  const int p = (int)(blk % (unsigned)P);
+  blk /= (unsigned)P;
+  const int d = (int)(blk % (unsigned)D);
+  const long e = blk / (unsigned)D;
+  const double f = freq[(long)fset[p] * D + d];
+  const __amdgpu_buffer_rsrc_t cres = big_rsrc(C + (long)items[p] * kBig);
+  const v2 base = ld2(twn + t);
+  const unsigned lane_off = (unsigned)t * 16u;
+  const float inv_n = 1.0f / (float)kBig;
+  const int lane = (t >> 8) + 4 * (t & 255);          // natural index (mod 1024) this lane holds after a transform
+  float q[kR];
+#pragma unroll
+  for (int k = 0; k < kR; k++) q[k] = 0.f;
+  for (int b = 0; b < B; b++) {
+    const float2* src = x + e * epoch_stride + (size_t)b * n;
+    v2 v[kR], w[kR];
+#pragma unroll
+    for (int j = 0; j < kR; j++) {
+      const int i = t + 1024 * j;
+      v[j] = ld2(src + i);
+      w[j] = ld2(nco_tab + nco_index(f, i));          // gnsstools/nco.py:6-9
+    }
+#pragma unroll
+    for (int j = 0; j < kR; j++) v[j] = cmul(v[j], w[j]);
+    fft16k<false>(v, lds, twn, base);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kR; k++) lds[lane + 1024 * k] = v[rev16(k)];
+    __syncthreads();
+    v2 c[kR];
+#pragma unroll
+    for (int jp = 0; jp < kR / 2; jp++) ld_pair_big(cres, lane_off, jp, c[2 * jp], c[2 * jp + 1]);
+#pragma unroll
+    for (int j = 0; j < kR; j++) { const v2 a = lds[t + 1024 * j]; v[j] = v2{a.x, -a.y}; }      // np.conj(fft.fft(b))
+    __syncthreads();                                  // natural-order reads done before the inverse reuses the buffer
+#pragma unroll
+    for (int j = 0; j < kR; j++) v[j] = cmul(c[j], v[j]);
+    fft16k<true>(v, lds, twn, base);
+#pragma unroll
+    for (int k = 0; k < kR; k++) {
+      const v2 r = v[rev16(k)];
+      q[k] += __builtin_amdgcn_sqrtf(r.x * r.x + r.y * r.y) * inv_n;
+    }
+    __syncthreads();                                  // the inverse transform's last LDS reads are complete
+  }
+  float peak = q[0];
+  int idx = lane;
+  float sum_f = q[0];
+#pragma unroll
+  for (int k = 1; k < kR; k++) {
+    if (q[k] > peak) { peak = q[k]; idx = lane + 1024 * k; }
+    sum_f += q[k];
+  }
+  const unsigned pbits = __builtin_bit_cast(unsigned, peak);
+  const unsigned wmax = wave_max_u32(pbits);
+  idx = (int)wave_min_u32(pbits == wmax ? (unsigned)idx : 0xffffffffu);
+  peak = __builtin_bit_cast(float, wmax);
+  double sum = (double)wave_add_f32(sum_f);
+  if ((t & 63) == 0) { s_peak[t >> 6] = peak; s_idx[t >> 6] = idx; s_sum[t >> 6] = sum; }
+  __syncthreads();
+  if (t == 0) {
+    for (int w = 1; w < kBigThreads / 64; w++) {
+      if (s_peak[w] > peak || (s_peak[w] == peak && s_idx[w] < idx)) { peak = s_peak[w]; idx = s_idx[w]; }
+      sum += s_sum[w];
+    }
+    RowRec r;
+    r.peak = peak;
+    r.idx = idx;
+    r.sum = sum;
+    rows[(e * P + p) * (long)D + d] = r;
+  }
+}
+
 // ---- inner transforms of the split engine (N = R * 4096, gacq_split.hip) -----------------------------
 // In-place forward FFT of natural-order rows (the outer stage's A[k1][n2]); output in the lane-pair layout,
 // conjugated for sample spectra (CONJ) and plain for code spectra.
@@ -638,6 +729,21 @@ int lds_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n,
   if (rc != GACQ_OK) return rc;
   const long rows = (long)nepoch * FD * B;
   hipLaunchKernelGGL(lds_forward_kernel, dim3((unsigned)rows), dim3(kBlock), 0, ctx->stream, x, nsamp, X, d_freq, tab, tw, n, FD, B);
+  GACQ_HIP(ctx, hipGetLastError());
+  return GACQ_OK;
+}
+
+bool lds_fused_supported(int N, int P, int F) { return N == kBig && F == P && !getenv("GACQ_NO_FUSED_16K"); }
+
+int lds_fused_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n, int N, const float2* spectra, const int* d_items,
+                     const int* d_fset, const double* d_freq, const float2* tab, int nitems, int D, int B, RowRec* rows) {
+  if (N != kBig) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "fused LDS search: N=%d not supported", N);
+  const float2* twn;
+  int rc = twiddle_cache(ctx, "W16384_lo", kBig, 1024, &twn);
+  if (rc != GACQ_OK) return rc;
+  GACQ_HIP(ctx, hipFuncSetAttribute((const void*)lds16k_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes));
+  hipLaunchKernelGGL(lds16k_fused_kernel, dim3((unsigned)((long)nepoch * D * nitems)), dim3(kBigThreads), kBigLdsBytes, ctx->stream, x,
+                     nsamp, spectra, d_items, d_fset, d_freq, tab, twn, rows, n, nitems, D, B);
   GACQ_HIP(ctx, hipGetLastError());
   return GACQ_OK;
 }

@@ -164,6 +164,33 @@ def test_batched_device_path_equals_single_searches(engine):
         engine.set_engine(0)
 
 
+def test_glonass_fused_16k_kernel_equals_two_kernel_path(engine):
+    """One carrier per item (FDMA channels): forward + correlate run in one kernel without the X buffer.  Same arithmetic
+    in the same order, so the peak records must be bit-identical to the forward-kernel + correlate-kernel path."""
+    import os
+    import torch
+    from gnss_dsp_tools_amd import acquire, signals, synth
+    sig = signals.get("glonass-l1")
+    items = [-7, -3, 0, 2, 6]
+    dop = acquire.doppler_grid([-3000.0, 3000.0, 500.0])
+    B = 3
+    xs = synth.make_epochs(sig, B, 99, synth.default_sats(items), 2)
+    xd = torch.from_numpy(xs).to("cuda:0")
+    try:
+        engine.set_profiling(True)
+        engine.reset_stage_times()
+        fused = engine.search_batch_dev(sig, xd, items, dop, B).cpu().numpy()
+        assert engine.stage_times()["mix_nco"][1] == 0                 # no separate forward launch
+        os.environ["GACQ_NO_FUSED_16K"] = "1"
+        engine.reset_stage_times()
+        plain = engine.search_batch_dev(sig, xd, items, dop, B).cpu().numpy()
+        assert engine.stage_times()["mix_nco"][1] == 1
+    finally:
+        os.environ.pop("GACQ_NO_FUSED_16K", None)
+        engine.set_profiling(False)
+    assert fused.tobytes() == plain.tobytes()
+
+
 def test_finalize_shard_merge(engine):
     """Doppler grid cut into shards, searched separately, merged by gacq_finalize == unsharded search.
     This is the cross-GPU exchange step exercised on one device."""
