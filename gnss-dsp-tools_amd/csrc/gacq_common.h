@@ -49,6 +49,7 @@ struct gacq_ctx {
   size_t ws_limit = (size_t)4 << 30;
   std::map<std::pair<long, long>, gacq::FftPlan> plans;   // (N * 2 + inverse, batch)
   gacq::DevBuf tab, xstage, X, Y, rows, freq, fset, items, out_peaks, d0, partial, fe_a, fe_b, fe_taps;
+  gacq::DevBuf pin_x, pin_peaks;       // pinned host staging for the host-buffer entry point (gacq_search)
   bool profiling = false;
   double stage_ms[GACQ_NSTAGES] = {0};
   long stage_n[GACQ_NSTAGES] = {0};
@@ -76,6 +77,7 @@ namespace gacq {
 
 int set_error(gacq_ctx* ctx, int code, const char* fmt, ...);
 int ensure(gacq_ctx* ctx, DevBuf& b, size_t bytes);
+int ensure_pinned(gacq_ctx* ctx, DevBuf& b, size_t bytes);      // hipHostMalloc'd, device-accessible
 // W_N^k = exp(-2 pi i k / N) for k < count, fp64-evaluated and rounded once to fp32; cached per ctx under `key`
 int twiddle_cache(gacq_ctx* ctx, const std::string& key, int N, int count, const float2** out);
 // arbitrary constant bytes cached per ctx under `key` (uploaded on first use)

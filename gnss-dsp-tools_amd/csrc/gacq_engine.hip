@@ -20,6 +20,7 @@
 using namespace gacq;
 
 namespace {
+constexpr size_t kPinnedStageMax = 1u << 20;     // host inputs up to 1 MiB are staged through pinned memory
 thread_local std::string g_last_error;     // last error of calls made without a ctx, per calling thread
 std::once_flag g_rocfft_once;
 const char* kStageNames[GACQ_NSTAGES] = {"mix_nco", "rocfft_forward", "conj_mul", "rocfft_inverse",
@@ -53,6 +54,20 @@ int ensure(gacq_ctx* ctx, DevBuf& b, size_t bytes) {
     want = bytes;
     GACQ_HIP(ctx, hipMalloc(&b.p, want));
   }
+  b.cap = want;
+  return GACQ_OK;
+}
+
+int ensure_pinned(gacq_ctx* ctx, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return GACQ_OK;
+  if (b.p) {
+    GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GACQ_HIP(ctx, hipHostFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  const size_t want = std::max<size_t>(bytes + bytes / 8, 4096);
+  GACQ_HIP(ctx, hipHostMalloc(&b.p, want, hipHostMallocDefault));
   b.cap = want;
   return GACQ_OK;
 }
@@ -366,6 +381,8 @@ void gacq_destroy(gacq_ctx* ctx) {
   for (auto& ev : ctx->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
   DevBuf* bufs[] = {&ctx->tab, &ctx->xstage, &ctx->X, &ctx->Y, &ctx->rows, &ctx->freq, &ctx->fset, &ctx->items, &ctx->out_peaks, &ctx->d0, &ctx->partial, &ctx->fe_a, &ctx->fe_b, &ctx->fe_taps};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
+  if (ctx->pin_x.p) (void)hipHostFree(ctx->pin_x.p);
+  if (ctx->pin_peaks.p) (void)hipHostFree(ctx->pin_peaks.p);
   for (auto& kv : ctx->tables) if (kv.second.p) (void)hipFree(kv.second.p);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -851,14 +868,22 @@ int gacq_search(gacq_sig* sig, const float* x_iq, size_t nsamp, const int* items
   const size_t need = (size_t)(blocks + (sig->desc.pad ? 1 : 0)) * sig->desc.n;
   const size_t take = std::max<size_t>(need, 1);
   if ((rc = ensure(ctx, ctx->xstage, sizeof(float2) * take)) != GACQ_OK) return rc;
-  if ((rc = ensure(ctx, ctx->out_peaks, sizeof(gacq_peak) * nitems)) != GACQ_OK) return rc;
-  if (need) GACQ_HIP(ctx, hipMemcpyAsync(ctx->xstage.p, x_iq, sizeof(float2) * need, hipMemcpyHostToDevice, ctx->stream));
-  rc = gacq_search_batch_dev(sig, ctx->xstage.p, take, 1, items, nitems, dopplers, nd, item_bias_hz, blocks, ctx->out_peaks.p);
+  if ((rc = ensure_pinned(ctx, ctx->pin_peaks, sizeof(gacq_peak) * nitems)) != GACQ_OK) return rc;
+  // Small inputs go through a pinned staging buffer (one host memcpy, then a true async DMA); a pageable hipMemcpyAsync
+  // stages internally and costs ~10 us more per call.  Large inputs are copied directly.
+  const size_t xbytes = sizeof(float2) * need;
+  const void* src = x_iq;
+  if (need && xbytes <= kPinnedStageMax) {
+    if ((rc = ensure_pinned(ctx, ctx->pin_x, xbytes)) != GACQ_OK) return rc;
+    std::memcpy(ctx->pin_x.p, x_iq, xbytes);
+    src = ctx->pin_x.p;
+  }
+  if (need) GACQ_HIP(ctx, hipMemcpyAsync(ctx->xstage.p, src, xbytes, hipMemcpyHostToDevice, ctx->stream));
+  // the Doppler scan writes its 16-byte records straight into device-visible pinned host memory: no D2H copy
+  rc = gacq_search_batch_dev(sig, ctx->xstage.p, take, 1, items, nitems, dopplers, nd, item_bias_hz, blocks, ctx->pin_peaks.p);
   if (rc != GACQ_OK) return rc;
-  std::vector<gacq_peak> peaks(nitems);
-  GACQ_HIP(ctx, hipMemcpyAsync(peaks.data(), ctx->out_peaks.p, sizeof(gacq_peak) * nitems, hipMemcpyDeviceToHost, ctx->stream));
   GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return gacq_finalize(&sig->desc, peaks.data(), 1, nullptr, nitems, dopplers, nd, out);
+  return gacq_finalize(&sig->desc, (const gacq_peak*)ctx->pin_peaks.p, 1, nullptr, nitems, dopplers, nd, out);
 }
 
 int gacq_debug_row(gacq_sig* sig, const float* x_iq, size_t nsamp, int item, double doppler, double bias_hz, int blocks,
@@ -874,7 +899,10 @@ int gacq_debug_row(gacq_sig* sig, const float* x_iq, size_t nsamp, int item, dou
   if ((rc = ensure(ctx, ctx->out_peaks, sizeof(gacq_peak))) != GACQ_OK) return rc;
   float* d_q = nullptr;
   GACQ_HIP(ctx, hipMalloc((void**)&d_q, sizeof(float) * sig->N));
-  GACQ_HIP(ctx, hipMemcpyAsync(ctx->xstage.p, x_iq, sizeof(float2) * need, hipMemcpyHostToDevice, ctx->stream));
+  if (hipMemcpyAsync(ctx->xstage.p, x_iq, sizeof(float2) * need, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+    (void)hipFree(d_q);
+    return set_error(ctx, GACQ_ERR_HIP, "gacq_debug_row: H2D failed");
+  }
   const int saved = ctx->engine;
   ctx->engine = (saved == 3 || saved == 4) ? saved : 1;      // row dump: rocFFT pipeline and the split engines
   rc = launch_search(sig, (const float2*)ctx->xstage.p, need, 1, &item, 1, &doppler, 1, bias_hz != 0.0 ? &bias_hz : nullptr, blocks,

@@ -179,11 +179,15 @@ def test_glonass_fused_16k_kernel_equals_two_kernel_path(engine):
     try:
         engine.set_profiling(True)
         engine.reset_stage_times()
-        fused = engine.search_batch_dev(sig, xd, items, dop, B).cpu().numpy()
+        fused = engine.search_batch_dev(sig, xd, items, dop, B)
+        torch.cuda.synchronize()                                       # the engine launches on its own stream
+        fused = fused.cpu().numpy()
         assert engine.stage_times()["mix_nco"][1] == 0                 # no separate forward launch
         os.environ["GACQ_NO_FUSED_16K"] = "1"
         engine.reset_stage_times()
-        plain = engine.search_batch_dev(sig, xd, items, dop, B).cpu().numpy()
+        plain = engine.search_batch_dev(sig, xd, items, dop, B)
+        torch.cuda.synchronize()
+        plain = plain.cpu().numpy()
         assert engine.stage_times()["mix_nco"][1] == 1
     finally:
         os.environ.pop("GACQ_NO_FUSED_16K", None)
