@@ -13,6 +13,7 @@
 #include "gacq_common.h"
 
 #include <cmath>
+#include <cstring>
 
 using namespace gacq;
 
@@ -118,19 +119,30 @@ extern "C" int gacq_correlate_batch(gacq_ctx* ctx, const float* x_iq, size_t n, 
   const int chunks = (int)((n + kTrChunk - 1) / kTrChunk);
   const size_t npart = (size_t)K * chunks;
   int rc;
-  if ((rc = ensure(ctx, ctx->xstage, sizeof(float2) * n)) != GACQ_OK) return rc;
-  if ((rc = ensure(ctx, ctx->partial, sizeof(double2) * (npart + K) + sizeof(CorrSpec) * (size_t)K)) != GACQ_OK) return rc;
-  double2* d_partial = (double2*)ctx->partial.p;
-  double2* d_out = d_partial + npart;
-  CorrSpec* d_specs = (CorrSpec*)(d_out + K);
-  GACQ_HIP(ctx, hipMemcpyAsync(ctx->xstage.p, x_iq, sizeof(float2) * n, hipMemcpyHostToDevice, st));
-  GACQ_HIP(ctx, hipMemcpyAsync(d_specs, specs.data(), sizeof(CorrSpec) * (size_t)K, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(correlate_partial_kernel, dim3((unsigned)npart), dim3(kTrBlock), 0, st, (const float2*)ctx->xstage.p, (long)n,
-                     (const CorrSpec*)d_specs, L, kind, chunks, d_partial);
+  // one pinned staging block [specs | x] -> one H2D copy; results land in device-visible pinned memory (no D2H copy);
+  // a single chunk per correlator (blocks up to kTrChunk samples, the tracking case) needs no second kernel
+  const size_t spec_bytes = (sizeof(CorrSpec) * (size_t)K + 15) & ~(size_t)15;
+  const size_t in_bytes = spec_bytes + sizeof(float2) * (size_t)n;
+  if ((rc = ensure(ctx, ctx->xstage, in_bytes)) != GACQ_OK) return rc;
+  if ((rc = ensure_pinned(ctx, ctx->pin_x, in_bytes)) != GACQ_OK) return rc;
+  if ((rc = ensure_pinned(ctx, ctx->pin_peaks, sizeof(double2) * (size_t)K)) != GACQ_OK) return rc;
+  if ((rc = ensure(ctx, ctx->partial, sizeof(double2) * npart)) != GACQ_OK) return rc;
+  std::memcpy(ctx->pin_x.p, specs.data(), sizeof(CorrSpec) * (size_t)K);
+  std::memcpy((char*)ctx->pin_x.p + spec_bytes, x_iq, sizeof(float2) * (size_t)n);
+  GACQ_HIP(ctx, hipMemcpyAsync(ctx->xstage.p, ctx->pin_x.p, in_bytes, hipMemcpyHostToDevice, st));
+  const CorrSpec* d_specs = (const CorrSpec*)ctx->xstage.p;
+  const float2* d_x = (const float2*)((const char*)ctx->xstage.p + spec_bytes);
+  double2* d_out = (double2*)ctx->pin_peaks.p;
+  double2* d_partial = chunks == 1 ? d_out : (double2*)ctx->partial.p;
+  hipLaunchKernelGGL(correlate_partial_kernel, dim3((unsigned)npart), dim3(kTrBlock), 0, st, d_x, (long)n, d_specs, L, kind, chunks,
+                     d_partial);
   GACQ_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(correlate_finish_kernel, dim3((unsigned)((K + 127) / 128)), dim3(128), 0, st, (const double2*)d_partial, d_out, K, chunks);
-  GACQ_HIP(ctx, hipGetLastError());
-  GACQ_HIP(ctx, hipMemcpyAsync(out_iq, d_out, sizeof(double2) * (size_t)K, hipMemcpyDeviceToHost, st));
+  if (chunks > 1) {
+    hipLaunchKernelGGL(correlate_finish_kernel, dim3((unsigned)((K + 127) / 128)), dim3(128), 0, st, (const double2*)d_partial, d_out, K,
+                       chunks);
+    GACQ_HIP(ctx, hipGetLastError());
+  }
   GACQ_HIP(ctx, hipStreamSynchronize(st));
+  std::memcpy(out_iq, ctx->pin_peaks.p, sizeof(double2) * (size_t)K);
   return GACQ_OK;
 }
