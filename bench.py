@@ -53,6 +53,10 @@ def stage_bytes(N, P, D, B, F=1):
     }
 
 
+def cells_step_1gpu(E, P, D, N):
+    return E * P * D * N
+
+
 def cpu_baseline(sig, xs, items, ds, ms, budget_s=12.0):
     """The oracle (numpy fp64 restatement of the reference, reference loop order) on this host, 1 core."""
     from oracle import acq_oracle           # checker / baseline only
@@ -251,6 +255,19 @@ def main():
         latency = {"search_all_32prn_us": t_all * 1e6, "search_1prn_us": t_one * 1e6,
                    "cells_per_s_single_epoch_pcie_inclusive": P * D * N / t_all}
         eng.use_torch_stream(dev)
+        # host-resident batches streamed through pinned double buffers (H2D of batch i+1 under the kernels of batch i)
+        from gnss_dsp_tools_amd import stream
+        st = stream.EpochStreamer(eng, sig, items, dop, B, E_total, xs.shape[1], depth=3, device=dev)
+        nb = 24
+        for _ in st.run(xs for _ in range(3)):
+            pass
+        t1 = time.perf_counter()
+        last = None
+        for last in st.run(xs for _ in range(nb)):
+            pass
+        t_stream = (time.perf_counter() - t1) / nb
+        latency["streamed_batches_pcie_inclusive"] = {"cells_per_s": cells_step_1gpu(E_total, P, D, N) / t_stream, "ms_per_batch": t_stream * 1e3,
+                                                      "epochs_per_batch": E_total, "h2d_bytes_per_batch": int(xs.nbytes)}
 
     out = None
     if rank == 0:

@@ -195,6 +195,30 @@ def test_glonass_fused_16k_kernel_equals_two_kernel_path(engine):
     assert fused.tobytes() == plain.tobytes()
 
 
+def test_streamed_host_batches_equal_resident_batches():
+    """EpochStreamer (pinned double buffers, copy stream overlapped with compute) returns, batch by batch, the records of a
+    plain device-resident gacq_search_batch_dev call on the same samples -- including after the staging slots wrap around."""
+    import torch
+    from gnss_dsp_tools_amd import acquire, signals, stream, synth
+    sig = signals.get("gps-l1")
+    items = [2, 5, 9, 17, 30]
+    dop = acquire.doppler_grid([-2000.0, 2000.0, 250.0])
+    E = 6
+    batches = [synth.make_epochs(sig, 1, 500 + 10 * k, synth.default_sats(items), E, nsamp=4096) for k in range(7)]
+    eng = acquire.Engine(0)
+    try:
+        st = stream.EpochStreamer(eng, sig, items, dop, 1, E, 4096, depth=3)
+        got = list(st.run(iter(batches)))
+        assert len(got) == len(batches)
+        for k, xs in enumerate(batches):
+            want = eng.search_batch_dev(sig, torch.from_numpy(xs).to("cuda:0"), items, dop, 1)
+            torch.cuda.synchronize()
+            want = want.cpu().numpy().view(acquire.PEAK_DTYPE).reshape(E, len(items))
+            assert got[k].tobytes() == want.tobytes(), k
+    finally:
+        eng.close()
+
+
 def test_finalize_shard_merge(engine):
     """Doppler grid cut into shards, searched separately, merged by gacq_finalize == unsharded search.
     This is the cross-GPU exchange step exercised on one device."""
