@@ -57,6 +57,20 @@ def cells_step_1gpu(E, P, D, N):
     return E * P * D * N
 
 
+def host_info():
+    """CPU model and library versions of the host the CPU baseline runs on."""
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    import scipy
+    return {"cpu_model": model, "cpu_count": os.cpu_count(), "numpy": np.__version__, "scipy": scipy.__version__}
+
+
 def cpu_baseline(sig, xs, items, ds, ms, budget_s=12.0):
     """The oracle (numpy fp64 restatement of the reference, reference loop order) on this host, 1 core."""
     from oracle import acq_oracle           # checker / baseline only
@@ -240,18 +254,19 @@ def main():
     if world == 1 and not args.no_latency:
         eng.set_stream(None)
         xh = base[0]
+        def median_call(fn, n=60):
+            ts = []
+            for _ in range(n):
+                t1 = time.perf_counter()
+                fn()
+                ts.append(time.perf_counter() - t1)
+            return float(np.median(ts))
         for _ in range(3):
             eng.search_all(sig, xh, items, ds, ms)
-        t1 = time.perf_counter()
-        for _ in range(20):
-            eng.search_all(sig, xh, items, ds, ms)
-        t_all = (time.perf_counter() - t1) / 20
+        t_all = median_call(lambda: eng.search_all(sig, xh, items, ds, ms))             # median of 60 calls
         for _ in range(3):
             eng.search(sig, xh, 7, ds, ms)              # builds the 1-PRN signal (code spectrum, FFT plan) once
-        t1 = time.perf_counter()
-        for _ in range(20):
-            eng.search(sig, xh, 7, ds, ms)
-        t_one = (time.perf_counter() - t1) / 20
+        t_one = median_call(lambda: eng.search(sig, xh, 7, ds, ms))
         latency = {"search_all_32prn_us": t_all * 1e6, "search_1prn_us": t_one * 1e6,
                    "cells_per_s_single_epoch_pcie_inclusive": P * D * N / t_all}
         eng.use_torch_stream(dev)
@@ -293,12 +308,15 @@ def main():
             "roofline": roofline,
             "valu": valu,
             "host_call_latency": latency,
-            "pipeline": {"a_pipe_bytes_per_step": a_pipe_step, "achieved_GBps": a_pipe_step / (dt / args.steps) / 1e9,
+            "pipeline": {"a_pipe_bytes_per_step": a_pipe_step,
+                         # compulsory I/O only: samples in, code spectra, 16-byte peak records out (SURVEY.md 8d "A_min")
+                         "a_min_bytes_per_step": E_total * B * N * 8 + P * N * 8 + E_total * P * 16, "achieved_GBps": a_pipe_step / (dt / args.steps) / 1e9,
                          "frac_of_8TBps": a_pipe_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS,
                          "us_per_search": dt / args.steps / E_total * 1e6, "stages": per_stage},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sig, base, items, ds, ms)
+            out["cpu_baseline"]["host"] = host_info()
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             try:
                 out["cpu_baseline_pool"] = cpu_baseline_pool(sig, base, items, ds, ms)

@@ -33,50 +33,77 @@ class ShardedSearch:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
+    def partition(self, nd, nitems):
+        """SURVEY 8e: cut the Doppler grid while every rank still gets >= 4 bins (forward FFTs are not duplicated);
+        otherwise cut the item list (each rank then repeats the forward transforms for its items)."""
+        if self.world == 1 or nd >= 4 * self.world or nitems < self.world:
+            return "doppler"
+        return "items"
+
+    def _launch(self, name, x, items, dopplers, blocks):
+        """Local part of one search.  Returns (local peaks, finish) where finish(gathered [world, ...]) -> merged peaks."""
+        import torch
+        dopplers = np.ascontiguousarray(dopplers, dtype=np.float64)
+        items = list(items)
+        run = self.local_fn
+        if run is None:
+            # kernels, the collective and the merge must share one stream: RCCL orders itself against torch's
+            # current stream only
+            self.engine.use_torch_stream(x.device)
+            run = self.engine.search_batch_dev
+        if self.partition(len(dopplers), len(items)) == "doppler":
+            b = doppler_bounds(len(dopplers), self.world)
+            local = run(name, x, items, dopplers[b[self.rank]:b[self.rank + 1]], blocks)
+
+            def finish(gathered):
+                if gathered.is_cuda:
+                    return self.engine.merge_peaks_dev(gathered, b[:-1])
+                return merge_peaks_host(gathered.numpy(), b[:-1])
+            return local, finish
+        # item split: every rank searches the whole Doppler grid for a contiguous slice of the items; slices are padded to
+        # a common length with "nothing found" records so that one fixed-size all-gather still does the exchange
+        ib = doppler_bounds(len(items), self.world)
+        width = max(ib[r + 1] - ib[r] for r in range(self.world))
+        mine = items[ib[self.rank]:ib[self.rank + 1]]
+        nepoch = x.shape[0]
+        local = torch.zeros((nepoch, width, 2), dtype=torch.float64, device=x.device)
+        local.view(torch.int64)[:, :, 1] = -1                        # idx = d_index = -1 (two int32 in one 8-byte word)
+        if mine:
+            local[:, :len(mine)] = run(name, x, mine, dopplers, blocks)
+
+        def finish(gathered):
+            return torch.cat([gathered[r, :, :ib[r + 1] - ib[r]] for r in range(self.world)], dim=1).contiguous()
+        return local, finish
+
+    def _exchange(self, local, async_op=False):
+        import torch
+        flat = local.contiguous().view(-1)
+        gathered = torch.empty(self.world * flat.numel(), dtype=local.dtype, device=local.device)
+        work = self.dist.all_gather_into_tensor(gathered, flat, group=self.group, async_op=async_op)      # the ONE collective
+        return gathered.view((self.world,) + tuple(local.shape)), work
+
+    def _solo(self):
+        return self.world == 1 and not (self.always_gather and self.dist.is_initialized())
+
     def search_batch(self, name, x, items, dopplers, blocks):
         """x: [nepoch, nsamp] complex64 tensor, identical on every rank (CUDA for the engine path).
         Returns the merged peaks tensor [nepoch, nitems, 2] (gacq_peak records, global Doppler index)
         on every rank."""
-        import torch
-        dopplers = np.ascontiguousarray(dopplers, dtype=np.float64)
-        b = doppler_bounds(len(dopplers), self.world)
-        lo, hi = b[self.rank], b[self.rank + 1]
-        if self.local_fn is not None:
-            local = self.local_fn(name, x, items, dopplers[lo:hi], blocks)
-        else:
-            # kernels, the collective and the merge must share one stream: RCCL orders itself against torch's
-            # current stream only
-            self.engine.use_torch_stream(x.device)
-            local = self.engine.search_batch_dev(name, x, items, dopplers[lo:hi], blocks)
-        if self.world == 1 and not (self.always_gather and self.dist.is_initialized()):
+        local, finish = self._launch(name, x, items, dopplers, blocks)
+        if self._solo():
             return local
-        flat = local.contiguous().view(-1)
-        gathered = torch.empty(self.world * flat.numel(), dtype=local.dtype, device=local.device)
-        self.dist.all_gather_into_tensor(gathered, flat, group=self.group)                  # the ONE collective
-        gathered = gathered.view((self.world,) + tuple(local.shape))
-        if gathered.is_cuda:
-            return self.engine.merge_peaks_dev(gathered, b[:-1])
-        return merge_peaks_host(gathered.numpy(), b[:-1])
+        gathered, _ = self._exchange(local)
+        return finish(gathered)
 
     def search_batch_async(self, name, x, items, dopplers, blocks):
         """Like search_batch, but the all-gather is issued asynchronously (RCCL runs it on its own stream once the local
         kernels are done) and the merge is deferred to PendingSearch.wait().  Launching the next search before waiting on
         the previous one overlaps the exchange of step i with the compute of step i+1."""
-        import torch
-        dopplers = np.ascontiguousarray(dopplers, dtype=np.float64)
-        b = doppler_bounds(len(dopplers), self.world)
-        lo, hi = b[self.rank], b[self.rank + 1]
-        if self.local_fn is not None:
-            local = self.local_fn(name, x, items, dopplers[lo:hi], blocks)
-        else:
-            self.engine.use_torch_stream(x.device)
-            local = self.engine.search_batch_dev(name, x, items, dopplers[lo:hi], blocks)
-        if self.world == 1 and not (self.always_gather and self.dist.is_initialized()):
-            return PendingSearch(self, local, None, None, b)
-        flat = local.contiguous().view(-1)
-        gathered = torch.empty(self.world * flat.numel(), dtype=local.dtype, device=local.device)
-        work = self.dist.all_gather_into_tensor(gathered, flat, group=self.group, async_op=True)     # the ONE collective
-        return PendingSearch(self, local, gathered.view((self.world,) + tuple(local.shape)), work, b)
+        local, finish = self._launch(name, x, items, dopplers, blocks)
+        if self._solo():
+            return PendingSearch(local, None, None, None)
+        gathered, work = self._exchange(local, async_op=True)
+        return PendingSearch(local, gathered, work, finish)
 
     def search_jobs(self, jobs):
         """Cold-start style multi-constellation search (BASELINE config 5): `jobs` is a list of dicts
@@ -121,8 +148,8 @@ class ShardedSearch:
 class PendingSearch:
     """A sharded search whose exchange may still be in flight (ShardedSearch.search_batch_async)."""
 
-    def __init__(self, owner, local, gathered, work, bounds):
-        self.owner, self.local, self.gathered, self.work, self.bounds = owner, local, gathered, work, bounds
+    def __init__(self, local, gathered, work, finish):
+        self.local, self.gathered, self.work, self.finish = local, gathered, work, finish
 
     def wait(self):
         """Merged peaks [nepoch, nitems, 2].  For RCCL, Work.wait() orders the current stream after the collective
@@ -131,9 +158,7 @@ class PendingSearch:
             return self.local
         if self.work is not None:
             self.work.wait()
-        if self.gathered.is_cuda:
-            return self.owner.engine.merge_peaks_dev(self.gathered, self.bounds[:-1])
-        return merge_peaks_host(self.gathered.numpy(), self.bounds[:-1])
+        return self.finish(self.gathered)
 
 
 def merge_peaks_host(gathered, shard_d0):

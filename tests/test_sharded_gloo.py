@@ -28,6 +28,8 @@ def _free_port():
     (3, "gps-l1", [3, 9], [1000.0, 2050.0, 150.0], 2, ""),
     (2, "glonass-l1", [-2, 5], [1200.0, 1900.0, 100.0], 1, ""),
     (2, "gps-l1", [3, 9], [1000.0, 2050.0, 150.0], 1, "GLOO_ASYNC"),
+    (2, "gps-l1", [3, 9, 4], [1400.0, 1700.0, 100.0], 1, ""),            # 3 bins < 4 per rank -> item split, ragged slices
+    (3, "glonass-l1", [-2, 5, 1, 0], [1300.0, 1700.0, 200.0], 1, "GLOO_ASYNC"),
 ])
 def test_sharded_search_equals_unsharded_oracle(tmp_path, world, name, items, ds, ms, mode):
     from gnss_dsp_tools_amd import signals, synth
