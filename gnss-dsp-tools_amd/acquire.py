@@ -16,6 +16,7 @@ import ctypes
 import numpy as np
 
 from . import _native as nat
+from . import codes
 from . import signals as _signals
 
 PEAK_DTYPE = np.dtype([("metric", "<f8"), ("idx", "<i4"), ("d_index", "<i4")])
@@ -96,6 +97,7 @@ class Engine:
         self._ctx = h
         self.device = int(device)
         self._signals = {}
+        self._families = {}
         if engine:
             self.set_engine(engine)
         if workspace_bytes:
@@ -137,9 +139,10 @@ class Engine:
         return out
 
     def close(self):
-        for s in self._signals.values():
+        for s in list(self._signals.values()) + [f for f in self._families.values() if f is not None]:
             s.close()
         self._signals.clear()
+        self._families.clear()
         if self._ctx:
             nat.lib.gacq_destroy(self._ctx)
             self._ctx = None
@@ -209,6 +212,50 @@ class Engine:
             dopplers.ctypes.data_as(nat.c_double_p), len(dopplers),
             bias.ctypes.data_as(nat.c_double_p) if bias is not None else None, blocks, res), self._ctx)
         return [_as_tuple(r) for r in res]
+
+    def search_family(self, names, x, items, doppler_search, ms):
+        """Signals that differ only in their code tables -- E1B + E1C, L5I + L5Q, E5aI + E5aQ, L1Cd + L1Cp ... -- searched
+        in ONE pass over x: the mix and the forward transforms are shared by all of them (BASELINE config 3 counts them
+        once), only the correlation rows multiply.  `items` is a list of item lists, one per name.  Returns one result list
+        per name, each identical to search_all(name, x, items_k, doppler_search, ms)."""
+        sigs = [_signals.get(n) if isinstance(n, str) else n for n in names]
+        if len(sigs) != len(items) or not sigs:
+            raise ValueError("search_family: one item list per signal name")
+        base = sigs[0]
+        shape = lambda g: (g.fs, g.n, g.pad, g.boc, g.normalised, g.fold, g.bias_hz, g.blocks(int(ms)), nat.check(nat.lib.gacq_code_length(g.code.encode())))
+        for g in sigs[1:]:
+            if shape(g) != shape(base):
+                raise ValueError("search_family: %s and %s differ in more than their code tables" % (base.name, g.name))
+        if base.bias_hz:
+            raise ValueError("search_family: FDMA signals share one code; use search_all")
+        lists = [[int(i) for i in it] for it in items]
+        key = (tuple(g.name for g in sigs), tuple(tuple(it) for it in lists))
+        fam = self._families.get(key)
+        if fam is None:
+            rows = [codes.chips(g.code, p) for g, it in zip(sigs, lists) for p in it]
+            total = len(rows)
+            fam = AcqSignal(self, base, list(range(total)), np.stack(rows).astype(np.uint8)) if total else None
+            self._families[key] = fam
+        if fam is None:
+            return [[] for _ in sigs]
+        total = len(fam.prns)
+        dopplers = doppler_grid(doppler_search)
+        blocks = max(base.blocks(int(ms)), 0)
+        need = base.samples_needed(blocks)
+        x = np.asarray(x)
+        if x.ndim != 1 or len(x) < need:
+            raise ValueError("operands could not be broadcast together: search needs %d samples, x has shape %r" % (need, x.shape))
+        xc = np.ascontiguousarray(x[:max(need, 1)], dtype=np.complex64)
+        idx = np.arange(total, dtype=np.int32)
+        res = (nat.Result * total)()
+        nat.check(nat.lib.gacq_search(fam._h, xc.ctypes.data_as(nat.c_float_p), len(xc), idx.ctypes.data_as(nat.c_int_p), total,
+                                      dopplers.ctypes.data_as(nat.c_double_p), len(dopplers), None, blocks, res), self._ctx)
+        flat = [_as_tuple(r) for r in res]
+        out, at = [], 0
+        for it in lists:
+            out.append(flat[at:at + len(it)])
+            at += len(it)
+        return out
 
     def debug_row(self, name, x, item, doppler, blocks):
         """Accumulated magnitude row q[0:N] of one (item, doppler) via the rocFFT pipeline."""

@@ -219,6 +219,29 @@ def test_streamed_host_batches_equal_resident_batches():
         eng.close()
 
 
+@pytest.mark.parametrize("names,items", [
+    (("galileo-e1b", "galileo-e1c"), ([1, 11, 19], [11, 4])),
+    (("gps-l5i", "gps-l5q"), ([3, 10], [10])),
+])
+def test_search_family_shares_forward_transforms_and_equals_separate_searches(engine, names, items):
+    """E1B + E1C (BASELINE config 3) and friends in one pass: same records as one search_all per signal."""
+    from gnss_dsp_tools_amd import signals, synth
+    sig = signals.get(names[0])
+    ds = [-1000.0, 1000.0, 250.0]
+    ms = 8 if "galileo" in names[0] else 1
+    B = sig.blocks(ms)
+    x = synth.make_iq(sig, B, 4321, [(items[0][1], 0.4, 310.0, 777)])
+    fam = engine.search_family(names, x, items, ds, ms)
+    assert len(fam) == len(names)
+    for name, it, got in zip(names, items, fam):
+        want = engine.search_all(name, x, it, ds, ms)
+        assert got == want, name
+    again = engine.search_family(names, x, items, ds, ms)            # cached family signal
+    assert again == fam
+    with pytest.raises(ValueError):
+        engine.search_family(("gps-l1", "gps-l5i"), x, ([1], [1]), ds, 1)
+
+
 def test_finalize_shard_merge(engine):
     """Doppler grid cut into shards, searched separately, merged by gacq_finalize == unsharded search.
     This is the cross-GPU exchange step exercised on one device."""
