@@ -333,6 +333,57 @@ def test_full_size_properties_config2(engine):
             assert np.all(base["idx"][:, c] == (-delay) % 4096), it
 
 
+FULL_SIZE = [
+    # BASELINE configs 3, 4, 5 at their full (P, D, B, N): name, items, doppler_search, ms (None = engine-level B = 1)
+    ("galileo-e1b", list(range(1, 37)), [-4000.0, 4000.0, 125.0], 8),
+    ("gps-l5i", list(range(1, 33)), [-7000.0, 7000.0, 200.0], 1),
+    ("beidou-b2ad", list(range(1, 64)), [-7000.0, 7000.0, 200.0], None),
+    ("beidou-b1i", list(range(1, 64)), [-10000.0, 10000.0, 100.0], 10),
+    ("glonass-l1", list(range(-7, 8)), [-10000.0, 10000.0, 100.0], 10),
+    ("galileo-e1b", list(range(1, 51)), [-10000.0, 10000.0, 100.0], 10),
+]
+
+
+@pytest.mark.parametrize("name,items,ds,ms", FULL_SIZE, ids=["cfg3-e1b", "cfg4-l5i", "cfg4-b2ad", "cfg5-b1i", "cfg5-glonass", "cfg5-e1b"])
+def test_full_size_properties_configs_3_4_5(engine, name, items, ds, ms):
+    """Full BASELINE shapes, too big for the oracle in a test: (a) the hand-written engine and the rocFFT pipeline (two
+    independent transform implementations) agree on every item's (lag, Doppler bin) and on the metric to 5e-6;
+    (b) linearity: 2.5 x the samples gives the same locations and 2.5 x the raw metric; (c) every injected satellite
+    is found at its delay."""
+    import torch
+    from gnss_dsp_tools_amd import acquire, signals, synth
+    sig = signals.get(name)
+    B = 1 if ms is None else sig.blocks(ms)
+    dop = acquire.doppler_grid(ds)
+    sats = synth.default_sats(items)
+    x = synth.make_iq(sig, B, 2468, sats, nsamp=sig.samples_needed(B))
+    xd = torch.from_numpy(x[None, :]).to("cuda:0")
+
+    def run(t, eng):
+        engine.set_engine(eng)
+        try:
+            pk = engine.search_batch_dev(sig, t, items, dop, B)
+            torch.cuda.synchronize()
+        finally:
+            engine.set_engine(0)
+        return pk.cpu().numpy().view(acquire.PEAK_DTYPE).reshape(len(items))
+
+    auto = run(xd, 0)
+    ref = run(xd, 1)
+    np.testing.assert_array_equal(auto["idx"], ref["idx"])
+    np.testing.assert_array_equal(auto["d_index"], ref["d_index"])
+    np.testing.assert_allclose(auto["metric"], ref["metric"], rtol=5e-6)
+    scaled = run((xd * 2.5).contiguous(), 0)
+    np.testing.assert_array_equal(scaled["idx"], auto["idx"])
+    np.testing.assert_array_equal(scaled["d_index"], auto["d_index"])
+    np.testing.assert_allclose(scaled["metric"], 2.5 * auto["metric"], rtol=5e-6)       # raw metrics (none of these is max/mean)
+    n = sig.n
+    for it, amp, f, delay in sats:
+        if amp >= 0.25:
+            # padded searches see two code periods in the 2n window: the peak sits at n - d or 2n - d (equal but for noise)
+            assert auto["idx"][items.index(it)] % n == (n - delay % n) % n, (it, delay)
+
+
 def test_bench_under_torchrun_single_rank_exercises_rccl_path():
     """The driver launches N>1 through torch.distributed.run; with one GPU the same launcher + --force-gather still
     exercises RCCL init, the all-gather of peak records on the engine's stream, the device-side merge and the
