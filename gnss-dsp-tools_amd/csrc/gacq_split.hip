@@ -81,10 +81,12 @@ __global__ __launch_bounds__(kBlock) void split_outer_forward_kernel(const float
 // ---- inverse outer stage + magnitude + reduce ------------------------------------------------------------
 // Z: [group][b][k1][n2] after the inner inverse transforms (unnormalised).  One workgroup handles 256 values of n2
 // of one group and emits a partial (peak, idx, sum) record; idx = M n1 + n2.
-template <int R, bool TW>
-__global__ __launch_bounds__(kBlock) void split_outer_inverse_kernel(const float2* __restrict__ Z, RowRec* __restrict__ partial,
-                                                                    const float2* __restrict__ tw, int M, int B, int chunks,
-                                                                    float inv_n, float* __restrict__ q_out) {
+// B1 (one block, no row dump): magnitudes are reduced as the DFT produces them instead of being accumulated in q[R]; that
+// and the 3-waves-per-SIMD register budget let a third wave hide the R strided loads of the other two.
+template <int R, bool TW, bool B1>
+__global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_inverse_kernel(
+    const float2* __restrict__ Z, RowRec* __restrict__ partial, const float2* __restrict__ tw, int M, int B, int chunks, float inv_n,
+    float* __restrict__ q_out) {
   __shared__ float s_peak[kBlock / 64];
   __shared__ int s_idx[kBlock / 64];
   __shared__ double s_sum[kBlock / 64];
@@ -109,6 +111,35 @@ __global__ __launch_bounds__(kBlock) void split_outer_inverse_kernel(const float
       const v2 wv = {wf.x, -wf.y};      // conj: W_N^{-n2}
       tp.init<R - 1>(wv);
     }
+    if (B1) {
+      if (TW) {
+#pragma unroll
+        for (int k1 = 1; k1 < R; k1++) v[k1] = tp.apply(v[k1], k1);
+      }
+      // outputs arrive as n1 = 0, then pairs (k, R-k) for the prime radices, in natural order otherwise: the first half is
+      // reduced on the fly, late arrivals (n1 > next expected) are parked so that the scan stays in ascending lag order
+      float late[R];
+      float sum_f = 0.f;
+      int expect = 0;
+      OuterDft<R, true>::run(v, [&](int n1, v2 val) {
+        const float m = __builtin_amdgcn_sqrtf(val.x * val.x + val.y * val.y) * inv_n;      // np.absolute(ifft(..)), 1/N folded in
+        if (n1 == expect) {
+          if (m > peak) { peak = m; idx = M * n1 + n2; }
+          sum_f += m;
+          expect++;
+        } else {
+          late[n1] = m;
+        }
+      });
+#pragma unroll
+      for (int n1 = 0; n1 < R; n1++) {
+        if (n1 >= expect) {                            // compile-time after unrolling: expect is a constant by now
+          if (late[n1] > peak) { peak = late[n1]; idx = M * n1 + n2; }
+          sum_f += late[n1];
+        }
+      }
+      sum = (double)sum_f;
+    } else {
     float q[R];
 #pragma unroll
     for (int k = 0; k < R; k++) q[k] = 0.f;
@@ -131,6 +162,7 @@ __global__ __launch_bounds__(kBlock) void split_outer_inverse_kernel(const float
       if (q[n1] > peak) { peak = q[n1]; idx = M * n1 + n2; }
       sum += (double)q[n1];
       if (q_out) q_out[M * n1 + n2] = q[n1];
+    }
     }
   }
 #pragma unroll
@@ -324,12 +356,16 @@ template <int R>
 int launch_inverse(gacq_ctx* ctx, const float2* Z, RowRec* partial, const float2* tw, int M, int B, long ng, float inv_n,
                    float* q_out, bool twiddle) {
   const int chunks = (M + kBlock - 1) / kBlock;
-  if (twiddle)
-    hipLaunchKernelGGL((split_outer_inverse_kernel<R, true>), dim3((unsigned)(ng * chunks)), dim3(kBlock), 0, ctx->stream, Z, partial,
-                       tw, M, B, chunks, inv_n, q_out);
+  const dim3 grid((unsigned)(ng * chunks));
+  const bool b1 = (B == 1) && !q_out;
+  if (twiddle && b1)
+    hipLaunchKernelGGL((split_outer_inverse_kernel<R, true, true>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, B, chunks, inv_n, q_out);
+  else if (twiddle)
+    hipLaunchKernelGGL((split_outer_inverse_kernel<R, true, false>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, B, chunks, inv_n, q_out);
+  else if (b1)
+    hipLaunchKernelGGL((split_outer_inverse_kernel<R, false, true>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, B, chunks, inv_n, q_out);
   else
-    hipLaunchKernelGGL((split_outer_inverse_kernel<R, false>), dim3((unsigned)(ng * chunks)), dim3(kBlock), 0, ctx->stream, Z, partial,
-                       tw, M, B, chunks, inv_n, q_out);
+    hipLaunchKernelGGL((split_outer_inverse_kernel<R, false, false>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, B, chunks, inv_n, q_out);
   GACQ_HIP(ctx, hipGetLastError());
   return GACQ_OK;
 }
