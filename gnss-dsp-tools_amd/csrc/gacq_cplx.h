@@ -328,6 +328,35 @@ template <bool INV> struct SmallDft<9, INV> {                          // 9 = 3 
   }
 };
 
+// Coprime composites by the prime-factor (Good-Thomas) mapping: R = N1 N2 with gcd 1,
+//   input  n = (N2 n1 + N1 n2) mod R,   output k = (A k1 + Bk k2) mod R,  A = N2 (N2^-1 mod N1), Bk = N1 (N1^-1 mod N2)
+// so that W_R^{nk} = W_N1^{n1 k1} W_N2^{n2 k2}: two layers of small DFTs and no twiddle factors at all (a register
+// permutation at compile time).  10 = 2 x 5, 12 = 3 x 4, 15 = 3 x 5 give 1980 = 11 * 12 * 15 and 990 = 11 * 9 * 10 in three passes.
+template <int N1, int N2, int A, int Bk, bool INV> struct PfaDft {
+  static constexpr int R = N1 * N2;
+  static __device__ __forceinline__ void run(v2 (&x)[R]) {
+    v2 u[N1][N2];                                                        // u[k1][n2]
+#pragma unroll
+    for (int n2 = 0; n2 < N2; n2++) {
+      v2 col[N1];
+#pragma unroll
+      for (int n1 = 0; n1 < N1; n1++) col[n1] = x[(N2 * n1 + N1 * n2) % R];
+      SmallDft<N1, INV>::run(col);
+#pragma unroll
+      for (int k1 = 0; k1 < N1; k1++) u[k1][n2] = col[k1];
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < N1; k1++) {
+      SmallDft<N2, INV>::run(u[k1]);
+#pragma unroll
+      for (int k2 = 0; k2 < N2; k2++) x[(A * k1 + Bk * k2) % R] = u[k1][k2];
+    }
+  }
+};
+template <bool INV> struct SmallDft<10, INV> : PfaDft<2, 5, 5, 6, INV> {};      // 5^-1 mod 2 = 1, 2^-1 mod 5 = 3
+template <bool INV> struct SmallDft<12, INV> : PfaDft<3, 4, 4, 9, INV> {};      // 4^-1 mod 3 = 1, 3^-1 mod 4 = 3
+template <bool INV> struct SmallDft<15, INV> : PfaDft<3, 5, 10, 6, INV> {};     // 5^-1 mod 3 = 2, 3^-1 mod 5 = 2
+
 // w^k for k = 0..43 from base-4 digits: w^k = p[k & 3] * q[k >> 2], p[a] = w^a, q[b] = w^(4b); multiplication depth <= 5
 struct TwPow {
   v2 p[4], q[11];

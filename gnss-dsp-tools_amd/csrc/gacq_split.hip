@@ -249,7 +249,10 @@ __device__ __forceinline__ void stockham_pass(v2* __restrict__ buf, float2* __re
 // the row pointer changes, i.e. across an epoch or frequency-set boundary).  Consecutive workgroups share k1 and the item
 // chunk, so the pch code-spectrum rows they read stay in every XCD's L2.  [g0, g0+ng) is the range of (e,p,d) groups whose
 // Z rows exist in this workspace pass; anything outside is skipped.
-// NT threads per workgroup: 256 for M = 1980 (180..495 butterflies per pass), 128 for M = 990 (90..495).
+// R3 == 1: three passes (R0, R1, R2).  NT threads per workgroup, chosen close to the butterflies per pass:
+//   M = 1980 = 11 * 12 * 15: 180, 165, 132 butterflies -> 192 threads;   M = 990 = 11 * 9 * 10: 90, 110, 99 -> 128 threads.
+// Three passes instead of four (11 * 9 * 5 * 4|2) mean one LDS exchange, one twiddle stage and two barriers less per row; the
+// composite radices 10, 12 and 15 are coprime products (PfaDft), so they cost no internal twiddles either.
 template <int R0, int R1, int R2, int R3, int NT>
 __global__ __launch_bounds__(NT) void split_inner_corr_kernel(const float2* __restrict__ X, const float2* __restrict__ C,
                                                                    float2* __restrict__ Z, const int* __restrict__ items,
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(NT) void split_inner_corr_kernel(const float2* __re
   v2* tw3 = tw2 + (R2 - 1) * R0 * R1;
   fill_pass_twiddles<R1, NT>(tw1, twm_g, R0, M);
   fill_pass_twiddles<R2, NT>(tw2, twm_g, R0 * R1, M);
-  fill_pass_twiddles<R3, NT>(tw3, twm_g, R0 * R1 * R2, M);
+  if (R3 > 1) fill_pass_twiddles<R3, NT>(tw3, twm_g, R0 * R1 * R2, M);
   unsigned blk = blockIdx.x;                       // 32-bit index math: 64-bit divisions cost ~100 scalar ops each
   const int b = (int)(blk % (unsigned)B);
   blk /= (unsigned)B;
@@ -308,9 +311,13 @@ __global__ __launch_bounds__(NT) void split_inner_corr_kernel(const float2* __re
     __syncthreads();
     stockham_pass<R1, false, M, NT>(buf0, nullptr, tw1, R0);
     __syncthreads();
-    stockham_pass<R2, false, M, NT>(buf0, nullptr, tw2, R0 * R1);
-    __syncthreads();
-    stockham_pass<R3, true, M, NT>(buf0, gz, tw3, R0 * R1 * R2);
+    if (R3 > 1) {
+      stockham_pass<R2, false, M, NT>(buf0, nullptr, tw2, R0 * R1);
+      __syncthreads();
+      stockham_pass<(R3 > 1 ? R3 : 2), true, M, NT>(buf0, gz, tw3, R0 * R1 * R2);
+    } else {
+      stockham_pass<R2, true, M, NT>(buf0, gz, tw2, R0 * R1);
+    }
     __syncthreads();                               // buf0 is rewritten by the next item's first pass
   }
 }
@@ -396,10 +403,10 @@ int split_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* C, const
   const int nblk_ep = (int)((nep + pch - 1) / pch);
   const dim3 grid((unsigned)((long)R * nblk_ep * D * B));
   if (M == 1980)
-    hipLaunchKernelGGL((split_inner_corr_kernel<11, 9, 5, 4, 256>), grid, dim3(256), smem, ctx->stream, X, C, Z, d_items, d_fset, twm, g0, ng,
+    hipLaunchKernelGGL((split_inner_corr_kernel<11, 12, 15, 1, 192>), grid, dim3(192), smem, ctx->stream, X, C, Z, d_items, d_fset, twm, g0, ng,
                        ep_first, nblk_ep, pch, P, F, D, B, R);
   else if (M == 990)
-    hipLaunchKernelGGL((split_inner_corr_kernel<11, 9, 5, 2, 128>), grid, dim3(128), smem, ctx->stream, X, C, Z, d_items, d_fset, twm, g0, ng,
+    hipLaunchKernelGGL((split_inner_corr_kernel<11, 9, 10, 1, 128>), grid, dim3(128), smem, ctx->stream, X, C, Z, d_items, d_fset, twm, g0, ng,
                        ep_first, nblk_ep, pch, P, F, D, B, R);
   else
     return set_error(ctx, GACQ_ERR_UNSUPPORTED, "fused inner transforms: M=%d not supported", M);
