@@ -227,12 +227,14 @@ def main():
     dk = per_stage[dominant]
     achieved = dk["alg_bytes_per_launch"] / (dk["avg_ms"] * 1e-3) / 1e9
     traffic = None
+    pipe_busy = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             if tj.get("kernel_stage") == dominant and tj.get("epochs") == E_total and world == 1:
                 traffic = tj.get("hbm_bytes_per_launch")
+                pipe_busy = tj.get("valu_pipe_busy")
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -247,7 +249,9 @@ def main():
         rows_launch = E_total * P * D_local * B / dk["launches_per_step"]
         flops = rows_launch * (5.0 * N * np.log2(N) + 6.0 * N + 4.0 * N)     # inverse FFT + C*X + |.|
         valu = {"useful_flop_per_launch": flops, "achieved_TFLOPs": flops / (dk["avg_ms"] * 1e-3) / 1e12, "peak_TFLOPs": 157.3,
-                "frac": flops / (dk["avg_ms"] * 1e-3) / 1e12 / 157.3}
+                "frac": flops / (dk["avg_ms"] * 1e-3) / 1e12 / 157.3,
+                # fraction of all SIMD cycles spent issuing VALU work, from the SQ counters of the same command (profiles/)
+                "pipe_busy_pmc": pipe_busy}
 
     # host-buffer entry point (gacq_search: H2D + launches + D2H + sync), the drop-in search() call surface; not part of `value`
     latency = None
