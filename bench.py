@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--epochs", type=int, default=64, help="1 ms epochs per GPU per step")
     ap.add_argument("--engine", type=int, default=0, help="0 auto, 1 rocFFT pipeline, 2 LDS FFT kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lanes", type=int, default=2, help="independent steps in flight (engine contexts / HIP streams)")
     ap.add_argument("--no-latency", action="store_true",
                     help="skip the single-epoch host-call latency probe (profiling runs: keeps every launch the bench workload)")
     ap.add_argument("--force-gather", action="store_true", help="run the all-gather + merge even on 1 rank (test aid)")
@@ -162,21 +163,31 @@ def main():
     def step():
         return sh.search_batch(sig, x_dev, items, dop, B)
 
+    # Steps are independent searches (a receiver scanning a recording keeps several batches in flight): they alternate
+    # between two engine contexts, each with its own HIP stream and workspace, so the forward kernel of step i+1 fills the
+    # CUs that the tail of step i's correlate kernel leaves idle, and (N > 1) the all-gather of step i runs under the
+    # kernels of step i+1.  Every step still runs all of its kernels, the exchange and the merge inside the timed region.
+    lanes = []
+    for _ in range(max(1, args.lanes)):
+        st = torch.cuda.Stream(dev)
+        e2 = acquire.Engine(local_rank, engine=args.engine)
+        with torch.cuda.stream(st):
+            lanes.append((st, e2, sharded.ShardedSearch(engine=e2, always_gather=args.force_gather)))
+
     def run_steps(k):
-        """k independent steps; with more than one rank the all-gather of step i overlaps the kernels of step i+1
-        (async collective on RCCL's stream, merge deferred by one step)."""
-        if not (use_dist and world > 1) and not args.force_gather:
-            out = None
-            for _ in range(k):
-                out = step()
-            return out
-        pending, out = None, None
-        for _ in range(k):
-            nxt = sh.search_batch_async(sig, x_dev, items, dop, B)
-            if pending is not None:
-                out = pending.wait()
-            pending = nxt
-        return pending.wait() if pending is not None else out
+        pend = [None] * len(lanes)
+        out = None
+        for i in range(k):
+            st, _, shl = lanes[i % len(lanes)]
+            with torch.cuda.stream(st):
+                if pend[i % len(lanes)] is not None:
+                    out = pend[i % len(lanes)].wait()
+                pend[i % len(lanes)] = shl.search_batch_async(sig, x_dev, items, dop, B)
+        for (st, _, _), p in zip(lanes, pend):
+            if p is not None:
+                with torch.cuda.stream(st):
+                    out = p.wait()
+        return out
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -308,7 +319,8 @@ def main():
                                    "Doppler arange(-5000,5000,250)=40 bins; %d epochs/step/GPU batched, inputs resident in HBM" % args.epochs,
                        "prns": P, "doppler_bins": D, "lags": N, "blocks": B, "epochs_per_step": E_total,
                        "cells_per_step": cells_step, "sharding": "doppler-slice x%d + 1 all-gather of peaks per step (async, overlapped with the next step's kernels)" % world,
-                       "engine": {0: "auto", 1: "rocfft", 2: "lds-fft"}[args.engine]},
+                       "engine": {0: "auto", 1: "rocfft", 2: "lds-fft"}[args.engine],
+                       "steps_in_flight": len(lanes)},
             "roofline": roofline,
             "valu": valu,
             "host_call_latency": latency,
@@ -329,6 +341,8 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
+    for _, e2, _ in lanes:
+        e2.close()
     eng.close()
     if use_dist:
         dist.destroy_process_group()
