@@ -122,7 +122,9 @@ def main():
     ap.add_argument("--epochs", type=int, default=64, help="1 ms epochs per GPU per step")
     ap.add_argument("--engine", type=int, default=0, help="0 auto, 1 rocFFT pipeline, 2 LDS FFT kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lanes", type=int, default=2, help="independent steps in flight (engine contexts / HIP streams)")
+    ap.add_argument("--lanes", type=int, default=1,
+                    help="engine contexts / HIP streams the independent steps alternate between (2 fills the correlate kernel's tail, "
+                         "+3.5 %%, but overlapping launches make per-kernel durations meaningless for the roofline line)")
     ap.add_argument("--no-latency", action="store_true",
                     help="skip the single-epoch host-call latency probe (profiling runs: keeps every launch the bench workload)")
     ap.add_argument("--force-gather", action="store_true", help="run the all-gather + merge even on 1 rank (test aid)")
@@ -163,10 +165,11 @@ def main():
     def step():
         return sh.search_batch(sig, x_dev, items, dop, B)
 
-    # Steps are independent searches (a receiver scanning a recording keeps several batches in flight): they alternate
-    # between two engine contexts, each with its own HIP stream and workspace, so the forward kernel of step i+1 fills the
-    # CUs that the tail of step i's correlate kernel leaves idle, and (N > 1) the all-gather of step i runs under the
-    # kernels of step i+1.  Every step still runs all of its kernels, the exchange and the merge inside the timed region.
+    # Steps are independent searches (a receiver scanning a recording keeps several batches in flight).  With N > 1 the
+    # all-gather of step i runs under the kernels of step i+1 (asynchronous collective, merge deferred by one step); with
+    # --lanes 2 the steps also alternate between two engine contexts with their own HIP streams and workspaces, so the next
+    # step's kernels fill the CUs the tail of the correlate kernel leaves idle.  Every step runs all of its kernels, the
+    # exchange and the merge inside the timed region.
     lanes = []
     for _ in range(max(1, args.lanes)):
         st = torch.cuda.Stream(dev)
@@ -180,9 +183,10 @@ def main():
         for i in range(k):
             st, _, shl = lanes[i % len(lanes)]
             with torch.cuda.stream(st):
-                if pend[i % len(lanes)] is not None:
+                nxt = shl.search_batch_async(sig, x_dev, items, dop, B)      # next search queued before the previous merge:
+                if pend[i % len(lanes)] is not None:                          # its kernels cover the previous exchange
                     out = pend[i % len(lanes)].wait()
-                pend[i % len(lanes)] = shl.search_batch_async(sig, x_dev, items, dop, B)
+                pend[i % len(lanes)] = nxt
         for (st, _, _), p in zip(lanes, pend):
             if p is not None:
                 with torch.cuda.stream(st):
