@@ -25,7 +25,8 @@ ALL_CASES = ["cfg1_gps_l1_prn1", "cfg2_gps_l1_all32", "gps_l1_ms3", "gps_l1_defa
              "cfg3_e1c_subset", "e1b_ms12", "cfg4_l5i_subset", "l5q_subset", "cfg4_b2ad_b80", "cfg5_b1i_ms10",
              "b2i_ms2", "cfg5_glonass_l1", "glonass_l2", "gps_l1cd", "bds_b1cp", "gps_l2cm", "gal_e6b", "gal_e5bq",
              "bds_b3i", "bds_b2bi", "glo_l3ocd", "xona_x1", "xona_x5p", "edge_empty_grid", "edge_zero_blocks_l1",
-             "edge_zero_blocks_e1b", "edge_fractional_grid"]
+             "edge_zero_blocks_e1b", "edge_fractional_grid", "bds_b1cd", "gps_l1cp", "bds_b2ap", "bds_b2bq", "gal_e5ai", "gal_e5aq",
+             "gal_e5bi", "gal_e6c", "glo_l3ocp"]
 N4096_CASES = ["cfg1_gps_l1_prn1", "cfg2_gps_l1_all32", "gps_l1_ms3", "gps_l1_default_grid", "xona_x1",
                "edge_fractional_grid"]
 
@@ -409,7 +410,7 @@ def test_bench_under_torchrun_single_rank_exercises_rccl_path():
 
 
 R31_CASES = ["cfg4_l5i_subset", "l5q_subset", "cfg4_b2ad_b80", "gal_e6b", "gal_e5bq", "bds_b3i", "bds_b2bi", "glo_l3ocd",
-             "xona_x5p"]
+             "xona_x5p", "bds_b2ap", "bds_b2bq", "gal_e5ai", "gal_e5aq", "gal_e5bi", "gal_e6c", "glo_l3ocp"]
 
 
 @pytest.mark.parametrize("cid", R31_CASES)
@@ -465,7 +466,7 @@ def test_radix31_code_spectrum_is_a_permutation_of_the_natural_one(engine):
 
 
 SPLIT_LDS_CASES = ["cfg3_e1b_subset", "cfg3_e1c_subset", "e1b_ms12", "cfg5_b1i_ms10", "b2i_ms2", "cfg5_glonass_l1", "glonass_l2",
-                   "gps_l1cd", "bds_b1cp", "gps_l2cm"]
+                   "gps_l1cd", "bds_b1cp", "gps_l2cm", "bds_b1cd", "gps_l1cp"]
 
 
 LDS16K_CASES = ["cfg5_b1i_ms10", "b2i_ms2", "cfg5_glonass_l1", "glonass_l2"]

@@ -14,8 +14,9 @@ RTOL = 1e-12
 FAST_CASES = ["cfg1_gps_l1_prn1", "cfg2_gps_l1_all32", "gps_l1_ms3", "gps_l1_default_grid", "e1b_ms12",
               "l5q_subset", "cfg5_b1i_ms10", "b2i_ms2", "cfg5_glonass_l1", "glonass_l2", "gps_l2cm", "gal_e6b",
               "gal_e5bq", "bds_b3i", "bds_b2bi", "glo_l3ocd", "xona_x1", "xona_x5p", "edge_empty_grid",
-              "edge_zero_blocks_l1", "edge_zero_blocks_e1b", "edge_fractional_grid", "cfg3_e1c_subset"]
-SLOW_CASES = ["cfg3_e1b_subset", "cfg4_l5i_subset", "cfg4_b2ad_b80", "gps_l1cd", "bds_b1cp"]
+              "edge_zero_blocks_l1", "edge_zero_blocks_e1b", "edge_fractional_grid", "cfg3_e1c_subset",
+              "bds_b2ap", "bds_b2bq", "gal_e5ai", "gal_e5aq", "gal_e5bi", "gal_e6c", "glo_l3ocp"]
+SLOW_CASES = ["cfg3_e1b_subset", "cfg4_l5i_subset", "cfg4_b2ad_b80", "gps_l1cd", "bds_b1cp", "bds_b1cd", "gps_l1cp"]
 
 
 def _check_case(case):

@@ -86,6 +86,16 @@ def cases():
     out.append(("glo_l3ocd", "glonass-l3ocd", [0, 63], [1000.0, 2000.0, 200.0], 1, 22, [(63, A[0], F[0], 1201)]))
     out.append(("xona_x1", "xona-x1", [0], [-2000.0, 3000.0, 200.0], 2, 23, [(0, A[1], F[0], 1201)]))
     out.append(("xona_x5p", "xona-x5p", [0], [1000.0, 2000.0, 200.0], 2, 24, [(0, A[1], F[0], 1201)]))
+    # the remaining acquire-*.py scripts, one small reference run each (every FFT script has at least one golden)
+    out.append(("bds_b1cd", "beidou-b1cd", [8, 40], [1480.0, 1600.0, 20.0], 10, 29, [(8, 0.2, F[0], 1201)]))
+    out.append(("gps_l1cp", "gps-l1cp", [9], [1480.0, 1600.0, 20.0], 10, 30, [(9, 0.2, F[0], 40000)]))
+    out.append(("bds_b2ap", "beidou-b2ap", [30], [1000.0, 2000.0, 200.0], 1, 31, [(30, A[0], F[0], 1201)]))
+    out.append(("bds_b2bq", "beidou-b2bq", [19, 48], [1000.0, 2000.0, 200.0], 1, 32, [(48, A[0], F[0], 1201)]))
+    out.append(("gal_e5ai", "galileo-e5ai", [11], [1000.0, 2000.0, 200.0], 2, 33, [(11, A[0], F[0], 29000)]))
+    out.append(("gal_e5aq", "galileo-e5aq", [12], [1000.0, 2000.0, 200.0], 1, 34, [(12, A[0], F[0], 1201)]))
+    out.append(("gal_e5bi", "galileo-e5bi", [13], [1000.0, 2000.0, 200.0], 1, 35, [(13, A[0], F[0], 1201)]))
+    out.append(("gal_e6c", "galileo-e6c", [4, 50], [1000.0, 2000.0, 200.0], 2, 36, [(4, A[0], F[0], 1201)]))
+    out.append(("glo_l3ocp", "glonass-l3ocp", [5], [1000.0, 2000.0, 200.0], 1, 37, [(5, A[0], F[0], 1201)]))
     # edge cases: empty Doppler grid, zero blocks (initial values come back untouched)
     out.append(("edge_empty_grid", "gps-l1", [1, 2], [1000.0, 1000.0, 100.0], 1, 25, gps4))
     out.append(("edge_zero_blocks_l1", "gps-l1", [3], [-1000.0, 1000.0, 500.0], 0, 26, gps4))
@@ -163,7 +173,10 @@ def main():
         fn = [v for k, v in vars(mod).items() if k.endswith("_code") and callable(v)][0]
         fam = {}
         for prn in codes.prns(code):
-            c = np.asarray(fn() if code == "glonass.ca" else fn(prn)).astype(np.uint8)
+            try:
+                c = np.asarray(fn(prn)).astype(np.uint8)
+            except TypeError:                                   # the GLONASS generators take no PRN argument
+                c = np.asarray(fn()).astype(np.uint8)
             fam[str(prn)] = {"sha256": sha(c), "head": "".join(map(str, c[:24])), "tail": "".join(map(str, c[-24:]))}
         chips[code] = {"code_length": int(mod.code_length), "chip_rate": float(mod.chip_rate), "prns": fam}
         print("chips", code, len(fam))
