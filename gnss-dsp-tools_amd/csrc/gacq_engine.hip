@@ -763,6 +763,8 @@ int check_search_args(gacq_sig* sig, const void* x, size_t nsamp, int nepoch, co
     return set_error(ctx, GACQ_ERR_BAD_ARG, "search: bad argument");
   for (int p = 0; p < nitems; p++)
     if (items[p] < 0 || items[p] >= sig->nprn) return set_error(ctx, GACQ_ERR_BAD_PRN, "search: item index %d out of range [0,%d)", items[p], sig->nprn);
+  for (int k = 0; k < nd; k++)
+    if (!std::isfinite(dopplers[k])) return set_error(ctx, GACQ_ERR_BAD_ARG, "search: Doppler value %d is not finite", k);
   const size_t need = (size_t)(blocks + (sig->desc.pad ? 1 : 0)) * sig->desc.n;
   if (blocks > 0 && nsamp < need)
     return set_error(ctx, GACQ_ERR_SHORT_INPUT, "search: %zu samples given, %zu needed for %d block(s) of n=%d%s", nsamp, need, blocks,

@@ -283,6 +283,50 @@ def test_error_behaviour(engine):
     assert ei.value.code == -9
 
 
+def test_c_abi_rejects_bad_arguments_with_codes_not_crashes(engine):
+    """Straight through ctypes: NULL pointers, negative counts, out-of-range item indices, short inputs and NaN Doppler values
+    come back as negative GACQ_ERR_* codes with a message; the context stays usable afterwards."""
+    import ctypes
+    from gnss_dsp_tools_amd import _native as nat
+    from gnss_dsp_tools_amd import signals, synth
+    lib = nat.lib
+    sig = signals.get("gps-l1")
+    s = engine.signal(sig, [1, 2, 3])
+    x = synth.make_iq(sig, 1, 11, [(2, 0.5, 1000.0, 100)], nsamp=4096)
+    xp = x.ctypes.data_as(nat.c_float_p)
+    items = np.array([0, 1, 2], dtype=np.int32)
+    dop = np.array([500.0, 1000.0, 1500.0])
+    res = (nat.Result * 3)()
+
+    def call(xptr=xp, nsamp=4096, it=items, nit=3, dp=dop, nd=3, blocks=1, out=res):
+        return lib.gacq_search(s._h, xptr, nsamp, it.ctypes.data_as(nat.c_int_p) if it is not None else None, nit,
+                               dp.ctypes.data_as(nat.c_double_p) if dp is not None else None, nd, None, blocks, out)
+
+    assert call() == 0
+    good = [(r.metric, r.code_chips, r.doppler_hz) for r in res]
+    assert call(xptr=None) < 0
+    assert call(it=None) < 0
+    assert call(dp=None) < 0
+    assert call(out=None) < 0
+    assert call(nit=-1) < 0
+    assert call(nd=-2) < 0
+    assert call(blocks=-1) < 0
+    assert call(nsamp=4095) == -6                                        # GACQ_ERR_SHORT_INPUT
+    assert call(it=np.array([0, 7, 1], dtype=np.int32)) < 0               # item index outside the signal's table
+    assert call(it=np.array([0, -1, 1], dtype=np.int32)) < 0
+    assert lib.gacq_last_error(engine._ctx)                               # a message is available
+    assert lib.gacq_search(None, xp, 4096, items.ctypes.data_as(nat.c_int_p), 3, dop.ctypes.data_as(nat.c_double_p), 3, None, 1, res) < 0
+    assert lib.gacq_set_engine(engine._ctx, 9) < 0
+    assert lib.gacq_set_workspace_limit(engine._ctx, 10) < 0
+    # a frequency whose phase index leaves the 32-bit range is refused, not wrapped
+    assert call(dp=np.array([1e30, 0.0, 1.0])) < 0
+    assert call(dp=np.array([0.0, float("nan"), 1.0])) < 0
+    assert call(dp=np.array([0.0, float("inf"), 1.0])) < 0
+    # the context still works and returns the same answer
+    assert call() == 0
+    assert [(r.metric, r.code_chips, r.doppler_hz) for r in res] == good
+
+
 # ---- full BASELINE sizes: size-independent properties ---------------------------------------------
 def test_full_size_properties_config2(engine):
     """Config 2 at full size (32 PRNs x 40 bins x 4096 lags, 64 epochs batched):
