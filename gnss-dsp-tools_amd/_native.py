@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("GACQ_LIB") or os.path.join(_HERE, "lib", "libgacq.so")     # GACQ_LIB: profiling builds only
+LIB_PATH = os.path.join(_HERE, "lib", "libgacq.so")
 
 # One HIP runtime per process: when torch is (or will be) in the process its bundled
 # libamdhip64/librocfft (same SONAMEs as /opt/rocm's) must be the ones that get bound, so it
@@ -50,6 +50,9 @@ ERRORS = {0: "GACQ_OK", -1: "GACQ_ERR_BAD_ARG", -2: "GACQ_ERR_UNKNOWN_CODE", -3:
           -4: "GACQ_ERR_HIP", -5: "GACQ_ERR_ROCFFT", -6: "GACQ_ERR_SHORT_INPUT", -7: "GACQ_ERR_NO_DEVICE",
           -8: "GACQ_ERR_INTERNAL", -9: "GACQ_ERR_UNSUPPORTED"}
 
+# GACQ_OPT_* of include/gacq.h
+OPTIONS = {"fused_inner": 0, "fused_16k": 1, "lds_variant": 2, "lds_pch": 3, "split_pch": 4, "graph": 5}
+
 # name -> (restype, argtypes): every symbol include/gacq.h declares
 SYMBOLS = {
     "gacq_code_count": (ctypes.c_int, []),
@@ -67,6 +70,8 @@ SYMBOLS = {
     "gacq_use_null_stream": (ctypes.c_int, [ctypes.c_void_p]),
     "gacq_set_engine": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "gacq_set_workspace_limit": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]),
+    "gacq_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_long]),
+    "gacq_get_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_long)]),
     "gacq_signal_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(SigDesc), ctypes.c_char_p,
                                           c_int_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "gacq_signal_create_chips": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(SigDesc), c_uint8_p,

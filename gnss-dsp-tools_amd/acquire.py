@@ -12,6 +12,7 @@ tuple) but every PRN / Doppler bin / block of the search runs on the GPU through
 No CPU fallback: constructing an Engine without a visible GPU raises.
 """
 import ctypes
+import weakref
 
 import numpy as np
 
@@ -70,8 +71,10 @@ class AcqSignal:
                                                        len(self.prns), ctypes.byref(h)), engine._ctx)
         self._h = h
         self._index = {p: i for i, p in enumerate(self.prns)}
+        engine._live.add(self)              # Engine.close() destroys every signal created on it before the context
 
     def close(self):
+        """Free the device-side code spectra.  A signal never outlives its context: Engine.close() closes it first."""
         if self._h:
             nat.lib.gacq_signal_destroy(self._h)
             self._h = None
@@ -98,6 +101,7 @@ class Engine:
         self.device = int(device)
         self._signals = {}
         self._families = {}
+        self._live = weakref.WeakSet()      # every AcqSignal created on this context (also user-held ones)
         if engine:
             self.set_engine(engine)
         if workspace_bytes:
@@ -123,6 +127,19 @@ class Engine:
         import torch
         self.set_stream(torch.cuda.current_stream(device).cuda_stream)
 
+    def set_option(self, option, value):
+        """gacq_set_option: tuning switches of the launch path (include/gacq.h GACQ_OPT_*), by number or by name."""
+        if isinstance(option, str):
+            option = nat.OPTIONS[option.lower()]
+        nat.check(nat.lib.gacq_set_option(self._ctx, int(option), int(value)), self._ctx)
+
+    def get_option(self, option):
+        if isinstance(option, str):
+            option = nat.OPTIONS[option.lower()]
+        v = ctypes.c_long()
+        nat.check(nat.lib.gacq_get_option(self._ctx, int(option), ctypes.byref(v)), self._ctx)
+        return v.value
+
     def set_profiling(self, on):
         nat.check(nat.lib.gacq_set_profiling(self._ctx, int(bool(on))), self._ctx)
 
@@ -139,7 +156,7 @@ class Engine:
         return out
 
     def close(self):
-        for s in list(self._signals.values()) + [f for f in self._families.values() if f is not None]:
+        for s in list(self._live):
             s.close()
         self._signals.clear()
         self._families.clear()
@@ -194,6 +211,8 @@ class Engine:
     def search_blocks(self, name, x, items, dopplers, blocks):
         """Engine-level form: explicit Doppler values and block count B."""
         sig = _signals.get(name) if isinstance(name, str) else name
+        if len(items) == 0:
+            return []                                   # the reference maps worker over an empty list
         s, idx, bias = self._plan(sig, items)
         dopplers = np.ascontiguousarray(dopplers, dtype=np.float64)
         blocks = max(int(blocks), 0)                    # range(negative) is empty in the reference
@@ -205,7 +224,7 @@ class Engine:
             # the reference fails here with numpy's broadcast ValueError (short last block * w)
             raise ValueError("operands could not be broadcast together: search needs %d samples "
                              "(%d block(s) of n=%d%s), x has %d" % (need, blocks, sig.n, ", padded" if sig.pad else "", len(x)))
-        xc = np.ascontiguousarray(x[:max(need, 1)], dtype=np.complex64)
+        xc = np.ascontiguousarray(x[:need], dtype=np.complex64) if need else np.zeros(1, dtype=np.complex64)
         res = (nat.Result * len(idx))()
         nat.check(nat.lib.gacq_search(
             s._h, xc.ctypes.data_as(nat.c_float_p), len(xc), idx.ctypes.data_as(nat.c_int_p), len(idx),
@@ -245,7 +264,7 @@ class Engine:
         x = np.asarray(x)
         if x.ndim != 1 or len(x) < need:
             raise ValueError("operands could not be broadcast together: search needs %d samples, x has shape %r" % (need, x.shape))
-        xc = np.ascontiguousarray(x[:max(need, 1)], dtype=np.complex64)
+        xc = np.ascontiguousarray(x[:need], dtype=np.complex64) if need else np.zeros(1, dtype=np.complex64)
         idx = np.arange(total, dtype=np.int32)
         res = (nat.Result * total)()
         nat.check(nat.lib.gacq_search(fam._h, xc.ctypes.data_as(nat.c_float_p), len(xc), idx.ctypes.data_as(nat.c_int_p), total,
@@ -283,8 +302,14 @@ class Engine:
         if not (x_dev.is_cuda and x_dev.dtype == torch.complex64 and x_dev.dim() == 2 and x_dev.is_contiguous()):
             raise ValueError("x_dev must be a contiguous 2-D complex64 CUDA tensor")
         nepoch, nsamp = x_dev.shape
+        if len(idx) == 0:
+            return torch.empty((nepoch, 0, 2), dtype=torch.float64, device=x_dev.device)
         if out is None:
             out = torch.empty((nepoch, len(idx), 2), dtype=torch.float64, device=x_dev.device)
+        elif not (torch.is_tensor(out) and out.dtype == torch.float64 and tuple(out.shape) == (nepoch, len(idx), 2) and out.is_contiguous()
+                  and (out.is_cuda or out.is_pinned())):
+            # the last kernel writes 16-byte gacq_peak records into it: a wrong buffer would be overwritten silently
+            raise ValueError("out must be a contiguous float64 tensor of shape (%d, %d, 2) on the device (or pinned host memory)" % (nepoch, len(idx)))
         nat.check(nat.lib.gacq_search_batch_dev(
             s._h, ctypes.c_void_p(x_dev.data_ptr()), nsamp, nepoch, idx.ctypes.data_as(nat.c_int_p), len(idx),
             dopplers.ctypes.data_as(nat.c_double_p), len(dopplers),

@@ -48,7 +48,8 @@ struct gacq_ctx {
   int engine = 0;
   size_t ws_limit = (size_t)4 << 30;
   std::map<std::pair<long, long>, gacq::FftPlan> plans;   // (N * 2 + inverse, batch)
-  gacq::DevBuf tab, xstage, X, Y, rows, freq, fset, items, out_peaks, d0, partial, fe_a, fe_b, fe_taps;
+  gacq::DevBuf tab, xstage, X, Y, rows, freq, fset, items, out_peaks, d0, partial, fe_a, fe_b, fe_taps, chunk_peaks;
+  long opt[GACQ_NOPTS] = {1, 1, -1, 0, 0, 0};   // gacq_set_option values (defaults documented in include/gacq.h)
   gacq::DevBuf pin_x, pin_peaks;       // pinned host staging for the host-buffer entry point (gacq_search)
   bool profiling = false;
   double stage_ms[GACQ_NSTAGES] = {0};
@@ -94,7 +95,7 @@ int lds_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n,
                 int FD, int B, const float2* tab, float2* X);
 // rows[(e*P + p)*D + d] = reduce_k sum_b | IFFT_N(C_p * X[e,f(p),d,b]) | / N
 // N = 16384 with one carrier per item (F == P): forward + correlate in one kernel, no X buffer
-bool lds_fused_supported(int N, int P, int F);
+bool lds_fused_supported(const gacq_ctx* ctx, int N, int P, int F);
 int lds_fused_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n, int N, const float2* spectra, const int* d_items,
                      const int* d_fset, const double* d_freq, const float2* tab, int nitems, int D, int B, RowRec* rows);
 int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const int* d_items, const int* d_fset,

@@ -11,6 +11,7 @@
 // fused LDS-resident FFT kernels in gacq_ldsfft.hip (engine 2).
 #include "gacq_common.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdlib>
@@ -43,7 +44,8 @@ int set_error(gacq_ctx* ctx, int code, const char* fmt, ...) {
 int ensure(gacq_ctx* ctx, DevBuf& b, size_t bytes) {
   if (bytes <= b.cap) return GACQ_OK;
   if (b.p) {
-    GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // device-wide: the buffer may still be read by work queued on a stream the ctx used before gacq_set_stream
+    GACQ_HIP(ctx, hipDeviceSynchronize());
     GACQ_HIP(ctx, hipFree(b.p));
     b.p = nullptr;
     b.cap = 0;
@@ -61,7 +63,7 @@ int ensure(gacq_ctx* ctx, DevBuf& b, size_t bytes) {
 int ensure_pinned(gacq_ctx* ctx, DevBuf& b, size_t bytes) {
   if (bytes <= b.cap) return GACQ_OK;
   if (b.p) {
-    GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GACQ_HIP(ctx, hipDeviceSynchronize());
     GACQ_HIP(ctx, hipHostFree(b.p));
     b.p = nullptr;
     b.cap = 0;
@@ -379,7 +381,7 @@ void gacq_destroy(gacq_ctx* ctx) {
     if (kv.second.work) (void)hipFree(kv.second.work);
   }
   for (auto& ev : ctx->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-  DevBuf* bufs[] = {&ctx->tab, &ctx->xstage, &ctx->X, &ctx->Y, &ctx->rows, &ctx->freq, &ctx->fset, &ctx->items, &ctx->out_peaks, &ctx->d0, &ctx->partial, &ctx->fe_a, &ctx->fe_b, &ctx->fe_taps};
+  DevBuf* bufs[] = {&ctx->tab, &ctx->xstage, &ctx->X, &ctx->Y, &ctx->rows, &ctx->freq, &ctx->fset, &ctx->items, &ctx->out_peaks, &ctx->d0, &ctx->partial, &ctx->fe_a, &ctx->fe_b, &ctx->fe_taps, &ctx->chunk_peaks};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   if (ctx->pin_x.p) (void)hipHostFree(ctx->pin_x.p);
   if (ctx->pin_peaks.p) (void)hipHostFree(ctx->pin_peaks.p);
@@ -409,6 +411,18 @@ int gacq_set_engine(gacq_ctx* ctx, int engine) {
 int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes) {
   if (!ctx || bytes < ((size_t)1 << 20)) return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_set_workspace_limit: need >= 1 MiB");
   ctx->ws_limit = bytes;
+  return GACQ_OK;
+}
+
+int gacq_set_option(gacq_ctx* ctx, int option, long value) {
+  if (!ctx || option < 0 || option >= GACQ_NOPTS) return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_set_option: unknown option %d", option);
+  ctx->opt[option] = value;
+  return GACQ_OK;
+}
+
+int gacq_get_option(gacq_ctx* ctx, int option, long* value) {
+  if (!ctx || !value || option < 0 || option >= GACQ_NOPTS) return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_get_option: unknown option %d", option);
+  *value = ctx->opt[option];
   return GACQ_OK;
 }
 
@@ -643,7 +657,7 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
     return set_error(ctx, GACQ_ERR_UNSUPPORTED, "engine 3 (split with rocFFT inner transforms) does not support N=%d", N);
 
   // epochs per pass so that the forward-spectra buffer respects the workspace limit
-  const bool fused16k = use_lds && lds_fused_supported(N, P, F);      // one carrier per item: no forward-spectra buffer at all
+  const bool fused16k = use_lds && lds_fused_supported(ctx, N, P, F);      // one carrier per item: no forward-spectra buffer at all
   const size_t x_epoch_bytes = sizeof(float2) * (size_t)F * D * B * N;
   int Ec = (int)std::max<size_t>(1, std::min<size_t>((size_t)nepoch, ctx->ws_limit / std::max<size_t>(1, x_epoch_bytes)));
   if (fused16k) Ec = nepoch;            // nothing but the 16-byte row records is buffered
@@ -711,7 +725,7 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
           if (rc != GACQ_OK) return rc;
           continue;
         }
-        if (use_split && split_inner_fused_supported(N) && !getenv("GACQ_NO_FUSED_INNER")) {
+        if (use_split && split_inner_fused_supported(N) && ctx->opt[GACQ_OPT_FUSED_INNER]) {
           stage_begin(ctx, 6);
           rc = split_inner_correlate(ctx, X, sig->spectra_r31, (const int*)ctx->items.p, (const int*)ctx->fset.p, g0, ng, P, F, D, B, N,
                                      Y);                                        // K2 + inner inverse FFTs (Stockham in LDS)
@@ -795,6 +809,31 @@ int gacq_search_batch_dev(gacq_sig* sig, const void* d_x, size_t nsamp, int nepo
     GACQ_HIP(ctx, hipGetLastError());
     return GACQ_OK;
   }
+  // One epoch's forward spectra [F][D][B][N] larger than the workspace limit (long integrations: galileo-e1b --time 200 is
+  // 9 GB): the Doppler grid is cut into slices that fit, each slice is an ordinary search, and the per-slice peaks are merged
+  // in grid order with strict '>' by the shard-merge kernel -- the same winner as one scan over the whole grid.
+  int F = 1;
+  if (item_bias_hz) {
+    std::vector<double> seen;
+    for (int p = 0; p < nitems; p++) if (std::find(seen.begin(), seen.end(), item_bias_hz[p]) == seen.end()) seen.push_back(item_bias_hz[p]);
+    F = (int)seen.size();
+  }
+  const size_t bin_bytes = sizeof(float2) * (size_t)F * blocks * sig->N;
+  const bool no_x = (ctx->engine == 0 || ctx->engine == 2) && lds_fused_supported(ctx, sig->N, nitems, F);
+  if (!no_x && nd > 1 && bin_bytes * nd > ctx->ws_limit) {
+    const int Dc = (int)std::max<size_t>(1, ctx->ws_limit / bin_bytes);
+    const int nch = (nd + Dc - 1) / Dc;
+    const long n = (long)nepoch * nitems;
+    if ((rc = ensure(ctx, ctx->chunk_peaks, sizeof(gacq_peak) * (size_t)nch * n)) != GACQ_OK) return rc;
+    std::vector<int> d0(nch);
+    for (int c = 0; c < nch; c++) {
+      d0[c] = c * Dc;
+      rc = launch_search(sig, (const float2*)d_x, nsamp, nepoch, items, nitems, dopplers + d0[c], std::min(Dc, nd - d0[c]), item_bias_hz,
+                         blocks, (gacq_peak*)ctx->chunk_peaks.p + (size_t)c * n, nullptr);
+      if (rc != GACQ_OK) return rc;
+    }
+    return gacq_merge_peaks_dev(ctx, ctx->chunk_peaks.p, nch, d0.data(), n, d_out);
+  }
   return launch_search(sig, (const float2*)d_x, nsamp, nepoch, items, nitems, dopplers, nd, item_bias_hz, blocks,
                        (gacq_peak*)d_out, nullptr);
 }
@@ -867,21 +906,27 @@ int gacq_search(gacq_sig* sig, const float* x_iq, size_t nsamp, const int* items
   int rc = check_search_args(sig, x_iq, nsamp, 1, items, nitems, dopplers, nd, blocks, out);
   if (rc != GACQ_OK) return rc;
   gacq_ctx* ctx = sig->ctx;
+  if (nd == 0 || blocks == 0) {
+    // empty Doppler grid / no block: the reference returns its untouched initial (0,0,0) (acquire-gps-l1.py:25,40) and never
+    // looks at x, which may then be shorter than one window (Python callers pass x[:0]) -- nothing is staged or launched
+    for (int p = 0; p < nitems; p++) { out[p].metric = 0.0; out[p].code_chips = 0.0; out[p].doppler_hz = 0.0; out[p].idx = -1; out[p].d_index = -1; }
+    return GACQ_OK;
+  }
   GACQ_DEVICE(ctx);
-  const size_t need = (size_t)(blocks + (sig->desc.pad ? 1 : 0)) * sig->desc.n;
-  const size_t take = std::max<size_t>(need, 1);
+  const size_t need = (size_t)(blocks + (sig->desc.pad ? 1 : 0)) * sig->desc.n;      // <= nsamp (check_search_args)
+  const size_t take = need;
   if ((rc = ensure(ctx, ctx->xstage, sizeof(float2) * take)) != GACQ_OK) return rc;
   if ((rc = ensure_pinned(ctx, ctx->pin_peaks, sizeof(gacq_peak) * nitems)) != GACQ_OK) return rc;
   // Small inputs go through a pinned staging buffer (one host memcpy, then a true async DMA); a pageable hipMemcpyAsync
   // stages internally and costs ~10 us more per call.  Large inputs are copied directly.
   const size_t xbytes = sizeof(float2) * need;
   const void* src = x_iq;
-  if (need && xbytes <= kPinnedStageMax) {
+  if (xbytes <= kPinnedStageMax) {
     if ((rc = ensure_pinned(ctx, ctx->pin_x, xbytes)) != GACQ_OK) return rc;
     std::memcpy(ctx->pin_x.p, x_iq, xbytes);
     src = ctx->pin_x.p;
   }
-  if (need) GACQ_HIP(ctx, hipMemcpyAsync(ctx->xstage.p, src, xbytes, hipMemcpyHostToDevice, ctx->stream));
+  GACQ_HIP(ctx, hipMemcpyAsync(ctx->xstage.p, src, xbytes, hipMemcpyHostToDevice, ctx->stream));
   // the Doppler scan writes its 16-byte records straight into device-visible pinned host memory: no D2H copy
   rc = gacq_search_batch_dev(sig, ctx->xstage.p, take, 1, items, nitems, dopplers, nd, item_bias_hz, blocks, ctx->pin_peaks.p);
   if (rc != GACQ_OK) return rc;

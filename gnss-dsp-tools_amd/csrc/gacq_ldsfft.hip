@@ -733,7 +733,7 @@ int lds_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n,
   return GACQ_OK;
 }
 
-bool lds_fused_supported(int N, int P, int F) { return N == kBig && F == P && !getenv("GACQ_NO_FUSED_16K"); }
+bool lds_fused_supported(const gacq_ctx* ctx, int N, int P, int F) { return N == kBig && F == P && ctx->opt[GACQ_OPT_FUSED_16K]; }
 
 int lds_fused_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n, int N, const float2* spectra, const int* d_items,
                      const int* d_fset, const double* d_freq, const float2* tab, int nitems, int D, int B, RowRec* rows) {
@@ -773,13 +773,13 @@ int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const i
   // items per workgroup: keep >= ~2048 workgroups in flight (256 CUs x 4 resident x 2), at most 8 per group
   const long rows_total = (long)nepoch * nitems * D;
   int pch = (int)std::max<long>(1, std::min<long>(8, rows_total / 2048));
-  if (const char* ev = getenv("GACQ_LDS_PCH")) { const int k = atoi(ev); if (k >= 1) pch = k; }
+  if (ctx->opt[GACQ_OPT_LDS_PCH] >= 1) pch = (int)ctx->opt[GACQ_OPT_LDS_PCH];
   pch = std::min(pch, nitems);
   const int nchunk = (nitems + pch - 1) / pch;
   const long units8 = ((long)nepoch * D + 7) / 8;
   const long grid = 8 * units8 * nchunk;
   int variant = kDefaultVariant;
-  if (const char* ev = getenv("GACQ_LDS_VARIANT")) { const int k = atoi(ev); if (k >= 0 && k < kNumVariants) variant = k; }
+  if (ctx->opt[GACQ_OPT_LDS_VARIANT] >= 0 && ctx->opt[GACQ_OPT_LDS_VARIANT] < kNumVariants) variant = (int)ctx->opt[GACQ_OPT_LDS_VARIANT];
   // register-cached X needs all items of a workgroup to share one forward set
   const bool b1 = (B == 1) && (F == 1);
   CorrKernel kern = b1 ? kVariants[variant].b1 : kVariants[variant].bn;
@@ -817,7 +817,7 @@ int lds_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, c
   const long ep_first = g0 / D, ep_last = (g0 + ng - 1) / D;
   const long nep = ep_last - ep_first + 1;
   int pch = (int)std::max<long>(1, std::min<long>(8, nep * D * B * R / 2048));
-  if (const char* ev = getenv("GACQ_SPLIT_PCH")) { const int k = atoi(ev); if (k >= 1) pch = k; }
+  if (ctx->opt[GACQ_OPT_SPLIT_PCH] >= 1) pch = (int)ctx->opt[GACQ_OPT_SPLIT_PCH];
   const int nblk_ep = (int)((nep + pch - 1) / pch);
   hipLaunchKernelGGL(lds_inner_correlate_kernel, dim3((unsigned)((long)R * nblk_ep * D * B)), dim3(kBlock), 0, ctx->stream, X, spectra,
                      d_items, d_fset, tw, twn, Z, g0, ng, ep_first, nblk_ep, pch, P, F, D, B, R);

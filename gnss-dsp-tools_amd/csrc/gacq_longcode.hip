@@ -48,6 +48,7 @@ __global__ __launch_bounds__(kLcBlock) void longcode_dot_kernel(const float2* __
       // idx = floor((chips % L) + frac + incr*i) mod L, fp64 as numpy does it (gnsstools/gps/l2cl.py:57-61)
       long idx = (long)floor(ph + __dmul_rn(incr, (double)i));
       if (idx >= L) { idx -= L; if (idx >= L) idx %= L; }
+      else if (idx < 0) { idx %= L; if (idx < 0) idx += L; }      // np.mod is floored: a negative start phase wraps upwards
       const float2 v = src[i];
       if (chips[idx]) { ar -= (double)v.x; ai -= (double)v.y; } else { ar += (double)v.x; ai += (double)v.y; }
     }
@@ -100,6 +101,9 @@ extern "C" int gacq_longcode_search(gacq_ctx* ctx, const float* x_iq, size_t nsa
   if (blocks == 0) { memset(q_out, 0, sizeof(double) * K); return GACQ_OK; }
   if (nsamp < (size_t)blocks * n)
     return set_error(ctx, GACQ_ERR_SHORT_INPUT, "gacq_longcode_search: %zu samples given, %zu needed", nsamp, (size_t)blocks * n);
+  const double f = -carrier_hz / fs;                                     // nco.nco(-doppler/fs,0,n)  (acquire-gps-l2cl.py:18)
+  if (!std::isfinite(f) || !nco_range_ok(std::fabs(f), n))
+    return set_error(ctx, GACQ_ERR_UNSUPPORTED, "gacq_longcode_search: NCO phase index out of range");
   GACQ_DEVICE(ctx);
   hipStream_t st = ctx->stream;
   const uint8_t* d_chips;
@@ -119,8 +123,6 @@ extern "C" int gacq_longcode_search(gacq_ctx* ctx, const float* x_iq, size_t nsa
   double* d_q = d_phase + (size_t)K * blocks;
   GACQ_HIP(ctx, hipMemcpyAsync(ctx->xstage.p, x_iq, sizeof(float2) * (size_t)total, hipMemcpyHostToDevice, st));
   GACQ_HIP(ctx, hipMemcpyAsync(d_phase, phase0, sizeof(double) * (size_t)K * blocks, hipMemcpyHostToDevice, st));
-  const double f = -carrier_hz / fs;                                     // nco.nco(-doppler/fs,0,n)  (acquire-gps-l2cl.py:18)
-  if (!nco_range_ok(std::fabs(f), n)) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "gacq_longcode_search: NCO phase index out of range");
   hipLaunchKernelGGL(longcode_mix_kernel, dim3((unsigned)((total + kLcBlock - 1) / kLcBlock)), dim3(kLcBlock), 0, st,
                      (const float2*)ctx->xstage.p, (float2*)ctx->fe_a.p, (long)n, blocks, f, (const float2*)ctx->tab.p);
   GACQ_HIP(ctx, hipGetLastError());

@@ -399,7 +399,7 @@ int split_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* C, const
   const long ep_first = g0 / D, ep_last = (g0 + ng - 1) / D;
   const long nep = ep_last - ep_first + 1;
   int pch = (int)std::max<long>(1, std::min<long>(8, nep * D * B * R / 2048));
-  if (const char* ev = getenv("GACQ_SPLIT_PCH")) { const int k = atoi(ev); if (k >= 1) pch = k; }
+  if (ctx->opt[GACQ_OPT_SPLIT_PCH] >= 1) pch = (int)ctx->opt[GACQ_OPT_SPLIT_PCH];
   const int nblk_ep = (int)((nep + pch - 1) / pch);
   const dim3 grid((unsigned)((long)R * nblk_ep * D * B));
   if (M == 1980)

@@ -97,8 +97,21 @@ int gacq_use_null_stream(gacq_ctx* ctx);
  * 3 = split engine, outer radix 31/16/4 + rocFFT inner transforms (N = 61380, 30690, 65536, 16384),
  * 4 = split engine with the inner transforms on the LDS FFT kernels (N = 65536, 16384). */
 int gacq_set_engine(gacq_ctx* ctx, int engine);
-/* Upper bound for the library-owned correlation workspace in bytes (default 4 GiB). */
+/* Upper bound for the library-owned correlation workspace in bytes (default 4 GiB).  A search whose forward spectra
+ * for one epoch exceed it is cut into Doppler slices that fit; the slices are merged in grid order with strict '>'
+ * (acquire-gps-l1.py:36-39), so the result is the one of a single scan. */
 int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes);
+/* Tuning switches of the launch path.  They are ctx state set through this call; nothing in the library reads the
+ * environment.  Defaults in brackets. */
+#define GACQ_OPT_FUSED_INNER 0  /* [1] engine 3: conj-multiply fused into the Stockham inner inverse transforms         */
+#define GACQ_OPT_FUSED_16K 1    /* [1] N = 16384 with one carrier per item: forward + correlate in one kernel           */
+#define GACQ_OPT_LDS_VARIANT 2  /* [-1 = built-in choice] register/occupancy variant of lds_correlate_kernel            */
+#define GACQ_OPT_LDS_PCH 3      /* [0 = auto] items per workgroup of the LDS correlate kernels                          */
+#define GACQ_OPT_SPLIT_PCH 4    /* [0 = auto] (epoch, item) rows per workgroup of the split engines' inner kernels      */
+#define GACQ_OPT_GRAPH 5        /* [0] 1: gacq_search replays a captured hipGraph when the call shape repeats           */
+#define GACQ_NOPTS 6
+int gacq_set_option(gacq_ctx* ctx, int option, long value);
+int gacq_get_option(gacq_ctx* ctx, int option, long* value);
 
 /* Build a signal: replicas from the built-in generators -> code spectra C_p resident on the device.
  * Replaces acquire-gps-l1.py:22-24 (c = ca.code(...); c = fft.fft(c)) for every PRN in `prns`. */

@@ -184,14 +184,14 @@ def test_glonass_fused_16k_kernel_equals_two_kernel_path(engine):
         torch.cuda.synchronize()                                       # the engine launches on its own stream
         fused = fused.cpu().numpy()
         assert engine.stage_times()["mix_nco"][1] == 0                 # no separate forward launch
-        os.environ["GACQ_NO_FUSED_16K"] = "1"
+        engine.set_option("fused_16k", 0)
         engine.reset_stage_times()
         plain = engine.search_batch_dev(sig, xd, items, dop, B)
         torch.cuda.synchronize()
         plain = plain.cpu().numpy()
         assert engine.stage_times()["mix_nco"][1] == 1
     finally:
-        os.environ.pop("GACQ_NO_FUSED_16K", None)
+        engine.set_option("fused_16k", 1)
         engine.set_profiling(False)
     assert fused.tobytes() == plain.tobytes()
 
@@ -679,4 +679,91 @@ def test_epoch_chunking_with_small_workspace():
             np.testing.assert_allclose(pa["metric"], pb["metric"], rtol=1e-6)
     finally:
         big.close()
+        small.close()
+
+
+@pytest.mark.parametrize("name,ms", [("galileo-e1b", 4), ("gps-l2cm", 20), ("beidou-b1i", 0), ("gps-l1", 0)])
+def test_zero_blocks_never_reads_x(engine, name, ms):
+    """ms -> B == 0 (galileo-e1b ms < 8, gps-l2cm ms < 40): the reference's block loop is empty, it returns its untouched
+    (0, 0, 0) and never looks at x.  Padded signals used to stage (0 + pad) * n samples from the caller's buffer anyway
+    (ADVICE r1): here x is ONE sample long, both through the Python mirror and straight through the C ABI."""
+    import ctypes
+    from gnss_dsp_tools_amd import _native as nat
+    from gnss_dsp_tools_amd import acquire, signals
+    sig = signals.get(name)
+    assert sig.blocks(ms) <= 0
+    x = np.ones(1, dtype=np.complex64)
+    ds = [-500.0, 500.0, 250.0]
+    assert acquire.make_search(name, engine)(x, 1, ds, ms) == (0, 0, 0)
+    assert engine.search_all(sig, x, [1, 2], ds, ms) == [(0, 0, 0), (0, 0, 0)]
+    s = engine.signal(sig, [1, 2])
+    items = np.array([0, 1], dtype=np.int32)
+    dop = acquire.doppler_grid(ds)
+    res = (nat.Result * 2)()
+    rc = nat.lib.gacq_search(s._h, x.ctypes.data_as(nat.c_float_p), 1, items.ctypes.data_as(nat.c_int_p), 2,
+                             dop.ctypes.data_as(nat.c_double_p), len(dop), None, 0, res)
+    assert rc == 0 and [(r.metric, r.idx, r.d_index) for r in res] == [(0.0, -1, -1)] * 2
+
+
+def test_empty_item_list_and_out_buffer_validation(engine):
+    """search_all over no items is [] like the reference's map over an empty list; a caller-supplied result buffer of the
+    wrong shape / dtype / layout is refused instead of being overwritten by the last kernel."""
+    import torch
+    from gnss_dsp_tools_amd import acquire, signals, synth
+    sig = signals.get("gps-l1")
+    x = synth.make_iq(sig, 1, 5, [(3, 0.5, 1000.0, 100)], nsamp=4096)
+    assert engine.search_all(sig, x, [], [-500.0, 500.0, 250.0], 1) == []
+    xd = torch.from_numpy(x[None]).cuda()
+    dop = acquire.doppler_grid([-500.0, 1500.0, 250.0])
+    assert tuple(engine.search_batch_dev(sig, xd, [], dop, 1).shape) == (1, 0, 2)
+    for bad in (torch.empty((1, 3, 2), dtype=torch.float32, device="cuda"), torch.empty((1, 2, 2), dtype=torch.float64, device="cuda"),
+                torch.empty((1, 3, 4), dtype=torch.float64, device="cuda")[:, :, ::2], torch.empty((1, 3, 2), dtype=torch.float64)):
+        with pytest.raises(ValueError):
+            engine.search_batch_dev(sig, xd, [1, 2, 3], dop, 1, out=bad)
+    good = torch.empty((1, 3, 2), dtype=torch.float64, device="cuda")
+    assert engine.search_batch_dev(sig, xd, [1, 2, 3], dop, 1, out=good) is good
+    torch.cuda.synchronize()
+    assert engine.finalize(sig, [1, 2, 3], good.cpu().numpy().view(acquire.PEAK_DTYPE).reshape(3), dop) == engine.search_blocks(sig, x, [1, 2, 3], dop, 1)
+
+
+def test_signal_handle_outliving_its_engine_is_harmless():
+    """Engine.close() destroys every signal created on it (also user-held ones) before the context, so a later close() /
+    garbage collection of the AcqSignal cannot touch a freed context."""
+    from gnss_dsp_tools_amd import acquire, signals
+    eng = acquire.Engine(0)
+    held = acquire.AcqSignal(eng, signals.get("gps-l1"), [1, 2, 3])        # not through the engine's cache
+    cached = eng.signal("gps-l1", [4, 5])
+    eng.close()
+    assert held._h is None and cached._h is None
+    held.close()
+    del held, cached
+
+
+def test_doppler_slicing_when_one_epoch_exceeds_the_workspace(engine):
+    """One epoch's forward spectra [D][B][N] larger than the workspace limit (galileo-e1b --time 200 would be 9 GB): the grid is
+    searched in slices and merged with strict '>' in grid order -- same records as the single pass, on every engine that
+    buffers X.  1 MiB limit: gps-l1 B=3 -> 10 bins per slice; beidou-b1i B=2 -> 4; galileo-e1b -> 2."""
+    import torch
+    from gnss_dsp_tools_amd import acquire, signals, synth
+    small = acquire.Engine(0, workspace_bytes=1 << 20)
+    try:
+        for name, items, ds, ms, engines in [("gps-l1", [3, 4, 11, 28], [-5000.0, 5000.0, 250.0], 3, (0, 1)),
+                                             ("beidou-b1i", [6, 7, 33], [-2000.0, 2000.0, 250.0], 2, (0, 1, 4)),
+                                             ("galileo-e1b", [5, 24], [-1000.0, 1000.0, 125.0], 8, (0,)),
+                                             ("gps-l5i", [7, 8], [-1000.0, 1000.0, 200.0], 1, (0,))]:
+            sig = signals.get(name)
+            B = sig.blocks(ms)
+            xs = synth.make_epochs(sig, B, 4242, [(items[0], 0.4, 537.0, 1201)], 2)
+            xd = torch.from_numpy(xs).cuda()
+            dop = acquire.doppler_grid(ds)
+            assert 8 * len(dop) * B * sig.nfft > (1 << 20)
+            for e in engines:
+                engine.set_engine(e)
+                small.set_engine(e)
+                a = engine.search_batch_dev(sig, xd, items, dop, B)
+                b = small.search_batch_dev(sig, xd, items, dop, B)
+                torch.cuda.synchronize()
+                assert a.cpu().numpy().tobytes() == b.cpu().numpy().tobytes(), (name, e)
+    finally:
+        engine.set_engine(0)
         small.close()

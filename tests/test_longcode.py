@@ -60,3 +60,17 @@ def test_gpu_longcode_edge_cases(engine):
     assert longcode.search_l2cl(x, 1, 0.0, 0.0, 20, 4092000.0, engine=engine) == (0, 0)      # all-zero input: nothing beats 0
     with pytest.raises(ValueError):
         longcode.search_l2cl(x[:1000], 1, 0.0, 0.0, 20, 4092000.0, engine=engine)
+
+
+@pytest.mark.gpu
+def test_gpu_negative_code_phase_wraps_like_numpy_mod(engine):
+    """A negative ca_code_phase makes the P-code start phase negative; the reference's np.mod(idx, code_length) is floored, so
+    the index wraps upwards (the kernel used to read chips[] out of bounds)."""
+    from gnss_dsp_tools_amd import longcode, synth
+    from oracle import longcode_oracle
+    fs = 16368000.0
+    x = synth.make_longcode_iq("glonass.p", 0, 5110000.0, 5110000, fs, int(fs * 0.008), 777, 0.6, 562500.0 * 2 + 250.0, 5110000 - 37.25 * 10)
+    want = longcode_oracle.search_glonass_p(x.astype(np.complex128), 2, 250.0, -37.25, 8, fs, band="l1")
+    got = longcode.search_glonass_p(x, 2, 250.0, -37.25, 8, fs, band="l1", engine=engine)
+    assert got[1] == want[1] and got[0] == pytest.approx(want[0], rel=1e-5)
+    assert got[1] == 0                 # the satellite sits at the candidate whose start phase is negative

@@ -1,10 +1,22 @@
 #!/bin/bash
-# Build profiling-only ablation variants of the engine (wrong results by construction) into lib/libgacq_abl<N>.so
-# usage (build container): tools/ablate.sh 1 2 3 ...   ; on the GPU box: GACQ_LIB=.../libgacq_abl1.so python bench.py ...
+# Build profiling-only ablation variants of the engine (wrong results by construction) into build/abl<N>/libgacq.so.
+# usage (build container): tools/ablate.sh 1 2 3 ...
+# on the GPU box (scratch copy of the repo): tools/ablate.sh --run N -- python bench.py --no-self-check ...
+#   swaps lib/libgacq.so for the variant for the duration of the command and puts the product build back afterwards
+#   (the product never loads a library from anywhere but lib/libgacq.so).
 set -e
-cd "$(dirname "$0")/../gnss-dsp-tools_amd/csrc"
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+if [ "$1" = "--run" ]; then
+  a=$2; shift 3
+  cp "$ROOT/gnss-dsp-tools_amd/lib/libgacq.so" "$ROOT/gnss-dsp-tools_amd/lib/libgacq.so.product"
+  cp "$ROOT/gnss-dsp-tools_amd/build/abl$a/libgacq.so" "$ROOT/gnss-dsp-tools_amd/lib/libgacq.so"
+  "$@" || true
+  mv "$ROOT/gnss-dsp-tools_amd/lib/libgacq.so.product" "$ROOT/gnss-dsp-tools_amd/lib/libgacq.so"
+  exit 0
+fi
+cd "$ROOT/gnss-dsp-tools_amd/csrc"
 for a in "$@"; do
   mkdir -p ../build/abl$a
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I/opt/rocm/include -DGACQ_ABL=$a -c gacq_ldsfft.hip -o ../build/abl$a/gacq_ldsfft.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libgacq_abl$a.so $(ls ../build/*.o | grep -v gacq_ldsfft.o) ../build/abl$a/gacq_ldsfft.o -L/opt/rocm/lib -lrocfft -Wl,-rpath,/opt/rocm/lib
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../build/abl$a/libgacq.so $(ls ../build/*.o | grep -v gacq_ldsfft.o) ../build/abl$a/gacq_ldsfft.o -L/opt/rocm/lib -lrocfft -Wl,-rpath,/opt/rocm/lib
 done
