@@ -101,6 +101,11 @@ int lds_fused_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, i
 int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const int* d_items, const int* d_fset,
                   int nepoch, int nitems, int F, int D, int B, int N, RowRec* rows);
 
+// test hook (gacq_debug_nco_indices): the forward kernel's own NCO index expression for one row, d_idx[N]; fused: the
+// one-kernel N = 16384 search
+int lds_debug_nco(gacq_ctx* ctx, int N, int n, const double* d_freq, bool fused, int* d_idx);
+int split_debug_nco(gacq_ctx* ctx, int N, int n, const double* d_freq, int* d_idx);
+
 // split engines (gacq_split.hip): N = R*M, hand-written outer DFT-R, inner length-M transforms (rocFFT, Stockham LDS or the 4096 kernels)
 bool split_supported(int N);
 // outer DFT-31 (+NCO mix when mix) + twiddle, then the inner forward transforms; X in [k1][k2] order

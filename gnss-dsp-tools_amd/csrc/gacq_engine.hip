@@ -152,6 +152,9 @@ void stage_end(gacq_ctx* ctx) {
 // K1: carrier wipe-off with the reference's 10-bit phase-quantised table NCO.
 // The table index is computed in fp64 exactly like numpy does: floor((0 + f*i) * 1024) mod 1024
 // (gnsstools/nco.py:6-9); one v_mul_f64 per sample is noise next to the HBM traffic.
+// DUMP (test hook gacq_debug_nco_indices): the same index expression on the same frequency table, stored as int32 instead of
+// being used for the table lookup; x is not read.
+template <bool DUMP>
 __global__ __launch_bounds__(kBlock) void mix_nco_kernel(const float2* __restrict__ x, size_t epoch_stride,
                                                           float2* __restrict__ y, const double* __restrict__ freq,
                                                           const float2* __restrict__ tab, int n, int span, int FD, int B,
@@ -174,6 +177,12 @@ __global__ __launch_bounds__(kBlock) void mix_nco_kernel(const float2* __restric
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int i0 = base + (j * kBlock + threadIdx.x) * 2;
+    if (DUMP) {
+      int* out = reinterpret_cast<int*>(y) + row * (long)span;
+      if (i0 < span) out[i0] = nco_index(f, (int)i0);
+      if (i0 + 1 < span) out[i0 + 1] = nco_index(f, (int)(i0 + 1));
+      continue;
+    }
     if (i0 + 1 < span) {
       const float4 s = *reinterpret_cast<const float4*>(src + i0);
       const int k0 = nco_index(f, (int)i0);
@@ -696,7 +705,7 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
         if (rc != GACQ_OK) return rc;
       } else {
         stage_begin(ctx, 0);
-        hipLaunchKernelGGL(mix_nco_kernel, dim3((unsigned)(rows_x * chunksN)), dim3(kBlock), 0, st, xe, nsamp, X,
+        hipLaunchKernelGGL(mix_nco_kernel<false>, dim3((unsigned)(rows_x * chunksN)), dim3(kBlock), 0, st, xe, nsamp, X,
                            (const double*)ctx->freq.p, (const float2*)ctx->tab.p, n, N, F * D, B, chunksN);
         stage_end(ctx);
         GACQ_HIP(ctx, hipGetLastError());
@@ -932,6 +941,41 @@ int gacq_search(gacq_sig* sig, const float* x_iq, size_t nsamp, const int* items
   if (rc != GACQ_OK) return rc;
   GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return gacq_finalize(&sig->desc, (const gacq_peak*)ctx->pin_peaks.p, 1, nullptr, nitems, dopplers, nd, out);
+}
+
+int gacq_debug_nco_indices(gacq_sig* sig, int kernel, double doppler, double bias_hz, int* idx_out) {
+  if (!sig || !idx_out || !std::isfinite(doppler) || !std::isfinite(bias_hz))
+    return set_error(sig ? sig->ctx : nullptr, GACQ_ERR_BAD_ARG, "gacq_debug_nco_indices: bad argument");
+  gacq_ctx* ctx = sig->ctx;
+  GACQ_DEVICE(ctx);
+  const int n = sig->desc.n, N = sig->N;
+  // the frequency goes through the same host expression as a search (fp64, the reference's operation order)
+  const Grid g = make_grid(sig->desc, 1, &doppler, 1, bias_hz != 0.0 ? &bias_hz : nullptr);
+  if (!nco_range_ok(std::fabs(g.freq[0]), N)) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "gacq_debug_nco_indices: NCO phase index out of range");
+  int rc;
+  if ((rc = ensure(ctx, ctx->freq, sizeof(double))) != GACQ_OK) return rc;
+  ctx->up_freq.clear();                                   // the cached search grid is overwritten
+  if ((rc = ensure(ctx, ctx->Y, sizeof(int) * (size_t)N)) != GACQ_OK) return rc;
+  GACQ_HIP(ctx, hipMemcpyAsync(ctx->freq.p, g.freq.data(), sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  GACQ_HIP(ctx, hipMemsetAsync(ctx->Y.p, 0xff, sizeof(int) * (size_t)N, ctx->stream));
+  int* d_idx = (int*)ctx->Y.p;
+  switch (kernel) {
+    case 1: {
+      const int chunksN = (N + kBlock * 8 - 1) / (kBlock * 8);
+      hipLaunchKernelGGL(mix_nco_kernel<true>, dim3((unsigned)chunksN), dim3(kBlock), 0, ctx->stream, (const float2*)nullptr, (size_t)0,
+                         (float2*)d_idx, (const double*)ctx->freq.p, (const float2*)ctx->tab.p, n, N, 1, 1, chunksN);
+      GACQ_HIP(ctx, hipGetLastError());
+      break;
+    }
+    case 2: rc = lds_debug_nco(ctx, N, n, (const double*)ctx->freq.p, false, d_idx); break;
+    case 3: rc = split_debug_nco(ctx, N, n, (const double*)ctx->freq.p, d_idx); break;
+    case 4: rc = lds_debug_nco(ctx, N, n, (const double*)ctx->freq.p, true, d_idx); break;
+    default: rc = set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_debug_nco_indices: kernel must be 1..4");
+  }
+  if (rc != GACQ_OK) return rc;
+  GACQ_HIP(ctx, hipMemcpyAsync(idx_out, d_idx, sizeof(int) * (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
+  GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return GACQ_OK;
 }
 
 int gacq_debug_row(gacq_sig* sig, const float* x_iq, size_t nsamp, int item, double doppler, double bias_hz, int blocks,

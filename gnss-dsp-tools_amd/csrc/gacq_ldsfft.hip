@@ -117,6 +117,9 @@ __device__ __forceinline__ void ld_pair(__amdgpu_buffer_rsrc_t r, unsigned lane_
 }
 
 // ---- forward: one workgroup per (e, f, d, b) row -------------------------------------------------
+// DUMP (test hook gacq_debug_nco_indices): the index expression below, on the same frequency table, is stored as int32 into X
+// (reinterpreted) and the kernel returns; x is not read.
+template <bool DUMP>
 __global__ __launch_bounds__(kBlock) void lds_forward_kernel(const float2* __restrict__ x, size_t epoch_stride,
                                                               float2* __restrict__ X, const double* __restrict__ freq,
                                                               const float2* __restrict__ nco_tab,
@@ -134,11 +137,13 @@ __global__ __launch_bounds__(kBlock) void lds_forward_kernel(const float2* __res
 #pragma unroll
   for (int j = 0; j < kR; j++) {
     const int i = t + 256 * j;
-    v[j] = ld2(src + i);
     // table NCO, index in fp64 exactly as numpy: floor((0 + f*i)*1024) mod 1024   (gnsstools/nco.py:6-9)
     const int k = nco_index(f, (int)i);
+    if (DUMP) { reinterpret_cast<int*>(X)[row * (long)kLdsN + i] = k; continue; }
+    v[j] = ld2(src + i);
     w[j] = ld2(nco_tab + k);
   }
+  if (DUMP) return;
   const v2 twa = ld2(tw + t), twb = ld2(tw + 16 * (t & 15));
 #pragma unroll
   for (int j = 0; j < kR; j++) v[j] = cmul(v[j], w[j]);
@@ -208,6 +213,7 @@ __device__ __forceinline__ void ld_pair_big(__amdgpu_buffer_rsrc_t r, unsigned l
 }
 
 // forward: one workgroup per (e, f, d, b) row; output conj(FFT) in the 1024-lane pair layout (j>>1)*2048 + 2 lane + (j&1)
+template <bool DUMP>
 __global__ __launch_bounds__(kBigThreads) void lds16k_forward_kernel(const float2* __restrict__ x, size_t epoch_stride,
                                                                       float2* __restrict__ X, const double* __restrict__ freq,
                                                                       const float2* __restrict__ nco_tab,
@@ -226,10 +232,12 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_forward_kernel(const float
 #pragma unroll
   for (int j = 0; j < kR; j++) {
     const int i = t + 1024 * j;
-    v[j] = ld2(src + i);
     const int k = nco_index(f, (int)i);   // gnsstools/nco.py:6-9
+    if (DUMP) { reinterpret_cast<int*>(X)[row * (long)kBig + i] = k; continue; }
+    v[j] = ld2(src + i);
     w[j] = ld2(nco_tab + k);
   }
+  if (DUMP) return;
   const v2 base = ld2(twn + t);
 #pragma unroll
   for (int j = 0; j < kR; j++) v[j] = cmul(v[j], w[j]);
@@ -344,6 +352,7 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_correlate_kernel(const flo
 // (8 N bytes each way per row) buys nothing.  Workgroup = (epoch, Doppler bin, item); per block b: mix + forward FFT,
 // one LDS pass back to natural lane order, conj * C_p, inverse FFT, |.| accumulated in registers.  Same arithmetic in the
 // same order as lds16k_forward_kernel + lds16k_correlate_kernel.
+template <bool DUMP>
 __global__ __launch_bounds__(kBigThreads) void lds16k_fused_kernel(const float2* __restrict__ x, size_t epoch_stride,
                                                                     const float2* __restrict__ C, const int* __restrict__ items,
                                                                     const int* __restrict__ fset, const double* __restrict__ freq,
@@ -376,9 +385,12 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_fused_kernel(const float2*
 #pragma unroll
     for (int j = 0; j < kR; j++) {
       const int i = t + 1024 * j;
+      const int k = nco_index(f, i);                  // gnsstools/nco.py:6-9
+      if (DUMP) { reinterpret_cast<int*>(rows)[(long)blockIdx.x * kBig + i] = k; continue; }
       v[j] = ld2(src + i);
-      w[j] = ld2(nco_tab + nco_index(f, i));          // gnsstools/nco.py:6-9
+      w[j] = ld2(nco_tab + k);
     }
+    if (DUMP) return;
 #pragma unroll
     for (int j = 0; j < kR; j++) v[j] = cmul(v[j], w[j]);
     fft16k<false>(v, lds, twn, base);
@@ -718,8 +730,8 @@ int lds_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n,
     const float2* twn;
     int rcb = twiddle_cache(ctx, "W16384_lo", kBig, 1024, &twn);
     if (rcb != GACQ_OK) return rcb;
-    GACQ_HIP(ctx, hipFuncSetAttribute((const void*)lds16k_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes));
-    hipLaunchKernelGGL(lds16k_forward_kernel, dim3((unsigned)((long)nepoch * FD * B)), dim3(kBigThreads), kBigLdsBytes, ctx->stream, x,
+    GACQ_HIP(ctx, hipFuncSetAttribute((const void*)lds16k_forward_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes));
+    hipLaunchKernelGGL(lds16k_forward_kernel<false>, dim3((unsigned)((long)nepoch * FD * B)), dim3(kBigThreads), kBigLdsBytes, ctx->stream, x,
                        nsamp, X, d_freq, tab, twn, n, FD, B);
     GACQ_HIP(ctx, hipGetLastError());
     return GACQ_OK;
@@ -728,7 +740,7 @@ int lds_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n,
   int rc = twiddle_table(ctx, &tw);
   if (rc != GACQ_OK) return rc;
   const long rows = (long)nepoch * FD * B;
-  hipLaunchKernelGGL(lds_forward_kernel, dim3((unsigned)rows), dim3(kBlock), 0, ctx->stream, x, nsamp, X, d_freq, tab, tw, n, FD, B);
+  hipLaunchKernelGGL(lds_forward_kernel<false>, dim3((unsigned)rows), dim3(kBlock), 0, ctx->stream, x, nsamp, X, d_freq, tab, tw, n, FD, B);
   GACQ_HIP(ctx, hipGetLastError());
   return GACQ_OK;
 }
@@ -741,9 +753,32 @@ int lds_fused_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, i
   const float2* twn;
   int rc = twiddle_cache(ctx, "W16384_lo", kBig, 1024, &twn);
   if (rc != GACQ_OK) return rc;
-  GACQ_HIP(ctx, hipFuncSetAttribute((const void*)lds16k_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes));
-  hipLaunchKernelGGL(lds16k_fused_kernel, dim3((unsigned)((long)nepoch * D * nitems)), dim3(kBigThreads), kBigLdsBytes, ctx->stream, x,
+  GACQ_HIP(ctx, hipFuncSetAttribute((const void*)lds16k_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes));
+  hipLaunchKernelGGL(lds16k_fused_kernel<false>, dim3((unsigned)((long)nepoch * D * nitems)), dim3(kBigThreads), kBigLdsBytes, ctx->stream, x,
                      nsamp, spectra, d_items, d_fset, d_freq, tab, twn, rows, n, nitems, D, B);
+  GACQ_HIP(ctx, hipGetLastError());
+  return GACQ_OK;
+}
+
+int lds_debug_nco(gacq_ctx* ctx, int N, int n, const double* d_freq, bool fused, int* d_idx) {
+  if (!lds_supported(N) || (fused && N != kBig)) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "NCO index dump: no %sLDS forward kernel for N=%d", fused ? "fused " : "", N);
+  if (N == kBig && fused) {
+    int rc = ensure(ctx, ctx->fset, sizeof(int));
+    if (rc != GACQ_OK) return rc;
+    ctx->up_fset.clear();
+    GACQ_HIP(ctx, hipMemsetAsync(ctx->fset.p, 0, sizeof(int), ctx->stream));
+    GACQ_HIP(ctx, hipFuncSetAttribute((const void*)lds16k_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes));
+    hipLaunchKernelGGL(lds16k_fused_kernel<true>, dim3(1), dim3(kBigThreads), kBigLdsBytes, ctx->stream, (const float2*)nullptr, (size_t)0,
+                       (const float2*)nullptr, (const int*)ctx->fset.p, (const int*)ctx->fset.p, d_freq, (const float2*)nullptr,
+                       (const float2*)nullptr, (RowRec*)d_idx, n, 1, 1, 1);
+  } else if (N == kBig) {
+    GACQ_HIP(ctx, hipFuncSetAttribute((const void*)lds16k_forward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes));
+    hipLaunchKernelGGL(lds16k_forward_kernel<true>, dim3(1), dim3(kBigThreads), kBigLdsBytes, ctx->stream, (const float2*)nullptr, (size_t)0,
+                       (float2*)d_idx, d_freq, (const float2*)nullptr, (const float2*)nullptr, n, 1, 1);
+  } else {
+    hipLaunchKernelGGL(lds_forward_kernel<true>, dim3(1), dim3(kBlock), 0, ctx->stream, (const float2*)nullptr, (size_t)0, (float2*)d_idx, d_freq,
+                       (const float2*)nullptr, (const float2*)nullptr, n, 1, 1);
+  }
   GACQ_HIP(ctx, hipGetLastError());
   return GACQ_OK;
 }

@@ -27,7 +27,8 @@ namespace {
 
 // ---- forward outer stage ---------------------------------------------------------------------------
 // grid = rows * chunks; thread -> n2.  MIX: multiply by the table NCO (rows = (e,f,d,b)); otherwise plain rows.
-template <int R, bool MIX>
+// DUMP (test hook gacq_debug_nco_indices, MIX only): the index expression is stored as int32 into A (reinterpreted), x is not read.
+template <int R, bool MIX, bool DUMP = false>
 __global__ __launch_bounds__(kBlock) void split_outer_forward_kernel(const float2* __restrict__ x, size_t epoch_stride,
                                                                     float2* __restrict__ A, const double* __restrict__ freq,
                                                                     const float2* __restrict__ nco_tab,
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(kBlock) void split_outer_forward_kernel(const float
 #pragma unroll
   for (int n1 = 0; n1 < R; n1++) {
     const int i = M * n1 + n2;
+    if (DUMP) { reinterpret_cast<int*>(A)[row * (long)(R * M) + i] = nco_index(f, (int)i); continue; }
     const float2 sf = src[i];
     v[n1] = v2{sf.x, sf.y};
     if (MIX) {
@@ -64,6 +66,7 @@ __global__ __launch_bounds__(kBlock) void split_outer_forward_kernel(const float
       w[n1] = v2{wf.x, wf.y};
     }
   }
+  if (DUMP) return;
   const float2 twf = tw[n2];            // W_N^{n2}
   if (MIX) {
 #pragma unroll
@@ -443,6 +446,30 @@ int split_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, long rows, int n
   if (rc != GACQ_OK) return rc;
   if (!inner) return GACQ_OK;
   return fft_exec(ctx, M, rows * R, false, X);            // inner transforms, rows contiguous
+}
+
+namespace {
+template <int R>
+void launch_dump(gacq_ctx* ctx, int n, int M, const double* d_freq, int* d_idx) {
+  const int chunks = (M + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL((split_outer_forward_kernel<R, true, true>), dim3((unsigned)chunks), dim3(kBlock), 0, ctx->stream, (const float2*)nullptr,
+                     (size_t)0, (float2*)d_idx, d_freq, (const float2*)nullptr, (const float2*)nullptr, n, M, 1, 1, chunks);
+}
+}  // namespace
+
+int split_debug_nco(gacq_ctx* ctx, int N, int n, const double* d_freq, int* d_idx) {
+  const int R = split_radix(N);
+  if (!R) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "NCO index dump: split engine does not support N=%d", N);
+  const int M = N / R;
+  switch (R) {
+    case 31: launch_dump<31>(ctx, n, M, d_freq, d_idx); break;
+    case 40: launch_dump<40>(ctx, n, M, d_freq, d_idx); break;
+    case 20: launch_dump<20>(ctx, n, M, d_freq, d_idx); break;
+    case 16: launch_dump<16>(ctx, n, M, d_freq, d_idx); break;
+    default: launch_dump<4>(ctx, n, M, d_freq, d_idx); break;
+  }
+  GACQ_HIP(ctx, hipGetLastError());
+  return GACQ_OK;
 }
 
 int split_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng, int B, int N, float* q_out, bool inner, bool twiddle_only) {

@@ -202,6 +202,14 @@ const char* gacq_stage_name(int stage);
 int gacq_debug_row(gacq_sig* sig, const float* x_iq, size_t nsamp, int item, double doppler,
                    double bias_hz, int blocks, float* q_out);
 
+/* Table-NCO index vector idx[i] = floor((0 + f*i)*1024) mod 1024, i < N (gnsstools/nco.py:6-9), f = -(bias + doppler)/fs as a
+ * search forms it, computed ON THE DEVICE by the forward kernel of the chosen path with the very expression it uses for its
+ * table lookup (the kernels are instantiated in a dump mode that stores the index instead of using it).  Index work is
+ * bit-exact against the reference; a wrong index moves the metric by less than the 1e-5 tolerance, so it gets its own check.
+ * kernel: 1 mix_nco_kernel (rocFFT pipeline), 2 lds_forward_kernel / lds16k_forward_kernel, 3 split_outer_forward_kernel,
+ *         4 lds16k_fused_kernel.  GACQ_ERR_UNSUPPORTED when that kernel does not serve the signal's N. */
+int gacq_debug_nco_indices(gacq_sig* sig, int kernel, double doppler, double bias_hz, int* idx_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -767,3 +767,37 @@ def test_doppler_slicing_when_one_epoch_exceeds_the_workspace(engine):
     finally:
         engine.set_engine(0)
         small.close()
+
+
+NCO_KERNELS = {            # (fs, N) -> (script, forward kernels that serve this length: 1 mix_nco, 2 LDS, 3 split outer, 4 fused 16K)
+    (4096000.0, 4096): ("gps-l1", (1, 2)),
+    (8192000.0, 65536): ("galileo-e1b", (1, 3)),
+    (30690000.0, 61380): ("gps-l5i", (1, 3)),
+    (16384000.0, 16384): ("glonass-l1", (1, 2, 3, 4)),
+    (8192000.0, 16384): ("beidou-b1i", (1, 2, 3, 4)),
+}
+
+
+def test_device_nco_indices_are_bit_exact(engine, golden_nco):
+    """index work is bit-exact.  Every forward kernel evaluates floor((f*i)*1024) mod 1024 itself (fp64 on the
+    device); one wrong index in 4096 moves the metric by ~1e-6, inside the 1e-5 tolerance of the search tests, so each kernel
+    dumps its index vector and the SHA-256 must equal the reference's (tests/golden/nco_indices.json, produced by
+    gnsstools/nco.py:6-10 incl. the GLONASS-biased carriers of acquire-glonass-l1.py:28)."""
+    import hashlib
+    from gnss_dsp_tools_amd import _native as nat
+    from gnss_dsp_tools_amd import signals
+    checked = 0
+    for v in golden_nco["vectors"]:
+        script, kernels = NCO_KERNELS[(v["fs"], v["n"])]
+        sig = signals.get(script)
+        s = engine.signal(sig, [0] if sig.bias_hz else [1])
+        for k in kernels:
+            idx = s.nco_indices(k, v["doppler"], v.get("bias", 0.0))
+            assert idx.dtype == np.int32 and len(idx) == v["n"]
+            assert [int(i) for i in idx[:16]] == v["head"] and [int(i) for i in idx[-16:]] == v["tail"], (script, k, v["doppler"])
+            assert hashlib.sha256(idx.tobytes()).hexdigest() == v["sha256"], (script, k, v["doppler"])
+            checked += 1
+    assert checked == 6 * 2 + 3 * 2 + 3 * 2 + 2 * 4 + 2 * 4 + 2 * 4
+    with pytest.raises(nat.GacqError) as ei:             # no LDS forward kernel for N = 65536
+        engine.signal("galileo-e1b", [1]).nco_indices(2, 125.0)
+    assert ei.value.code == -9
