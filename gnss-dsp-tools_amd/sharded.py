@@ -110,6 +110,11 @@ class ShardedSearch:
         {name, x, items, dopplers, blocks}.  Every job's Doppler grid is sliced over the ranks like search_batch, all
         local peaks are packed into ONE buffer and exchanged with a single all-gather, then merged per job.
         Returns the list of merged peak tensors (one per job, [nepoch, nitems, 2])."""
+        return self.search_jobs_async(jobs, async_op=False).wait()
+
+    def search_jobs_async(self, jobs, async_op=True):
+        """search_jobs with the single all-gather issued asynchronously and the per-job merges deferred to
+        PendingJobs.wait(): queueing the next step before waiting puts the exchange under the next step's kernels."""
         import torch
         locals_, bounds, shapes = [], [], []
         for job in jobs:
@@ -124,19 +129,12 @@ class ShardedSearch:
             locals_.append(loc.contiguous())
             bounds.append(b)
             shapes.append(tuple(loc.shape))
-        if self.world == 1 and not (self.always_gather and self.dist.is_initialized()):
-            return locals_
+        if self._solo():
+            return PendingJobs(self, locals_, None, None, shapes, bounds)
         flat = torch.cat([t.view(-1) for t in locals_])
         gathered = torch.empty(self.world * flat.numel(), dtype=flat.dtype, device=flat.device)
-        self.dist.all_gather_into_tensor(gathered, flat, group=self.group)                    # the ONE collective
-        gathered = gathered.view(self.world, flat.numel())
-        out, off = [], 0
-        for shp, b in zip(shapes, bounds):
-            cnt = int(np.prod(shp))
-            part = gathered[:, off:off + cnt].contiguous().view((self.world,) + shp)
-            off += cnt
-            out.append(self.engine.merge_peaks_dev(part, b[:-1]) if part.is_cuda else merge_peaks_host(part.numpy(), b[:-1]))
-        return out
+        work = self.dist.all_gather_into_tensor(gathered, flat, group=self.group, async_op=async_op)      # the ONE collective
+        return PendingJobs(self, locals_, gathered.view(self.world, flat.numel()), work if async_op else None, shapes, bounds)
 
     def results(self, name, items, merged, dopplers):
         """Merged peaks -> per-epoch lists of the reference's (metric, code, doppler) tuples."""
@@ -159,6 +157,33 @@ class PendingSearch:
         if self.work is not None:
             self.work.wait()
         return self.finish(self.gathered)
+
+
+class PendingJobs:
+    """A sharded multi-job search whose single exchange may still be in flight (ShardedSearch.search_jobs_async)."""
+
+    def __init__(self, owner, locals_, gathered, work, shapes, bounds):
+        self.owner, self.locals_, self.gathered, self.work, self.shapes, self.bounds = owner, locals_, gathered, work, shapes, bounds
+
+    def shards(self):
+        """The un-merged exchange buffer [world, sum of job record counts * 2] (None on a single rank): what every rank
+        received from every other rank."""
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        return self.gathered
+
+    def wait(self):
+        if self.gathered is None:
+            return self.locals_
+        g = self.shards()
+        out, off = [], 0
+        for shp, b in zip(self.shapes, self.bounds):
+            cnt = int(np.prod(shp))
+            part = g[:, off:off + cnt].contiguous().view((self.owner.world,) + shp)
+            off += cnt
+            out.append(self.owner.engine.merge_peaks_dev(part, b[:-1]) if part.is_cuda else merge_peaks_host(part.numpy(), b[:-1]))
+        return out
 
 
 def merge_peaks_host(gathered, shard_d0):

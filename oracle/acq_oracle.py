@@ -164,3 +164,14 @@ def search_script(name, x, item, doppler_search, ms, chips01=None):
         chips01 = codes_oracle.chips(code, 0 if bias else item)
     return search(x, chips01, doppler_search, blocks(ms), fs=fs, n=n, pad=pad, boc=boc,
                   normalised=normalised, fold=fold, bias_hz=(bias * item if bias else 0.0))
+
+
+def search_script_blocks(name, x, item, doppler_search, blocks, chips01=None):
+    """search() of acquire-<name>.py with the block count B given directly instead of through the script's ms -> B rule
+    (BASELINE config 4 runs B2aD at B = 1; the script itself fixes B = 80, acquire-beidou-b2ad.py:29)."""
+    from . import codes_oracle
+    code, fs, n, pad, boc, normalised, fold, _, bias = VARIANTS[name]
+    if chips01 is None:
+        chips01 = codes_oracle.chips(code, 0 if bias else item)
+    return search(x, chips01, doppler_search, blocks, fs=fs, n=n, pad=pad, boc=boc,
+                  normalised=normalised, fold=fold, bias_hz=(bias * item if bias else 0.0))

@@ -33,7 +33,39 @@ def oracle_local(name, x, items, dopplers, blocks):
     return torch.from_numpy(out.view(np.float64).reshape(xs.shape[0], len(items), 2).copy())
 
 
+def main_mix(out_path, spec):
+    """BASELINE config 5 in miniature: several different signals, every grid Doppler-sliced over the ranks, ONE all-gather
+    (search_jobs_async with two steps in flight, as bench.py --config 5 runs it)."""
+    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    try:
+        from gnss_dsp_tools_amd import acquire, sharded, signals, synth
+        jobs = []
+        for name, items, ds, ms in spec:
+            sig = signals.get(name)
+            B = sig.blocks(ms)
+            xs = synth.make_epochs(sig, B, 6060, [(items[0], 0.4, 1537.0, 1201)], 1, nsamp=sig.samples_needed(B))
+            jobs.append({"name": name, "x": torch.from_numpy(xs), "items": items, "dopplers": acquire.doppler_grid(ds), "blocks": B})
+        sh = sharded.ShardedSearch(engine=None, local_fn=oracle_local)
+        p1 = sh.search_jobs_async(jobs)
+        p2 = sh.search_jobs_async(jobs)                     # second step queued before the first merge
+        g = p1.shards()
+        assert g.shape[0] == dist.get_world_size() and bool((g.view(g.shape[0], -1, 2)[:, :, 0] > 0).all())
+        merged = p1.wait()
+        again = p2.wait()
+        res = []
+        for job, m, m2 in zip(jobs, merged, again):
+            assert torch.equal(m, m2)
+            res.append(sh.results(job["name"], job["items"], m, job["dopplers"])[0])
+        if dist.get_rank() == 0:
+            with open(out_path, "w") as f:
+                json.dump([[[float(v) for v in r] for r in job] for job in res], f)
+    finally:
+        dist.destroy_process_group()
+
+
 def main():
+    if os.environ.get("GLOO_MIX"):
+        return main_mix(sys.argv[1], json.loads(sys.argv[2]))
     out_path, name = sys.argv[1], sys.argv[2]
     items = [int(v) for v in sys.argv[3].split(",")]
     ds = [float(v) for v in sys.argv[4].split(",")]

@@ -429,10 +429,12 @@ def test_full_size_properties_configs_3_4_5(engine, name, items, ds, ms):
             assert auto["idx"][items.index(it)] % n == (n - delay % n) % n, (it, delay)
 
 
-def test_bench_under_torchrun_single_rank_exercises_rccl_path():
+@pytest.mark.parametrize("config,extra", [(2, ["--epochs", "8"]), (4, ["--epochs", "1"]), (5, ["--epochs", "1"])])
+def test_bench_under_torchrun_single_rank_exercises_rccl_path(config, extra):
     """The driver launches N>1 through torch.distributed.run; with one GPU the same launcher + --force-gather still
-    exercises RCCL init, the all-gather of peak records on the engine's stream, the device-side merge and the
-    barrier/max-reduce timing code."""
+    exercises RCCL init, the single all-gather of every signal's peak records on the engine's stream, the device-side
+    merge, the shard census and the barrier/max-reduce timing code -- for the headline config and for the multi-signal
+    configs 4 and 5 (ShardedSearch.search_jobs_async), i.e. what `bench.py --gpus 8 --config 4` runs on a node."""
     import json
     import os
     import socket
@@ -445,12 +447,15 @@ def test_bench_under_torchrun_single_rank_exercises_rccl_path():
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-           "--epochs", "8", "--force-gather", "--no-cpu-baseline"]
+           "--config", str(config), "--force-gather", "--no-cpu-baseline", "--sustained-s", "0.2"] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 1 and j["value"] > 1e9 and j["roofline"]["kernel"]
+    assert j["roofline"]["bound"] in ("valu", "hbm") and 0.0 < j["roofline"]["frac"] < 1.0        # a fraction of a real ceiling
+    assert j["config"]["baseline_config"] == config and j["config"]["shards_seen_by_every_rank"] == 1
+    assert j["sustained"]["seconds"] >= 0.2 and len(j["roofline"]["per_rank"]) == 1
 
 
 R31_CASES = ["cfg4_l5i_subset", "l5q_subset", "cfg4_b2ad_b80", "gal_e6b", "gal_e5bq", "bds_b3i", "bds_b2bi", "glo_l3ocd",

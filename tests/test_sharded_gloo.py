@@ -89,6 +89,35 @@ def test_multi_job_search_uses_one_exchange_and_matches_oracle(tmp_path):
             assert got[2] == float(w[2]) and got[1] == float(w[1]) and got[0] == pytest.approx(float(w[0]), rel=1e-12)
 
 
+def test_config5_signal_mix_world2_one_exchange(tmp_path):
+    """bench.py --config 5's job mix (GPS L1 + Galileo E1B + BeiDou B1I + GLONASS L1: four FFT lengths, normalised and raw
+    metrics, padded / BOC / FDMA variants) over 2 ranks: each grid sliced, one all-gather for all four signals, per-signal
+    tie-exact merge == the unsharded oracle."""
+    from gnss_dsp_tools_amd import signals, synth
+    from oracle import acq_oracle
+    spec = [["gps-l1", [3, 28], [-1000.0, 2000.0, 500.0], 2], ["galileo-e1b", [5], [1000.0, 2000.0, 250.0], 10],
+            ["beidou-b1i", [6, 33], [1000.0, 2000.0, 250.0], 2], ["glonass-l1", [-7, 3], [1000.0, 2000.0, 250.0], 1]]
+    out = tmp_path / "res.json"
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_MIX="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gloo_worker.py"), str(out), json.dumps(spec)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        log, _ = p.communicate(timeout=400)
+        assert p.returncode == 0, log.decode()[-2000:]
+    res = json.load(open(out))
+    assert len(res) == len(spec)
+    for (name, items, ds, ms), got in zip(spec, res):
+        sig = signals.get(name)
+        B = sig.blocks(ms)
+        x = synth.make_epochs(sig, B, 6060, [(items[0], 0.4, 1537.0, 1201)], 1, nsamp=sig.samples_needed(B))[0].astype(np.complex128)
+        for it, g in zip(items, got):
+            w = acq_oracle.search_script(name, x, it, ds, ms)
+            assert g[2] == float(w[2]) and g[1] == float(w[1]) and g[0] == pytest.approx(float(w[0]), rel=1e-12), (name, it)
+
+
 def test_doppler_bounds_cover_grid():
     from gnss_dsp_tools_amd import sharded
     for nd in (0, 1, 5, 40, 70, 200):
