@@ -194,6 +194,7 @@ def main():
     ap.add_argument("--no-latency", action="store_true",
                     help="skip the single-epoch host-call latency probe (profiling runs: keeps every launch the bench workload)")
     ap.add_argument("--sustained-s", type=float, default=1.5, help="length of the second, sustained timed region (0 = skip)")
+    ap.add_argument("--preroll-s", type=float, default=0.4, help="untimed load before the warm-up steps so the GPU has clocked up (0 = none)")
     ap.add_argument("--no-self-check", action="store_true", help="ablation builds compute garbage on purpose (tools/ablate.sh)")
     ap.add_argument("--force-gather", action="store_true", help="run the all-gather + merge even on 1 rank (test aid)")
     args = ap.parse_args()
@@ -291,6 +292,18 @@ def main():
             dt = float(t.item())
         return out, dt
 
+    # Clock ramp: after the idle seconds of start-up (signal build, H2D) the GPU needs tens of milliseconds of load before it
+    # clocks up (tools/exp_cfg2.py timeline: 0.66 -> 0.45 -> 0.41 ms per step over the first ~100 steps after 0.5 s idle, flat
+    # 0.41-0.42 without the idle gap).  An untimed pre-roll of the same steps puts the chip in its sustained state before the
+    # W warm-up steps and the K timed steps; its length is reported in the JSON line.
+    preroll = {"seconds": 0.0, "steps": 0}
+    if args.preroll_s > 0:
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < args.preroll_s:
+            run_steps(4)
+            torch.cuda.synchronize(dev)
+            preroll["steps"] += 4
+        preroll["seconds"] = time.perf_counter() - t0
     run_steps(args.warmup)
     merged, dt = timed(args.steps)
 
@@ -298,12 +311,17 @@ def main():
     # the same steps for >= --sustained-s seconds so that DVFS cannot flatter the number (reported beside `value`).
     sustained = None
     if args.sustained_s > 0:
-        k_sus = max(args.steps, int(np.ceil(args.sustained_s / (dt / args.steps))))
-        if use_dist:
-            kt = torch.tensor([k_sus], dtype=torch.int64, device=dev)
-            dist.all_reduce(kt, op=dist.ReduceOp.MAX)
-            k_sus = int(kt.item())
-        _, dt_sus = timed(k_sus)
+        k_sus, per_step = args.steps, dt / args.steps
+        for _ in range(4):                               # the first estimate of the step time may be off: repeat until long enough
+            k_sus = max(args.steps, int(np.ceil(1.05 * args.sustained_s / per_step)))
+            if use_dist:
+                kt = torch.tensor([k_sus], dtype=torch.int64, device=dev)
+                dist.all_reduce(kt, op=dist.ReduceOp.MAX)
+                k_sus = int(kt.item())
+            _, dt_sus = timed(k_sus)
+            per_step = dt_sus / k_sus
+            if dt_sus >= args.sustained_s:
+                break
         sustained = {"steps": k_sus, "seconds": dt_sus, "ms_per_step": dt_sus / k_sus * 1e3, "value": cells_step * k_sus / dt_sus}
 
     # ---- correctness of what was just computed (not timed) ----------------------------------------------------------
@@ -471,6 +489,7 @@ def main():
                        "shards_seen_by_every_rank": shards_seen,
                        "engine": {0: "auto", 1: "rocfft", 2: "lds-fft", 3: "split", 4: "split-lds"}[args.engine],
                        "steps_in_flight": len(lanes)},
+            "preroll": preroll,
             "sustained": sustained,
             "roofline": roofline,
             "host_call_latency": latency,
