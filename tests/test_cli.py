@@ -1,5 +1,6 @@
-"""CLI shim + host front-end against the reference script's own stdout (golden captured by running
-/root/reference/acquire-gps-l1.py as a subprocess in the build container on tests/golden/cli_gps_l1_int8.iq)."""
+"""CLI shim + front-end against the reference scripts' own stdout.  tools/make_goldens_cli.py (committed) writes the
+synthetic int8 recordings tests/golden/cli_*_int8.iq and runs /root/reference/acquire-<name>.py on them as subprocesses in the
+build container; re-running it leaves the fixtures byte-identical."""
 import hashlib
 import io
 import json

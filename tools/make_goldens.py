@@ -8,7 +8,8 @@ synthetic IQ of gnss-dsp-tools_amd/synth.py (spec stored next to the results so 
 the identical samples; a SHA-256 of the sample bytes guards the generator).
 
 Outputs (data only -- no reference source text):
-  tests/golden/search_cases.json   per case: spec + [(metric, code, doppler)] + formatted lines
+  tests/golden/search_cases.json   per case: spec + [(metric, code, doppler)] from the reference's search() + the result lines
+                                   returned by the reference's own worker() (its format string, acquire-gps-l1.py:100-103)
   tests/golden/rows.npz            a few full accumulated-magnitude rows q (fp64)
   tests/golden/chips_sha256.json   SHA-256 + first/last 24 chips of every PRN of every code family
   tests/golden/nco_indices.json    nco.nco table-index vectors (hash + head) for benchmark (fs, doppler) pairs
@@ -19,6 +20,7 @@ import hashlib
 import importlib
 import json
 import os
+import re
 import sys
 import time
 import warnings
@@ -39,13 +41,36 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 
 def load_reference_script(name):
-    """exec the head of acquire-<name>.py (imports + search()) and return its namespace."""
+    """exec the head of acquire-<name>.py (imports + search()) and, in the same namespace, the script's own `def worker(p)`
+    block lifted out of its main program (acquire-gps-l1.py:100-103: unpack (x, prn), call search(x, prn, doppler_search, ms),
+    format the result line) -- the main program itself cannot be exec'd, it parses sys.argv and reads a file.  worker() reads
+    `doppler_search` and `ms` as module globals, exactly as in the script; the caller sets them in the namespace."""
     path = os.path.join(REF, "acquire-%s.py" % name)
     src = open(path).read()
     head = src.split("#\n# main program\n#")[0]
     ns = {}
     exec(compile(head, path, "exec"), ns)
+    m = re.search(r"^def worker\(p\):\n(?:[ \t]+.*\n)+", src, re.M)
+    if m is None:
+        raise SystemExit("no worker() in %s" % path)
+    exec(compile(m.group(0), path, "exec"), ns)
     return ns
+
+
+def run_reference_worker(ns, x, item, doppler_search, ms):
+    """One task of the reference's Pool.map (acquire-gps-l1.py:105-108): returns (search()'s tuple, worker()'s line)."""
+    seen = {}
+    search = ns["search"]
+
+    def spy(*a):
+        seen["r"] = search(*a)
+        return seen["r"]
+    ns["search"], ns["doppler_search"], ns["ms"] = spy, doppler_search, ms
+    try:
+        line = ns["worker"]((x, item))
+    finally:
+        ns["search"] = search
+    return seen["r"], line
 
 
 def sha(a):
@@ -149,13 +174,13 @@ def main():
         t0 = time.time()
         results, lines = [], []
         for it in items:
-            m, c, d = ns["search"](x, it, ds, ms)
+            (m, c, d), line = run_reference_worker(ns, x, it, ds, ms)
             results.append([float(m), float(c), float(d)])
-            lines.append(sig.fmt % (it, d, m, c))
+            lines.append(line)                       # the reference's own format string, not this repo's
         dt = time.time() - t0
         out_cases.append({"id": cid, "script": name, "items": items, "doppler_search": ds, "ms": ms,
                           "seed": synth.BASE_SEED + soff, "sats": [list(s) for s in sats], "nsamp": int(len(x64)),
-                          "x_sha256": sha(x64), "results": results, "lines": lines, "ref_seconds": round(dt, 3)})
+                          "x_sha256": sha(x64), "results": results, "lines": lines})
         print("%-24s %-14s items=%d  %.2fs  %s" % (cid, name, len(items), dt, lines[0]))
         for it, dop in row_plan.get(cid, []):
             rows["%s|%d|%g" % (cid, it, dop)] = ref_row(ns, sig, x, it, dop, blocks)
