@@ -84,6 +84,18 @@ SYMBOLS = {
     "gacq_search_batch_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
                                              c_int_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p,
                                              ctypes.c_int, ctypes.c_void_p]),
+    "gacq_search_batch": (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_size_t, ctypes.c_int, c_int_p, ctypes.c_int,
+                                         c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.POINTER(Result)]),
+    "gacq_group_create": (ctypes.c_int, [c_int_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "gacq_group_destroy": (None, [ctypes.c_void_p]),
+    "gacq_group_size": (ctypes.c_int, [ctypes.c_void_p]),
+    "gacq_group_member": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
+    "gacq_group_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "gacq_group_signal_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(SigDesc), ctypes.c_char_p, c_int_p, ctypes.c_int,
+                                                ctypes.POINTER(ctypes.c_void_p)]),
+    "gacq_group_signal_destroy": (None, [ctypes.c_void_p]),
+    "gacq_group_search_batch": (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_size_t, ctypes.c_int, c_int_p, ctypes.c_int,
+                                               c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.POINTER(Result)]),
     "gacq_merge_peaks_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c_int_p, ctypes.c_long,
                                             ctypes.c_void_p]),
     "gacq_finalize": (ctypes.c_int, [ctypes.POINTER(SigDesc), ctypes.POINTER(Peak), ctypes.c_int, c_int_p, ctypes.c_int,

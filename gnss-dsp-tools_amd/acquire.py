@@ -325,6 +325,28 @@ class Engine:
             ctypes.c_void_p(out.data_ptr())), self._ctx)
         return out
 
+    def search_batch_host(self, name, xs, items, dopplers, blocks):
+        """Host-buffer batch (gacq_search_batch): xs [nepoch, nsamp] complex64 in host memory -> per epoch the list of the
+        reference's (metric, code, doppler) tuples.  No torch involved: the library stages the epochs through its own pinned
+        ring, H2D copies overlapped with the kernels of the previous chunk."""
+        sig = _signals.get(name) if isinstance(name, str) else name
+        xs = np.ascontiguousarray(xs, dtype=np.complex64)
+        if xs.ndim != 2:
+            raise ValueError("xs must be [nepoch, nsamp]")
+        if len(items) == 0:
+            return [[] for _ in range(xs.shape[0])]
+        s, idx, bias = self._plan(sig, items)
+        dopplers = np.ascontiguousarray(dopplers, dtype=np.float64)
+        blocks = max(int(blocks), 0)
+        if xs.shape[1] < sig.samples_needed(blocks):
+            raise ValueError("operands could not be broadcast together: search needs %d samples per epoch, xs has %d" % (sig.samples_needed(blocks), xs.shape[1]))
+        res = (nat.Result * (xs.shape[0] * len(idx)))()
+        nat.check(nat.lib.gacq_search_batch(
+            s._h, xs.ctypes.data_as(nat.c_float_p), xs.shape[1], xs.shape[0], idx.ctypes.data_as(nat.c_int_p), len(idx),
+            dopplers.ctypes.data_as(nat.c_double_p), len(dopplers),
+            bias.ctypes.data_as(nat.c_double_p) if bias is not None else None, blocks, res), self._ctx)
+        return [[_as_tuple(res[e * len(idx) + p]) for p in range(len(idx))] for e in range(xs.shape[0])]
+
     def finalize(self, name, items, peaks, dopplers, shard_d0=None):
         return finalize(name, items, peaks, dopplers, shard_d0)
 
@@ -359,6 +381,83 @@ class Engine:
         nat.check(nat.lib.gacq_merge_peaks_dev(self._ctx, ctypes.c_void_p(gathered.data_ptr()), nshard,
                                                d0.ctypes.data_as(nat.c_int_p), n, ctypes.c_void_p(out.data_ptr())), self._ctx)
         return out
+
+
+class DeviceGroup:
+    """Several GPUs driven from one process through the library alone (gacq_group_*): the Doppler grid (or, for coarse grids,
+    the item list) is cut over the devices, every device reads the same samples, the 16-byte peak records are merged on the
+    host with the reference's tie rule.  `devices` may repeat an index (several contexts on one GPU).
+    One-process-per-GPU deployments use sharded.ShardedSearch over torch.distributed / RCCL instead."""
+
+    def __init__(self, devices):
+        ids = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        h = ctypes.c_void_p()
+        nat.check(nat.lib.gacq_group_create(ids, len(devices), ctypes.byref(h)))
+        self._g = h
+        self.devices = [int(d) for d in devices]
+        self._signals = {}
+
+    def _check(self, rc):
+        if rc < 0:
+            msg = nat.lib.gacq_group_last_error(self._g)
+            raise nat.GacqError(rc, msg.decode() if msg else "")
+
+    def set_engine(self, engine):
+        for k in range(len(self.devices)):
+            nat.check(nat.lib.gacq_set_engine(ctypes.c_void_p(nat.lib.gacq_group_member(self._g, k)), int(engine)))
+
+    def _signal(self, sig, prns):
+        key = (sig.name, tuple(prns))
+        if key not in self._signals:
+            L = nat.check(nat.lib.gacq_code_length(sig.code.encode()))
+            desc = nat.SigDesc(L, sig.n, int(sig.pad), int(sig.boc), int(sig.normalised), int(sig.fold), sig.fs)
+            arr = (ctypes.c_int * len(prns))(*prns)
+            h = ctypes.c_void_p()
+            self._check(nat.lib.gacq_group_signal_create(self._g, ctypes.byref(desc), sig.code.encode(), arr, len(prns), ctypes.byref(h)))
+            self._signals[key] = h
+        return self._signals[key]
+
+    def search_batch_host(self, name, xs, items, dopplers, blocks):
+        """Same contract as Engine.search_batch_host, over all devices of the group."""
+        sig = _signals.get(name) if isinstance(name, str) else name
+        xs = np.ascontiguousarray(xs, dtype=np.complex64)
+        items = [int(i) for i in items]
+        if xs.ndim != 2:
+            raise ValueError("xs must be [nepoch, nsamp]")
+        if not items:
+            return [[] for _ in range(xs.shape[0])]
+        if sig.bias_hz:
+            prns, idx = [0], np.zeros(len(items), dtype=np.int32)
+            bias = np.array([sig.bias_hz * c for c in items], dtype=np.float64)
+        else:
+            prns = sorted(set(items))
+            idx = np.array([prns.index(p) for p in items], dtype=np.int32)
+            bias = None
+        h = self._signal(sig, prns)
+        dopplers = np.ascontiguousarray(dopplers, dtype=np.float64)
+        blocks = max(int(blocks), 0)
+        if xs.shape[1] < sig.samples_needed(blocks):
+            raise ValueError("operands could not be broadcast together: search needs %d samples per epoch, xs has %d" % (sig.samples_needed(blocks), xs.shape[1]))
+        res = (nat.Result * (xs.shape[0] * len(idx)))()
+        self._check(nat.lib.gacq_group_search_batch(
+            h, xs.ctypes.data_as(nat.c_float_p), xs.shape[1], xs.shape[0], idx.ctypes.data_as(nat.c_int_p), len(idx),
+            dopplers.ctypes.data_as(nat.c_double_p), len(dopplers),
+            bias.ctypes.data_as(nat.c_double_p) if bias is not None else None, blocks, res))
+        return [[_as_tuple(res[e * len(idx) + p]) for p in range(len(idx))] for e in range(xs.shape[0])]
+
+    def close(self):
+        for h in self._signals.values():
+            nat.lib.gacq_group_signal_destroy(h)
+        self._signals.clear()
+        if self._g:
+            nat.lib.gacq_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def firwin_hann(ntaps, cutoff_norm):

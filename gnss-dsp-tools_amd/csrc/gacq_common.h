@@ -38,6 +38,8 @@ struct FftPlan {
 
 struct StageEvent { int stage; hipEvent_t a, b; };
 
+struct BatchRing;                      // pinned staging ring of the host-buffer batched entry points (gacq_host.hip)
+
 }  // namespace gacq
 
 struct gacq_ctx {
@@ -51,6 +53,7 @@ struct gacq_ctx {
   gacq::DevBuf tab, xstage, X, Y, rows, freq, fset, items, out_peaks, d0, partial, fe_a, fe_b, fe_taps, chunk_peaks;
   long opt[GACQ_NOPTS] = {1, 1, -1, 0, 0, 0};   // gacq_set_option values (defaults documented in include/gacq.h)
   gacq::DevBuf pin_x, pin_peaks;       // pinned host staging for the host-buffer entry point (gacq_search)
+  gacq::BatchRing* ring = nullptr;     // staging ring of gacq_search_batch / gacq_group_search_batch, created on first use
   bool profiling = false;
   double stage_ms[GACQ_NSTAGES] = {0};
   long stage_n[GACQ_NSTAGES] = {0};
@@ -77,6 +80,7 @@ struct gacq_sig {
 namespace gacq {
 
 int set_error(gacq_ctx* ctx, int code, const char* fmt, ...);
+void ring_destroy(gacq_ctx* ctx);
 int ensure(gacq_ctx* ctx, DevBuf& b, size_t bytes);
 int ensure_pinned(gacq_ctx* ctx, DevBuf& b, size_t bytes);      // hipHostMalloc'd, device-accessible
 // W_N^k = exp(-2 pi i k / N) for k < count, fp64-evaluated and rounded once to fp32; cached per ctx under `key`

@@ -384,6 +384,7 @@ void gacq_destroy(gacq_ctx* ctx) {
   if (!ctx) return;
   DeviceGuard device_guard_(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  ring_destroy(ctx);
   for (auto& kv : ctx->plans) {
     if (kv.second.info) rocfft_execution_info_destroy(kv.second.info);
     if (kv.second.plan) rocfft_plan_destroy(kv.second.plan);

@@ -11,7 +11,7 @@
  * GACQ_ERR_* code and never throws across the ABI; gacq_last_error() gives the message.
  * Host buffers are caller-owned; device buffers passed to *_dev entry points are caller-owned
  * device pointers (e.g. torch tensors' data_ptr()); everything else on the device is library-owned.
- * A gacq_ctx is bound to one HIP device and is single-threaded (one process per GPU).
+ * A gacq_ctx is bound to one HIP device and is single-threaded; a gacq_group drives several devices from one thread.
  */
 #ifndef GACQ_H
 #define GACQ_H
@@ -143,6 +143,36 @@ int gacq_search(gacq_sig* sig, const float* x_iq, size_t nsamp, const int* items
 int gacq_search_batch_dev(gacq_sig* sig, const void* d_x, size_t nsamp, int nepoch,
                           const int* items, int nitems, const double* dopplers, int nd,
                           const double* item_bias_hz, int blocks, void* d_out);
+
+/* Host-buffer batch: nepoch independent sample blocks in HOST memory (x_iq: complex64 [nepoch][nsamp]) -> out [nepoch][nitems]
+ * on the host.  Synchronous for the caller, pipelined inside: the epochs go through a ring of pinned staging slots in chunks,
+ * the H2D copy of chunk c+1 runs on a copy stream under the kernels of chunk c, and the peak records are written by the last
+ * kernel into device-visible pinned memory (no D2H copy).  Amortises the launch latency of gacq_search over many epochs for
+ * callers without a device-memory framework; results are identical to nepoch calls of gacq_search. */
+int gacq_search_batch(gacq_sig* sig, const float* x_iq, size_t nsamp, int nepoch, const int* items, int nitems,
+                      const double* dopplers, int nd, const double* item_bias_hz, int blocks, gacq_result* out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Several GPUs driven from ONE process (no torch, no MPI): a group owns one context per device.  gacq_group_search_batch cuts
+ * the Doppler grid into contiguous slices, one per device, while every device still gets >= 4 bins (forward FFTs are not
+ * duplicated; every device holds all code spectra), otherwise the item list; all devices read the same samples from one
+ * portable pinned staging buffer; the per-device peak records (16 B per epoch and item) come back through pinned host memory
+ * and are merged in global Doppler order with strict '>' -- the scan order of acquire-gps-l1.py:36-39, so the result equals
+ * a one-device search bit for bit.  device_ids may name a device more than once.  Replaces the mp.Pool.map over PRNs
+ * (acquire-gps-l1.py:105-108) for a single-process caller; one-process-per-GPU callers use torch.distributed (sharded.py).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct gacq_group gacq_group;
+typedef struct gacq_gsig gacq_gsig;
+int gacq_group_create(const int* device_ids, int ndev, gacq_group** out);
+void gacq_group_destroy(gacq_group* group);
+int gacq_group_size(const gacq_group* group);
+gacq_ctx* gacq_group_member(gacq_group* group, int k);   /* member context, e.g. for gacq_set_engine / gacq_set_option */
+const char* gacq_group_last_error(gacq_group* group);
+int gacq_group_signal_create(gacq_group* group, const gacq_sigdesc* desc, const char* code, const int* prns, int nprn,
+                             gacq_gsig** out);
+void gacq_group_signal_destroy(gacq_gsig* sig);
+int gacq_group_search_batch(gacq_gsig* sig, const float* x_iq, size_t nsamp, int nepoch, const int* items, int nitems,
+                            const double* dopplers, int nd, const double* item_bias_hz, int blocks, gacq_result* out);
 
 /* Device-side shard merge: d_peaks [nshard][n] (as gathered from the ranks, shard s covering Doppler
  * indices from shard_d0[s]) -> d_out [n] with global d_index; shards scanned in order with strict '>'

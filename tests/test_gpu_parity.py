@@ -806,3 +806,55 @@ def test_device_nco_indices_are_bit_exact(engine, golden_nco):
     with pytest.raises(nat.GacqError) as ei:             # no LDS forward kernel for N = 65536
         engine.signal("galileo-e1b", [1]).nco_indices(2, 125.0)
     assert ei.value.code == -9
+
+
+def _shifted_epochs(sig, B, seed, sats, nepoch, nsamp):
+    """nepoch distinct epochs from 8 seeded ones: every epoch a different circular shift, so every epoch has its own answer."""
+    from gnss_dsp_tools_amd import synth
+    base = synth.make_epochs(sig, B, seed, sats, 8, nsamp=nsamp)
+    return np.stack([np.roll(base[e % 8], 7 * e + 3) for e in range(nepoch)])
+
+
+def test_host_batched_entry_point_equals_single_calls(engine):
+    """gacq_search_batch (host buffers in, host results out, pinned staging ring in C, no torch): identical to one gacq_search per
+    epoch, across more chunks than the ring has slots (GPS L1: 256 epochs per chunk, 3 slots -> 1000 epochs wrap the ring)
+    and for a signal whose chunks hold a few epochs only (E1B: 42 per chunk)."""
+    from gnss_dsp_tools_amd import acquire, signals
+    for name, items, ds, ms, E in [("gps-l1", [3, 11, 19, 28], [-2000.0, 2000.0, 250.0], 1, 1000),
+                                   ("galileo-e1b", [5, 24], [1000.0, 2000.0, 250.0], 8, 90),
+                                   ("glonass-l1", [-7, 0, 3], [1000.0, 2000.0, 250.0], 1, 10)]:
+        sig = signals.get(name)
+        B = sig.blocks(ms)
+        xs = _shifted_epochs(sig, B, 321, [(items[0], 0.4, 1537.0, 1201)], E, sig.samples_needed(B))
+        dop = acquire.doppler_grid(ds)
+        got = engine.search_batch_host(sig, xs, items, dop, B)
+        assert len(got) == E
+        for e in list(range(0, E, max(1, E // 40))) + [E - 1]:
+            assert got[e] == engine.search_blocks(sig, xs[e], items, dop, B), (name, e)
+        assert len({tuple(map(tuple, g)) for g in got}) > E // 2           # the epochs really differ
+    assert engine.search_batch_host("gps-l1", np.zeros((3, 1), dtype=np.complex64), [1, 2], acquire.doppler_grid([0.0, 500.0, 250.0]), 0) == [[(0, 0, 0)] * 2] * 3
+    with pytest.raises(ValueError):
+        engine.search_batch_host("gps-l1", np.zeros((3, 100), dtype=np.complex64), [1], acquire.doppler_grid([0.0, 500.0, 250.0]), 1)
+
+
+def test_in_library_device_group_equals_one_device(engine):
+    """gacq_group_*: several contexts driven from one process (here three on the one GPU of the test box): Doppler-slice
+    split, item split for a coarse grid, FDMA biases, raw and normalised metrics -- bit-identical to the one-device batch."""
+    from gnss_dsp_tools_amd import acquire, signals
+    grp = acquire.DeviceGroup([0, 0, 0])
+    try:
+        for name, items, ds, ms, E in [("gps-l1", list(range(1, 33)), [-5000.0, 5000.0, 250.0], 1, 300),      # 40 bins -> 13/13/14
+                                       ("gps-l1", [3, 11, 19, 28, 30], [-500.0, 750.0, 250.0], 2, 20),        # 5 bins < 12 -> item split 1/2/2
+                                       ("glonass-l1", [-7, -2, 0, 3, 6], [1000.0, 2000.0, 500.0], 2, 6),      # item split with per-item bias
+                                       ("beidou-b1i", [6, 33], [-3000.0, 3000.0, 250.0], 2, 8),               # raw metric, padded
+                                       ("gps-l1", [7], [-500.0, 0.0, 250.0], 1, 4)]:                          # 2 bins, 1 item: an empty shard
+            sig = signals.get(name)
+            B = sig.blocks(ms)
+            xs = _shifted_epochs(sig, B, 654, [(items[0], 0.4, 537.0, 1201)], E, sig.samples_needed(B))
+            dop = acquire.doppler_grid(ds)
+            assert grp.search_batch_host(sig, xs, items, dop, B) == engine.search_batch_host(sig, xs, items, dop, B), name
+        assert grp.search_batch_host("gps-l1", xs[:, :1], [1], acquire.doppler_grid([0.0, 0.0, 1.0]), 1) == [[(0, 0, 0)]] * len(xs)
+        with pytest.raises(Exception):
+            acquire.DeviceGroup([0, 4096])
+    finally:
+        grp.close()
