@@ -21,6 +21,7 @@ from . import codes
 from . import signals as _signals
 
 PEAK_DTYPE = np.dtype([("metric", "<f8"), ("idx", "<i4"), ("d_index", "<i4")])
+RESULT_DTYPE = np.dtype([("metric", "<f8"), ("code_chips", "<f8"), ("doppler_hz", "<f8"), ("idx", "<i4"), ("d_index", "<i4")])      # gacq_result
 
 
 def parse_list_ranges(s, sep='-'):
@@ -305,13 +306,13 @@ class Engine:
         Asynchronous on the engine's stream."""
         import torch
         sig = _signals.get(name) if isinstance(name, str) else name
-        s, idx, bias = self._plan(sig, items)
-        dopplers = np.ascontiguousarray(dopplers, dtype=np.float64)
         if not (x_dev.is_cuda and x_dev.dtype == torch.complex64 and x_dev.dim() == 2 and x_dev.is_contiguous()):
             raise ValueError("x_dev must be a contiguous 2-D complex64 CUDA tensor")
+        if len(items) == 0:
+            return torch.empty((x_dev.shape[0], 0, 2), dtype=torch.float64, device=x_dev.device)
+        s, idx, bias = self._plan(sig, items)
+        dopplers = np.ascontiguousarray(dopplers, dtype=np.float64)
         nepoch, nsamp = x_dev.shape
-        if len(idx) == 0:
-            return torch.empty((nepoch, 0, 2), dtype=torch.float64, device=x_dev.device)
         if out is None:
             out = torch.empty((nepoch, len(idx), 2), dtype=torch.float64, device=x_dev.device)
         elif not (torch.is_tensor(out) and out.dtype == torch.float64 and tuple(out.shape) == (nepoch, len(idx), 2) and out.is_contiguous()
@@ -325,10 +326,11 @@ class Engine:
             ctypes.c_void_p(out.data_ptr())), self._ctx)
         return out
 
-    def search_batch_host(self, name, xs, items, dopplers, blocks):
+    def search_batch_host(self, name, xs, items, dopplers, blocks, raw=False):
         """Host-buffer batch (gacq_search_batch): xs [nepoch, nsamp] complex64 in host memory -> per epoch the list of the
-        reference's (metric, code, doppler) tuples.  No torch involved: the library stages the epochs through its own pinned
-        ring, H2D copies overlapped with the kernels of the previous chunk."""
+        reference's (metric, code, doppler) tuples (raw=True: the gacq_result records as a structured array [nepoch, nitems],
+        without building Python tuples).  No torch involved: the library stages the epochs through its own pinned ring, H2D
+        copies overlapped with the kernels of the previous chunk."""
         sig = _signals.get(name) if isinstance(name, str) else name
         xs = np.ascontiguousarray(xs, dtype=np.complex64)
         if xs.ndim != 2:
@@ -345,6 +347,8 @@ class Engine:
             s._h, xs.ctypes.data_as(nat.c_float_p), xs.shape[1], xs.shape[0], idx.ctypes.data_as(nat.c_int_p), len(idx),
             dopplers.ctypes.data_as(nat.c_double_p), len(dopplers),
             bias.ctypes.data_as(nat.c_double_p) if bias is not None else None, blocks, res), self._ctx)
+        if raw:
+            return np.frombuffer(res, dtype=RESULT_DTYPE).reshape(xs.shape[0], len(idx))
         return [[_as_tuple(res[e * len(idx) + p]) for p in range(len(idx))] for e in range(xs.shape[0])]
 
     def finalize(self, name, items, peaks, dopplers, shard_d0=None):

@@ -23,7 +23,7 @@ namespace gacq {
 
 constexpr int kRingDepth = 3;
 constexpr size_t kChunkBytes = (size_t)32 << 20;      // samples per staging slot
-constexpr int kChunkEpochs = 256;
+constexpr int kChunkEpochs = 64;                      // several chunks in flight matter more than the last percent of batching
 
 // Staging ring of one device.  pin_in is owned by the ring (single-device calls) or by the group (shared by all members).
 struct BatchRing {

@@ -817,8 +817,8 @@ def _shifted_epochs(sig, B, seed, sats, nepoch, nsamp):
 
 def test_host_batched_entry_point_equals_single_calls(engine):
     """gacq_search_batch (host buffers in, host results out, pinned staging ring in C, no torch): identical to one gacq_search per
-    epoch, across more chunks than the ring has slots (GPS L1: 256 epochs per chunk, 3 slots -> 1000 epochs wrap the ring)
-    and for a signal whose chunks hold a few epochs only (E1B: 42 per chunk)."""
+    epoch, across more chunks than the ring has slots (GPS L1: 64 epochs per chunk, 3 slots -> 1000 epochs wrap the ring five
+    times) and for a signal whose chunks are bounded by bytes (E1B: 42 epochs per 32 MiB chunk)."""
     from gnss_dsp_tools_amd import acquire, signals
     for name, items, ds, ms, E in [("gps-l1", [3, 11, 19, 28], [-2000.0, 2000.0, 250.0], 1, 1000),
                                    ("galileo-e1b", [5, 24], [1000.0, 2000.0, 250.0], 8, 90),
@@ -853,7 +853,7 @@ def test_in_library_device_group_equals_one_device(engine):
             xs = _shifted_epochs(sig, B, 654, [(items[0], 0.4, 537.0, 1201)], E, sig.samples_needed(B))
             dop = acquire.doppler_grid(ds)
             assert grp.search_batch_host(sig, xs, items, dop, B) == engine.search_batch_host(sig, xs, items, dop, B), name
-        assert grp.search_batch_host("gps-l1", xs[:, :1], [1], acquire.doppler_grid([0.0, 0.0, 1.0]), 1) == [[(0, 0, 0)]] * len(xs)
+        assert grp.search_batch_host("gps-l1", xs, [1], acquire.doppler_grid([0.0, 0.0, 1.0]), 1) == [[(0, 0, 0)]] * len(xs)     # empty grid
         with pytest.raises(Exception):
             acquire.DeviceGroup([0, 4096])
     finally:
