@@ -118,7 +118,7 @@ class Engine:
 
     # -- configuration -----------------------------------------------------------------------
     def set_engine(self, engine):
-        """0 auto, 1 rocFFT pipeline, 2 LDS-resident FFT kernels."""
+        """0 auto, 1 rocFFT pipeline, 2 LDS-resident FFT kernels, 3 / 4 split engines, 5 complex128 verification pipeline."""
         nat.check(nat.lib.gacq_set_engine(self._ctx, int(engine)), self._ctx)
 
     def set_stream(self, stream_handle):

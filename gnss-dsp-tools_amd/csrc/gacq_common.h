@@ -75,6 +75,8 @@ struct gacq_sig {
   float2* spectra_r31 = nullptr;   // same in the radix-31 engine's [k1][k2] order (only when split_supported(N))
   float2* spectra_split = nullptr; // split engine with LDS inner transforms: R lane-pair rows per item (N = R*4096)
   float2* spectra_lds = nullptr;   // same in the LDS engine's lane-pair layout (only when lds_supported(N))
+  double2* spectra64 = nullptr;    // complex128 code spectra of the verification engine (engine 5), built on first use
+  std::vector<float> replica;      // host copy of the +-1 replicas [nprn][n] (source of spectra64)
 };
 
 namespace gacq {
@@ -87,7 +89,9 @@ int ensure_pinned(gacq_ctx* ctx, DevBuf& b, size_t bytes);      // hipHostMalloc
 int twiddle_cache(gacq_ctx* ctx, const std::string& key, int N, int count, const float2** out);
 // arbitrary constant bytes cached per ctx under `key` (uploaded on first use)
 int table_cache(gacq_ctx* ctx, const std::string& key, const void* host, size_t bytes, const void** out);
-int fft_exec(gacq_ctx* ctx, int N, long batch, bool inverse, void* data);
+int fft_exec(gacq_ctx* ctx, int N, long batch, bool inverse, void* data, bool fp64 = false);
+// engine 5: the pipeline in complex128 on the device (gacq_verify.hip); ctx->freq / items / fset already uploaded
+int verify_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, int P, int F, int D, int B, gacq_peak* d_out, float* d_qrow);
 void stage_begin(gacq_ctx* ctx, int stage);
 void stage_end(gacq_ctx* ctx);
 

@@ -104,15 +104,15 @@ int twiddle_cache(gacq_ctx* ctx, const std::string& key, int N, int count, const
   return rc;
 }
 
-int fft_exec(gacq_ctx* ctx, int N, long batch, bool inverse, void* data) {
-  auto key = std::make_pair((long)N * 2 + (inverse ? 1 : 0), batch);
+int fft_exec(gacq_ctx* ctx, int N, long batch, bool inverse, void* data, bool fp64) {
+  auto key = std::make_pair((long)N * 4 + (inverse ? 1 : 0) + (fp64 ? 2 : 0), batch);
   auto it = ctx->plans.find(key);
   if (it == ctx->plans.end()) {
     FftPlan p;
     size_t len[1] = {(size_t)N};
     GACQ_FFT(ctx, rocfft_plan_create(&p.plan, rocfft_placement_inplace,
                                      inverse ? rocfft_transform_type_complex_inverse : rocfft_transform_type_complex_forward,
-                                     rocfft_precision_single, 1, len, (size_t)batch, nullptr));
+                                     fp64 ? rocfft_precision_double : rocfft_precision_single, 1, len, (size_t)batch, nullptr));
     GACQ_FFT(ctx, rocfft_execution_info_create(&p.info));
     GACQ_FFT(ctx, rocfft_plan_get_work_buffer_size(p.plan, &p.work_size));
     if (p.work_size) {
@@ -413,7 +413,7 @@ int gacq_use_null_stream(gacq_ctx* ctx) {
 }
 
 int gacq_set_engine(gacq_ctx* ctx, int engine) {
-  if (!ctx || engine < 0 || engine > 4) return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_set_engine: engine must be 0..4");
+  if (!ctx || engine < 0 || engine > 5) return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_set_engine: engine must be 0..5");
   ctx->engine = engine;
   return GACQ_OK;
 }
@@ -491,6 +491,7 @@ static int build_signal(gacq_ctx* ctx, const gacq_sigdesc* desc, const std::vect
   s->desc = *desc;
   s->nprn = nprn;
   s->N = desc->pad ? 2 * desc->n : desc->n;
+  s->replica = replicas;
   const size_t bytes = sizeof(float2) * (size_t)nprn * s->N;
   if (hipMalloc((void**)&s->spectra, bytes) != hipSuccess) {
     delete s;
@@ -573,6 +574,7 @@ void gacq_signal_destroy(gacq_sig* sig) {
   if (sig->spectra_lds) (void)hipFree(sig->spectra_lds);
   if (sig->spectra_r31) (void)hipFree(sig->spectra_r31);
   if (sig->spectra_split) (void)hipFree(sig->spectra_split);
+  if (sig->spectra64) (void)hipFree(sig->spectra64);
   delete sig;
 }
 
@@ -653,6 +655,8 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
     ctx->up_fset = g.fset;
     ctx->up_items = items_v;
   }
+
+  if (ctx->engine == 5) return verify_search(sig, d_x, nsamp, nepoch, P, F, D, B, d_out, d_qrow);      // complex128 verification pipeline
 
   const bool use_lds = (ctx->engine == 2) || (ctx->engine == 0 && lds_supported(N) && !d_qrow);      // whole transform in one workgroup
   if (ctx->engine == 2 && (!lds_supported(N) || d_qrow))
@@ -828,7 +832,7 @@ int gacq_search_batch_dev(gacq_sig* sig, const void* d_x, size_t nsamp, int nepo
     for (int p = 0; p < nitems; p++) if (std::find(seen.begin(), seen.end(), item_bias_hz[p]) == seen.end()) seen.push_back(item_bias_hz[p]);
     F = (int)seen.size();
   }
-  const size_t bin_bytes = sizeof(float2) * (size_t)F * blocks * sig->N;
+  const size_t bin_bytes = (ctx->engine == 5 ? sizeof(double2) : sizeof(float2)) * (size_t)F * blocks * sig->N;
   const bool no_x = (ctx->engine == 0 || ctx->engine == 2) && lds_fused_supported(ctx, sig->N, nitems, F);
   if (!no_x && nd > 1 && bin_bytes * nd > ctx->ws_limit) {
     const int Dc = (int)std::max<size_t>(1, ctx->ws_limit / bin_bytes);
@@ -997,7 +1001,7 @@ int gacq_debug_row(gacq_sig* sig, const float* x_iq, size_t nsamp, int item, dou
     return set_error(ctx, GACQ_ERR_HIP, "gacq_debug_row: H2D failed");
   }
   const int saved = ctx->engine;
-  ctx->engine = (saved == 3 || saved == 4) ? saved : 1;      // row dump: rocFFT pipeline and the split engines
+  ctx->engine = (saved == 3 || saved == 4 || saved == 5) ? saved : 1;      // row dump: rocFFT pipeline, split engines, fp64 pipeline
   rc = launch_search(sig, (const float2*)ctx->xstage.p, need, 1, &item, 1, &doppler, 1, bias_hz != 0.0 ? &bias_hz : nullptr, blocks,
                      (gacq_peak*)ctx->out_peaks.p, d_q);
   ctx->engine = saved;

@@ -1,0 +1,187 @@
+// Engine 5: complex128 verification pipeline (hard part 1: "keep a complex128 build").
+//
+// The product engines compute in complex64; the reference computes in complex128 (numpy / scipy.fftpack).  This engine is the
+// north-star pipeline K1 -> FFT -> K2 -> IFFT -> K3 -> K4 with every value in fp64 on the device (rocFFT double precision, fp64
+// NCO table, fp64 magnitudes and metric), so it agrees with the reference to ~1e-12 instead of ~1e-7.  It exists to bisect:
+// when an fp32 engine and the oracle disagree on a near-tied peak, engine 5 says which side the rounding fell on.  Slow by
+// design (twice the bytes, a quarter of the flops/s); selected only by gacq_set_engine(ctx, 5), never by auto.
+#include "gacq_common.h"
+
+#include <cmath>
+
+using namespace gacq;
+
+namespace {
+
+struct RowRec64 {
+  double peak;
+  double sum;
+  int idx;
+  int pad;
+};
+
+// K1: y = x * tab64[floor((f*i)*1024) & 1023]   (acquire-gps-l1.py:28,30-31, gnsstools/nco.py:6-10), samples widened to fp64
+__global__ __launch_bounds__(kBlock) void mix64_kernel(const float2* __restrict__ x, size_t epoch_stride, double2* __restrict__ y,
+                                                        const double* __restrict__ freq, const double2* __restrict__ tab, int n, int span,
+                                                        int FD, int B, unsigned cols) {
+  const unsigned row = blockIdx.x / cols;           // ((e*FD + fd)*B + b)
+  const int b = (int)(row % (unsigned)B);
+  const unsigned t = row / (unsigned)B;
+  const int fd = (int)(t % (unsigned)FD);
+  const long e = t / (unsigned)FD;
+  const double f = freq[fd];
+  const int i = (int)(blockIdx.x % cols) * kBlock + threadIdx.x;
+  if (i >= span) return;
+  const float2 s = x[e * epoch_stride + (size_t)b * n + i];
+  const double2 w = tab[nco_index(f, i)];
+  y[row * (long)span + i] = make_double2((double)s.x * w.x - (double)s.y * w.y, (double)s.x * w.y + (double)s.y * w.x);
+}
+
+// K2: Y = C_p * conj(X)   (acquire-gps-l1.py:32)
+__global__ __launch_bounds__(kBlock) void conj_mul64_kernel(const double2* __restrict__ X, const double2* __restrict__ C, double2* __restrict__ Y,
+                                                             const int* __restrict__ items, const int* __restrict__ fset, long g0, int P, int F,
+                                                             int D, int B, int N, unsigned cols) {
+  const unsigned ry = blockIdx.x / cols;
+  const int b = (int)(ry % (unsigned)B);
+  const unsigned g = (unsigned)g0 + ry / (unsigned)B;
+  const int d = (int)(g % (unsigned)D);
+  const unsigned ep = g / (unsigned)D;
+  const int p = (int)(ep % (unsigned)P);
+  const long e = ep / (unsigned)P;
+  const int i = (int)(blockIdx.x % cols) * kBlock + threadIdx.x;
+  if (i >= N) return;
+  const double2 xv = X[(((e * F + fset[p]) * D + d) * (long)B + b) * (long)N + i];
+  const double2 cv = C[(long)items[p] * N + i];
+  Y[ry * (long)N + i] = make_double2(cv.x * xv.x + cv.y * xv.y, cv.y * xv.x - cv.x * xv.y);
+}
+
+// K3: q[k] = sum_b |Y_b[k] / N| in fp64 (the reference's ifft carries the 1/N, then np.absolute, then the sum over blocks)
+__global__ __launch_bounds__(kBlock) void mag_peak64_kernel(const double2* __restrict__ Y, RowRec64* __restrict__ rows, long g0, int B, int N,
+                                                             float* __restrict__ q_out) {
+  __shared__ double s_peak[kBlock], s_sum[kBlock];
+  __shared__ int s_idx[kBlock];
+  const long gl = blockIdx.x;
+  const double2* ys = Y + gl * (long)B * N;
+  const double inv_n = 1.0 / (double)N;
+  double peak = -1.0, sum = 0.0;
+  int idx = 0x7fffffff;
+  for (int k = threadIdx.x; k < N; k += kBlock) {
+    double q = 0.0;
+    for (int b = 0; b < B; b++) {
+      const double2 v = ys[(long)b * N + k];
+      q += hypot(v.x * inv_n, v.y * inv_n);
+    }
+    if (q_out) q_out[k] = (float)q;
+    if (q > peak) { peak = q; idx = k; }
+    sum += q;
+  }
+  s_peak[threadIdx.x] = peak; s_sum[threadIdx.x] = sum; s_idx[threadIdx.x] = idx;
+  __syncthreads();
+  for (int off = kBlock / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      const double op = s_peak[threadIdx.x + off];
+      const int oi = s_idx[threadIdx.x + off];
+      if (op > s_peak[threadIdx.x] || (op == s_peak[threadIdx.x] && oi < s_idx[threadIdx.x])) { s_peak[threadIdx.x] = op; s_idx[threadIdx.x] = oi; }
+      s_sum[threadIdx.x] += s_sum[threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { RowRec64 r; r.peak = s_peak[0]; r.sum = s_sum[0]; r.idx = s_idx[0]; r.pad = 0; rows[g0 + gl] = r; }
+}
+
+// K4: strict-'>' scan over the Doppler bins in order, running best starts at 0 (acquire-gps-l1.py:25,36-39)
+__global__ void best_doppler64_kernel(const RowRec64* __restrict__ rows, gacq_peak* __restrict__ out, long nep, int D, int N, int normalised) {
+  const long ep = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ep >= nep) return;
+  double best = 0.0;
+  int bidx = -1, bd = -1;
+  for (int d = 0; d < D; d++) {
+    const RowRec64 r = rows[ep * D + d];
+    const double m = normalised ? r.peak / (r.sum / (double)N) : r.peak;      // q[idx]/np.mean(q)
+    if (m > best) { best = m; bidx = r.idx; bd = d; }
+  }
+  gacq_peak o;
+  o.metric = best; o.idx = bidx; o.d_index = bd;
+  out[ep] = o;
+}
+
+int nco_table64(gacq_ctx* ctx, const double2** out) {
+  auto it = ctx->tables.find("nco64");
+  if (it != ctx->tables.end()) { *out = (const double2*)it->second.p; return GACQ_OK; }
+  std::vector<double2> h(kNcoTableSize);
+  for (int k = 0; k < kNcoTableSize; k++) {
+    const double a = 2.0 * M_PI * (double)k * (1.0 / kNcoTableSize);       // np.exp(2*pi*1j*np.arange(NT)*(1.0/NT))  nco.py:4
+    h[k] = make_double2(std::cos(a), std::sin(a));
+  }
+  const void* p = nullptr;
+  const int rc = table_cache(ctx, "nco64", h.data(), sizeof(double2) * kNcoTableSize, &p);
+  *out = (const double2*)p;
+  return rc;
+}
+
+}  // namespace
+
+namespace gacq {
+
+int verify_spectra(gacq_sig* s) {
+  if (s->spectra64) return GACQ_OK;
+  gacq_ctx* ctx = s->ctx;
+  const size_t count = (size_t)s->nprn * s->N;
+  std::vector<double2> host(count, make_double2(0.0, 0.0));
+  for (int p = 0; p < s->nprn; p++)
+    for (int i = 0; i < s->desc.n; i++) host[(size_t)p * s->N + i].x = (double)s->replica[(size_t)p * s->desc.n + i];
+  GACQ_HIP(ctx, hipMalloc((void**)&s->spectra64, sizeof(double2) * count));
+  GACQ_HIP(ctx, hipMemcpyAsync(s->spectra64, host.data(), sizeof(double2) * count, hipMemcpyHostToDevice, ctx->stream));
+  int rc = fft_exec(ctx, s->N, s->nprn, false, s->spectra64, true);          // c = fft.fft(c)   acquire-gps-l1.py:24
+  if (rc != GACQ_OK) return rc;
+  GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return GACQ_OK;
+}
+
+int verify_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, int P, int F, int D, int B, gacq_peak* d_out, float* d_qrow) {
+  gacq_ctx* ctx = sig->ctx;
+  hipStream_t st = ctx->stream;
+  const int n = sig->desc.n, N = sig->N;
+  int rc;
+  if ((rc = verify_spectra(sig)) != GACQ_OK) return rc;
+  const double2* tab;
+  if ((rc = nco_table64(ctx, &tab)) != GACQ_OK) return rc;
+  const size_t x_epoch_bytes = sizeof(double2) * (size_t)F * D * B * N;
+  const int Ec = (int)std::max<size_t>(1, std::min<size_t>((size_t)nepoch, ctx->ws_limit / std::max<size_t>(1, x_epoch_bytes)));
+  if ((rc = ensure(ctx, ctx->X, x_epoch_bytes * Ec)) != GACQ_OK) return rc;
+  if ((rc = ensure(ctx, ctx->rows, sizeof(RowRec64) * (size_t)Ec * P * D)) != GACQ_OK) return rc;
+  const unsigned cols = (unsigned)((N + kBlock - 1) / kBlock);
+  for (int e0 = 0; e0 < nepoch; e0 += Ec) {
+    const int ne = std::min(Ec, nepoch - e0);
+    double2* X = (double2*)ctx->X.p;
+    RowRec64* rows = (RowRec64*)ctx->rows.p;
+    const long rows_x = (long)ne * F * D * B;
+    if (rows_x * cols >= (1L << 31)) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "verification engine: too many forward rows in one pass (lower the workspace limit)");
+    hipLaunchKernelGGL(mix64_kernel, dim3((unsigned)(rows_x * cols)), dim3(kBlock), 0, st, d_x + (size_t)e0 * nsamp, nsamp, X, (const double*)ctx->freq.p, tab, n,
+                       N, F * D, B, cols);
+    GACQ_HIP(ctx, hipGetLastError());
+    if ((rc = fft_exec(ctx, N, rows_x, false, X, true)) != GACQ_OK) return rc;
+    const long groups = (long)ne * P * D;
+    const size_t group_bytes = sizeof(double2) * (size_t)B * N;
+    long gc = (long)std::max<size_t>(1, std::min<size_t>((size_t)groups, ctx->ws_limit / group_bytes));
+    gc = std::min<long>(gc, std::max<long>(1, ((1L << 31) - 1) / ((long)B * cols)));
+    if ((rc = ensure(ctx, ctx->Y, group_bytes * gc)) != GACQ_OK) return rc;
+    double2* Y = (double2*)ctx->Y.p;
+    for (long g0 = 0; g0 < groups; g0 += gc) {
+      const long ng = std::min(gc, groups - g0);
+      hipLaunchKernelGGL(conj_mul64_kernel, dim3((unsigned)(ng * B * cols)), dim3(kBlock), 0, st, (const double2*)X, (const double2*)sig->spectra64, Y,
+                         (const int*)ctx->items.p, (const int*)ctx->fset.p, g0, P, F, D, B, N, cols);
+      GACQ_HIP(ctx, hipGetLastError());
+      if ((rc = fft_exec(ctx, N, ng * B, true, Y, true)) != GACQ_OK) return rc;
+      hipLaunchKernelGGL(mag_peak64_kernel, dim3((unsigned)ng), dim3(kBlock), 0, st, (const double2*)Y, rows, g0, B, N, d_qrow);
+      GACQ_HIP(ctx, hipGetLastError());
+    }
+    const long nep = (long)ne * P;
+    hipLaunchKernelGGL(best_doppler64_kernel, dim3((unsigned)((nep + 63) / 64)), dim3(64), 0, st, (const RowRec64*)rows, d_out + (size_t)e0 * P, nep, D, N,
+                       sig->desc.metric_mode);
+    GACQ_HIP(ctx, hipGetLastError());
+  }
+  return GACQ_OK;
+}
+
+}  // namespace gacq

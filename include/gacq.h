@@ -95,7 +95,10 @@ int gacq_set_stream(gacq_ctx* ctx, void* hip_stream);
 int gacq_use_null_stream(gacq_ctx* ctx);
 /* Engine selection: 0 = auto, 1 = rocFFT pipeline (any N), 2 = LDS-resident FFT kernels (N = 4096, 16384),
  * 3 = split engine, outer radix 31/16/4 + rocFFT inner transforms (N = 61380, 30690, 65536, 16384),
- * 4 = split engine with the inner transforms on the LDS FFT kernels (N = 65536, 16384). */
+ * 4 = split engine with the inner transforms on the LDS FFT kernels (N = 65536, 16384),
+ * 5 = complex128 verification pipeline (any N): the rocFFT pipeline with every value in fp64 on the device, as the reference
+ *     computes (numpy complex128); agrees with it to ~1e-12 and is what a near-tie disagreement of an fp32 engine is bisected
+ *     against.  Never chosen by auto. */
 int gacq_set_engine(gacq_ctx* ctx, int engine);
 /* Upper bound for the library-owned correlation workspace in bytes (default 4 GiB).  A search whose forward spectra
  * for one epoch exceed it is cut into Doppler slices that fit; the slices are merged in grid order with strict '>'

@@ -858,3 +858,47 @@ def test_in_library_device_group_equals_one_device(engine):
             acquire.DeviceGroup([0, 4096])
     finally:
         grp.close()
+
+
+@pytest.mark.parametrize("cid", ALL_CASES)
+def test_complex128_verification_engine_matches_reference_to_1e_10(engine, golden_cases, cid):
+    """Engine 5 = the pipeline in complex128 on the device (rocFFT double, fp64 NCO table, fp64 magnitudes and metric): the same
+    arithmetic type as the reference, so it must agree with the reference's own outputs to rounding (1e-10 relative; the fp32
+    engines are held to 1e-5).  It is the tool for bisecting a near-tie disagreement between an fp32 engine and the oracle."""
+    case = golden_cases[cid]
+    x = case_iq(case)
+    engine.set_engine(5)
+    try:
+        got = engine.search_all(case["script"], x, case["items"], case["doppler_search"], case["ms"])
+    finally:
+        engine.set_engine(0)
+    for g, w, item in zip(got, case["results"], case["items"]):
+        assert float(g[2]) == w[2] and float(g[1]) == pytest.approx(w[1], rel=1e-12, abs=1e-9), (cid, item, g, w)
+        assert float(g[0]) == pytest.approx(w[0], rel=1e-10), (cid, item, g, w)
+
+
+def test_fp32_engines_agree_with_the_complex128_engine_on_near_ties(engine):
+    """Noise-only searches (every row a near-tie between thousands of lags): every fp32 engine picks the lag and Doppler bin
+    the complex128 engine picks, batched, at three FFT lengths."""
+    import torch
+    from gnss_dsp_tools_amd import acquire, signals, synth
+    for name, items, ds, B, engines in [("gps-l1", list(range(1, 33)), [-5000.0, 5000.0, 250.0], 1, (1, 2)),
+                                         ("beidou-b1i", [1, 2, 3, 4], [-1000.0, 1000.0, 250.0], 2, (1, 2, 4)),
+                                         ("gps-l5i", [1, 2], [-600.0, 600.0, 200.0], 1, (1, 3))]:
+        sig = signals.get(name)
+        xs = synth.make_epochs(sig, B, 8642, [], 3, nsamp=sig.samples_needed(B))
+        xd = torch.from_numpy(xs).cuda()
+        dop = acquire.doppler_grid(ds)
+        engine.set_engine(5)
+        ref = engine.search_batch_dev(sig, xd, items, dop, B)
+        torch.cuda.synchronize()
+        ref = ref.cpu().numpy().view(acquire.PEAK_DTYPE)
+        for e in engines:
+            engine.set_engine(e)
+            got = engine.search_batch_dev(sig, xd, items, dop, B)
+            torch.cuda.synchronize()
+            got = got.cpu().numpy().view(acquire.PEAK_DTYPE)
+            np.testing.assert_array_equal(got["idx"], ref["idx"], err_msg="%s engine %d" % (name, e))
+            np.testing.assert_array_equal(got["d_index"], ref["d_index"])
+            np.testing.assert_allclose(got["metric"], ref["metric"], rtol=METRIC_RTOL)
+        engine.set_engine(0)
