@@ -83,7 +83,6 @@ LONGCODE = {"gps-l2cl": 40, "glonass-l1-p": 80, "glonass-l2-p": 80}        # def
 
 def run_longcode(name, argv, out=sys.stdout):
     """acquire-gps-l2cl.py / acquire-glonass-l{1,2}-p.py: FILE FS COFFSET ITEM DOPPLER CODE_PHASE [--time MS]."""
-    import numpy as np
     from . import longcode
     ap = argparse.ArgumentParser(prog="acquire-%s" % name)
     ap.add_argument("--time", type=int, default=LONGCODE[name])
@@ -101,15 +100,15 @@ def run_longcode(name, argv, out=sys.stdout):
         x = frontend.read_iq_int8(fp, n)
     if x is None:
         raise SystemExit("input file too short: need %d complex int8 samples" % n)
-    x = frontend.mix_fixed_point(x, -a.carrier_offset / a.sample_rate, 0)       # nco.mix(x,-coffset/fs,0)
     eng = acquire.Engine(a.device)
     try:
+        # the raw int8 samples go to the GPU; nco.mix(x,-coffset/fs,0) (acquire-gps-l2cl.py:72) runs there too
         if name == "gps-l2cl":
-            metric, k = longcode.search_l2cl(x, a.item, a.doppler, a.code_phase, a.time, a.sample_rate, engine=eng)
+            metric, k = longcode.search_l2cl(x, a.item, a.doppler, a.code_phase, a.time, a.sample_rate, engine=eng, coffset=a.carrier_offset)
             line = '%f %f' % (10230 * k + a.code_phase, metric)                  # acquire-gps-l2cl.py:76
         else:
             metric, k = longcode.search_glonass_p(x, a.item, a.doppler, a.code_phase, a.time, a.sample_rate,
-                                                  band=name.split("-")[1], engine=eng)
+                                                  band=name.split("-")[1], engine=eng, coffset=a.carrier_offset)
             line = '%f %f' % (5110 * k + 10 * a.code_phase, metric)              # acquire-glonass-l1-p.py:79
     finally:
         eng.close()

@@ -114,6 +114,9 @@ int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const i
 int lds_debug_nco(gacq_ctx* ctx, int N, int n, const double* d_freq, bool fused, int* d_idx);
 int split_debug_nco(gacq_ctx* ctx, int N, int n, const double* d_freq, int* d_idx);
 
+// front-end carrier wipe-off alone (gacq_frontend.hip): int8 I/Q on the device -> complex64, fixed-point table NCO
+int frontend_mix(gacq_ctx* ctx, const void* d_iq_int8, long n, double fs_in, double carrier_offset_hz, float2* d_out);
+
 // split engines (gacq_split.hip): N = R*M, hand-written outer DFT-R, inner length-M transforms (rocFFT, Stockham LDS or the 4096 kernels)
 bool split_supported(int N);
 // outer DFT-31 (+NCO mix when mix) + twiddle, then the inner forward transforms; X in [k1][k2] order

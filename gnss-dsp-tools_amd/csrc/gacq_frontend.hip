@@ -128,6 +128,20 @@ __global__ __launch_bounds__(kFeBlock) void fe_resample_kernel(const float2* __r
 
 }  // namespace
 
+namespace gacq {
+
+// nco.mix(x, -coffset/fs, 0) on int8 I/Q already on the device: dp = floor(p*NT*2^50) = 0, df = floor(f*NT*2^50)   gnsstools/nco.py:33-34
+int frontend_mix(gacq_ctx* ctx, const void* d_iq_int8, long n, double fs_in, double carrier_offset_hz, float2* d_out) {
+  const double f = -carrier_offset_hz / fs_in;
+  const long long df = (long long)std::floor(f * (double)kNcoTableSize * (double)(1LL << 50));
+  hipLaunchKernelGGL(fe_mix_kernel, dim3((unsigned)((n + kFeBlock - 1) / kFeBlock)), dim3(kFeBlock), 0, ctx->stream, (const char2*)d_iq_int8, d_out, n,
+                     0LL, df, (const float2*)ctx->tab.p);
+  GACQ_HIP(ctx, hipGetLastError());
+  return GACQ_OK;
+}
+
+}  // namespace gacq
+
 extern "C" {
 
 // scipy.signal.firwin(ntaps, cutoff_norm, window='hann') (low-pass, unity DC gain); cutoff_norm = cutoff / (fs/2)
@@ -169,14 +183,9 @@ int gacq_frontend_dev(gacq_ctx* ctx, const void* d_iq_int8, size_t nsamp_in, dou
     GACQ_HIP(ctx, hipStreamSynchronize(st));            // h dies with this frame; a repeated filter skips copy and sync
     ctx->up_taps = h;
   }
-  // nco.mix(x, -coffset/fs, 0): dp = floor(p*NT*2^50) = 0, df = floor(f*NT*2^50)        gnsstools/nco.py:33-34
-  const double f = -carrier_offset_hz / fs_in;
-  const long long df = (long long)std::floor(f * (double)kNcoTableSize * (double)(1LL << 50));
   float2* a = (float2*)ctx->fe_a.p;
   float2* b = (float2*)ctx->fe_b.p;
-  hipLaunchKernelGGL(fe_mix_kernel, dim3((unsigned)((n + kFeBlock - 1) / kFeBlock)), dim3(kFeBlock), 0, st, (const char2*)d_iq_int8, a, n,
-                     0LL, df, (const float2*)ctx->tab.p);
-  GACQ_HIP(ctx, hipGetLastError());
+  if ((rc = frontend_mix(ctx, d_iq_int8, n, fs_in, carrier_offset_hz, a)) != GACQ_OK) return rc;
   const int tile_elems = kTile + ntaps;
   const size_t smem = sizeof(float2) * (size_t)(tile_elems + tile_elems / 32 + 2);
   hipLaunchKernelGGL(fe_fir_kernel<1>, dim3((unsigned)((L + kTile - 1) / kTile)), dim3(kFeBlock), smem, st, (const float2*)a, b, n, p,

@@ -94,9 +94,11 @@ int device_chips(gacq_ctx* ctx, const char* code, int prn, const uint8_t** out, 
 
 }  // namespace
 
-extern "C" int gacq_longcode_search(gacq_ctx* ctx, const float* x_iq, size_t nsamp, double fs, const char* code, int prn,
-                                    double carrier_hz, const double* phase0, int K, int blocks, int n, double* q_out) {
-  if (!ctx || !x_iq || !code || !phase0 || !q_out || K <= 0 || blocks < 0 || n <= 0 || !(fs > 0.0))
+// x: host complex64 after the caller's carrier-offset wipe-off (iq_int8 == nullptr), or the raw interleaved int8 I/Q of the
+// file, wiped off here on the device with the front-end's fixed-point NCO (nco.mix(x,-coffset/fs,0), acquire-gps-l2cl.py:72)
+static int longcode_run(gacq_ctx* ctx, const float* x_iq, const int8_t* iq_int8, double coffset_hz, size_t nsamp, double fs, const char* code,
+                        int prn, double carrier_hz, const double* phase0, int K, int blocks, int n, double* q_out) {
+  if (!ctx || (!x_iq && !iq_int8) || !code || !phase0 || !q_out || K <= 0 || blocks < 0 || n <= 0 || !(fs > 0.0) || !std::isfinite(coffset_hz))
     return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_longcode_search: bad argument");
   if (blocks == 0) { memset(q_out, 0, sizeof(double) * K); return GACQ_OK; }
   if (nsamp < (size_t)blocks * n)
@@ -121,7 +123,13 @@ extern "C" int gacq_longcode_search(gacq_ctx* ctx, const float* x_iq, size_t nsa
   double2* d_partial = (double2*)ctx->partial.p;
   double* d_phase = (double*)(d_partial + npart);
   double* d_q = d_phase + (size_t)K * blocks;
-  GACQ_HIP(ctx, hipMemcpyAsync(ctx->xstage.p, x_iq, sizeof(float2) * (size_t)total, hipMemcpyHostToDevice, st));
+  if (iq_int8) {
+    // the int8 pairs are staged in the (not yet used) mixed-block buffer, wiped off into xstage as complex64
+    GACQ_HIP(ctx, hipMemcpyAsync(ctx->fe_a.p, iq_int8, 2 * (size_t)total, hipMemcpyHostToDevice, st));
+    if ((rc = frontend_mix(ctx, ctx->fe_a.p, total, fs, coffset_hz, (float2*)ctx->xstage.p)) != GACQ_OK) return rc;
+  } else {
+    GACQ_HIP(ctx, hipMemcpyAsync(ctx->xstage.p, x_iq, sizeof(float2) * (size_t)total, hipMemcpyHostToDevice, st));
+  }
   GACQ_HIP(ctx, hipMemcpyAsync(d_phase, phase0, sizeof(double) * (size_t)K * blocks, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(longcode_mix_kernel, dim3((unsigned)((total + kLcBlock - 1) / kLcBlock)), dim3(kLcBlock), 0, st,
                      (const float2*)ctx->xstage.p, (float2*)ctx->fe_a.p, (long)n, blocks, f, (const float2*)ctx->tab.p);
@@ -135,4 +143,15 @@ extern "C" int gacq_longcode_search(gacq_ctx* ctx, const float* x_iq, size_t nsa
   GACQ_HIP(ctx, hipMemcpyAsync(q_out, d_q, sizeof(double) * K, hipMemcpyDeviceToHost, st));
   GACQ_HIP(ctx, hipStreamSynchronize(st));
   return GACQ_OK;
+}
+
+extern "C" int gacq_longcode_search(gacq_ctx* ctx, const float* x_iq, size_t nsamp, double fs, const char* code, int prn,
+                                    double carrier_hz, const double* phase0, int K, int blocks, int n, double* q_out) {
+  return longcode_run(ctx, x_iq, nullptr, 0.0, nsamp, fs, code, prn, carrier_hz, phase0, K, blocks, n, q_out);
+}
+
+extern "C" int gacq_longcode_search_int8(gacq_ctx* ctx, const int8_t* iq_int8, size_t nsamp, double fs, double carrier_offset_hz,
+                                         const char* code, int prn, double carrier_hz, const double* phase0, int K, int blocks, int n,
+                                         double* q_out) {
+  return longcode_run(ctx, nullptr, iq_int8, carrier_offset_hz, nsamp, fs, code, prn, carrier_hz, phase0, K, blocks, n, q_out);
 }

@@ -6,7 +6,8 @@
 
 The reference reads `fs` from a module global; here it is an explicit argument.  Per candidate k and block the start code
 phase is formed on the host in fp64 exactly like the reference's expression, everything per-sample runs on the GPU
-(gacq_longcode_search).  x is the complex input at the file rate after the carrier-offset wipe-off (nco.mix)."""
+(gacq_longcode_search).  x is the complex input at the file rate after the carrier-offset wipe-off (nco.mix) -- or, with
+`coffset=`, the file's raw int8 I/Q, wiped off on the GPU as well (gacq_longcode_search_int8; what the CLI uses)."""
 import ctypes
 
 import numpy as np
@@ -18,7 +19,9 @@ L2CL_LENGTH = 767250
 P_LENGTH = 5110000
 
 
-def _run(engine, x, fs, code, prn, carrier_hz, phase0, blocks, n):
+def _run(engine, x, fs, code, prn, carrier_hz, phase0, blocks, n, coffset=None):
+    """coffset None: x is complex (the caller already wiped off the carrier offset, as the reference's search() expects);
+    coffset given: x is the file's raw int8 I/Q [nsamp, 2] and the wipe-off nco.mix(x,-coffset/fs,0) runs on the GPU."""
     eng = engine or acquire.default_engine()
     K = phase0.shape[0]
     if blocks <= 0:
@@ -26,12 +29,20 @@ def _run(engine, x, fs, code, prn, carrier_hz, phase0, blocks, n):
     x = np.asarray(x)
     if len(x) < blocks * n:
         raise ValueError("operands could not be broadcast together: search needs %d samples, x has %d" % (blocks * n, len(x)))
-    xc = np.ascontiguousarray(x[:blocks * n], dtype=np.complex64)
     ph = np.ascontiguousarray(phase0, dtype=np.float64)
     q = np.empty(K, dtype=np.float64)
-    nat.check(nat.lib.gacq_longcode_search(eng._ctx, xc.ctypes.data_as(nat.c_float_p), len(xc), float(fs), code.encode(), int(prn),
-                                           float(carrier_hz), ph.ctypes.data_as(nat.c_double_p), K, int(blocks), int(n),
-                                           q.ctypes.data_as(nat.c_double_p)), eng._ctx)
+    if coffset is None:
+        xc = np.ascontiguousarray(x[:blocks * n], dtype=np.complex64)
+        nat.check(nat.lib.gacq_longcode_search(eng._ctx, xc.ctypes.data_as(nat.c_float_p), len(xc), float(fs), code.encode(), int(prn),
+                                               float(carrier_hz), ph.ctypes.data_as(nat.c_double_p), K, int(blocks), int(n),
+                                               q.ctypes.data_as(nat.c_double_p)), eng._ctx)
+    else:
+        if x.dtype != np.int8 or x.ndim != 2 or x.shape[1] != 2:
+            raise ValueError("raw input must be an int8 array [nsamp, 2]")
+        xi = np.ascontiguousarray(x[:blocks * n])
+        nat.check(nat.lib.gacq_longcode_search_int8(eng._ctx, ctypes.c_void_p(xi.ctypes.data), len(xi), float(fs), float(coffset),
+                                                    code.encode(), int(prn), float(carrier_hz), ph.ctypes.data_as(nat.c_double_p), K,
+                                                    int(blocks), int(n), q.ctypes.data_as(nat.c_double_p)), eng._ctx)
     return q
 
 
@@ -44,7 +55,7 @@ def _best(q):
     return m_metric, m_k
 
 
-def search_l2cl(x, prn, doppler, l2cm_code_phase, ms, fs, engine=None):
+def search_l2cl(x, prn, doppler, l2cm_code_phase, ms, fs, engine=None, coffset=None):
     blocks = ms // 20
     n = int(fs * 0.020)
     phase0 = np.empty((75, max(blocks, 0)), dtype=np.float64)
@@ -52,10 +63,10 @@ def search_l2cl(x, prn, doppler, l2cm_code_phase, ms, fs, engine=None):
         for block in range(blocks):
             chips = (k + block) * 10230 + l2cm_code_phase            # acquire-gps-l2cl.py:24
             phase0[k, block] = (chips % L2CL_LENGTH) + 0             # (chips % code_length) + frac   gps/l2cl.py:59
-    return _best(_run(engine, x, fs, "gps.l2cl", prn, doppler, phase0, blocks, n))
+    return _best(_run(engine, x, fs, "gps.l2cl", prn, doppler, phase0, blocks, n, coffset))
 
 
-def search_glonass_p(x, chan, doppler, ca_code_phase, ms, fs, band="l1", engine=None):
+def search_glonass_p(x, chan, doppler, ca_code_phase, ms, fs, band="l1", engine=None, coffset=None):
     spacing = {"l1": 562500, "l2": 437500}[band]                    # acquire-glonass-l1-p.py:18 / -l2-p.py:18
     blocks = ms // 4
     n = int(fs * 0.004)
@@ -66,4 +77,4 @@ def search_glonass_p(x, chan, doppler, ca_code_phase, ms, fs, band="l1", engine=
         for block in range(blocks):
             phase0[k, block] = (0 % P_LENGTH) + cp                   # p.code(0, cp, incr, n): chips = 0, frac = cp
             cp += n * incr
-    return _best(_run(engine, x, fs, "glonass.p", 0, spacing * chan + doppler, phase0, blocks, n))
+    return _best(_run(engine, x, fs, "glonass.p", 0, spacing * chan + doppler, phase0, blocks, n, coffset))

@@ -211,6 +211,12 @@ int gacq_frontend_dev(gacq_ctx* ctx, const void* d_iq_int8, size_t nsamp_in, dou
  * ------------------------------------------------------------------------------------------- */
 int gacq_longcode_search(gacq_ctx* ctx, const float* x_iq, size_t nsamp, double fs, const char* code, int prn,
                          double carrier_hz, const double* phase0, int K, int blocks, int n, double* q_out);
+/* Same from the file's raw samples: iq_int8 = interleaved signed 8-bit I/Q (host, nsamp complex samples, gnsstools/io.py:3-12);
+ * the carrier-offset wipe-off nco.mix(x,-coffset/fs,0) (acquire-gps-l2cl.py:72, fixed-point table NCO of gnsstools/nco.py:30-41)
+ * runs on the device before the search, so the caller does no per-sample work at all. */
+int gacq_longcode_search_int8(gacq_ctx* ctx, const int8_t* iq_int8, size_t nsamp, double fs, double carrier_offset_hz,
+                              const char* code, int prn, double carrier_hz, const double* phase0, int K, int blocks, int n,
+                              double* q_out);
 
 /* ---------------------------------------------------------------------------------------------
  * Batched code correlators for the tracking hand-off (SURVEY.md section 8f "next #4"): the reference's

@@ -22,15 +22,16 @@ def gold():
     return g
 
 
-def test_frontend_matches_reference_conditioning(gold):
+def test_frontend_oracle_matches_reference_conditioning(gold):
     from gnss_dsp_tools_amd import frontend, signals
+    from oracle import frontend_oracle
     sig = signals.get("gps-l1")
     ms_pad = 2 + 5
     n = int(gold["fs"] * 0.001 * ms_pad)
     with open(gold["path"], "rb") as fp:
-        x = frontend.read_iq_int8(fp, n)
+        x = frontend_oracle.iq_to_complex(frontend.read_iq_int8(fp, n))
         assert frontend.read_iq_int8(fp, n) is None           # short read -> None (gnsstools/io.py:5-6)
-    y = frontend.condition(x, gold["fs"], gold["coffset"], sig, ms_pad)
+    y = frontend_oracle.condition(x, gold["fs"], gold["coffset"], sig, ms_pad)
     c = gold["conditioned"]
     assert len(y) == c["len"]
     np.testing.assert_allclose(np.c_[y[:16].real, y[:16].imag], c["head"], rtol=1e-9, atol=1e-9)
@@ -72,15 +73,16 @@ def test_native_firwin_matches_scipy():
 
 @pytest.mark.gpu
 def test_gpu_frontend_matches_host_frontend(gold):
-    """GPU front-end (fp32) vs the numpy front-end that is pinned to the reference: 1e-5 of the signal RMS."""
+    """GPU front-end (fp32) vs the numpy front-end oracle that is pinned to the reference: 1e-5 of the signal RMS."""
     import torch
     from gnss_dsp_tools_amd import acquire, frontend, signals
+    from oracle import frontend_oracle
     sig = signals.get("gps-l1")
     ms_pad = 2 + 5
     n = int(gold["fs"] * 0.001 * ms_pad)
     raw = open(gold["path"], "rb").read(2 * n)
     with open(gold["path"], "rb") as fp:
-        want = frontend.condition(frontend.read_iq_int8(fp, n), gold["fs"], gold["coffset"], sig, ms_pad)
+        want = frontend_oracle.condition(frontend_oracle.iq_to_complex(frontend.read_iq_int8(fp, n)), gold["fs"], gold["coffset"], sig, ms_pad)
     eng = acquire.Engine(0)
     try:
         got = eng.frontend_dev(sig, np.frombuffer(raw, dtype=np.int8), gold["fs"], gold["coffset"], ms_pad)
@@ -99,7 +101,7 @@ def test_gpu_frontend_matches_host_frontend(gold):
     iq = rng.integers(-100, 100, size=(n2, 2), dtype=np.int8)
     x = np.empty(n2, dtype=np.complex64)
     x.real, x.imag = iq[:, 0], iq[:, 1]
-    want2 = frontend.condition(x, fs_in, coff, sig2, 4)
+    want2 = frontend_oracle.condition(x, fs_in, coff, sig2, 4)
     eng = acquire.Engine(0)
     try:
         got2 = eng.frontend_dev(sig2, iq, fs_in, coff, 4)

@@ -243,6 +243,32 @@ def test_search_family_shares_forward_transforms_and_equals_separate_searches(en
         engine.search_family(("gps-l1", "gps-l5i"), x, ([1], [1]), ds, 1)
 
 
+def test_full_size_config3_family_e1b_plus_e1c_72_rows(engine):
+    """BASELINE config 3 as it is defined: E1B + E1C, 36 PRNs each, Doppler arange(-4000,4000,125) = 64 bins, ms = 8 (B = 1),
+    N = 65536, searched as ONE 72-row family (mix and forward transforms shared by both signals).  Every record equals the
+    one of the separate per-signal searches, and the injected satellites of both signals sit at their delays."""
+    from gnss_dsp_tools_amd import codes, signals, synth
+    names = ("galileo-e1b", "galileo-e1c")
+    items = (list(range(1, 37)), list(range(1, 37)))
+    ds, ms = [-4000.0, 4000.0, 125.0], 8
+    sig = signals.get(names[0])
+    B = sig.blocks(ms)
+    assert B == 1
+    n = sig.n
+    x = synth.make_iq(sig, B, 3636, [(5, 0.4, 1537.0, 1201), (30, 0.3, -3262.0, 20077)], nsamp=sig.samples_needed(B)).astype(np.complex128)
+    i = np.arange(len(x))
+    rep = codes.replica("galileo.e1c", 17, n, True).astype(np.float64)           # an E1C satellite on top of the two E1B ones
+    x = (x + 0.35 * rep[(i - 9000) % n] * np.exp(2j * np.pi * 409.0 * i / sig.fs)).astype(np.complex64)
+    fam = engine.search_family(names, x, items, ds, ms)
+    assert [len(f) for f in fam] == [36, 36]
+    for name, it, got in zip(names, items, fam):
+        assert got == engine.search_all(name, x, it, ds, ms), name
+    L = 4092
+    for k, prn, delay in [(0, 5, 1201), (0, 30, 20077), (1, 17, 9000)]:
+        code = fam[k][prn - 1][1]
+        assert any(abs(code - (L * ((n * m - delay) % (2 * n)) / n) % L) < 1e-9 for m in (1, 2)), (names[k], prn, code)
+
+
 def test_finalize_shard_merge(engine):
     """Doppler grid cut into shards, searched separately, merged by gacq_finalize == unsharded search.
     This is the cross-GPU exchange step exercised on one device."""
@@ -386,10 +412,11 @@ FULL_SIZE = [
     ("beidou-b1i", list(range(1, 64)), [-10000.0, 10000.0, 100.0], 10),
     ("glonass-l1", list(range(-7, 8)), [-10000.0, 10000.0, 100.0], 10),
     ("galileo-e1b", list(range(1, 51)), [-10000.0, 10000.0, 100.0], 10),
+    ("gps-l1", list(range(1, 33)), [-10000.0, 10000.0, 100.0], 10),              # config 5's GPS L1 leg: P=32, D=200, B=10, max/mean metric
 ]
 
 
-@pytest.mark.parametrize("name,items,ds,ms", FULL_SIZE, ids=["cfg3-e1b", "cfg4-l5i", "cfg4-b2ad", "cfg5-b1i", "cfg5-glonass", "cfg5-e1b"])
+@pytest.mark.parametrize("name,items,ds,ms", FULL_SIZE, ids=["cfg3-e1b", "cfg4-l5i", "cfg4-b2ad", "cfg5-b1i", "cfg5-glonass", "cfg5-e1b", "cfg5-gps-l1"])
 def test_full_size_properties_configs_3_4_5(engine, name, items, ds, ms):
     """Full BASELINE shapes, too big for the oracle in a test: (a) the hand-written engine and the rocFFT pipeline (two
     independent transform implementations) agree on every item's (lag, Doppler bin) and on the metric to 5e-6;
@@ -421,7 +448,8 @@ def test_full_size_properties_configs_3_4_5(engine, name, items, ds, ms):
     scaled = run((xd * 2.5).contiguous(), 0)
     np.testing.assert_array_equal(scaled["idx"], auto["idx"])
     np.testing.assert_array_equal(scaled["d_index"], auto["d_index"])
-    np.testing.assert_allclose(scaled["metric"], 2.5 * auto["metric"], rtol=5e-6)       # raw metrics (none of these is max/mean)
+    # raw metrics scale with the samples; the normalised max/mean metric (GPS L1) does not change at all
+    np.testing.assert_allclose(scaled["metric"], (1.0 if sig.normalised else 2.5) * auto["metric"], rtol=5e-6)
     n = sig.n
     for it, amp, f, delay in sats:
         if amp >= 0.25:

@@ -74,3 +74,22 @@ def test_gpu_negative_code_phase_wraps_like_numpy_mod(engine):
     got = longcode.search_glonass_p(x, 2, 250.0, -37.25, 8, fs, band="l1", engine=engine)
     assert got[1] == want[1] and got[0] == pytest.approx(want[0], rel=1e-5)
     assert got[1] == 0                 # the satellite sits at the candidate whose start phase is negative
+
+
+@pytest.mark.gpu
+def test_gpu_int8_input_with_device_wipe_off_equals_host_wipe_off(engine):
+    """gacq_longcode_search_int8: raw int8 I/Q in, nco.mix(x,-coffset/fs,0) on the device (the front-end's fixed-point NCO kernel)
+    == the complex path fed with the oracle's numpy wipe-off (same fp32 products, same table)."""
+    from gnss_dsp_tools_amd import longcode
+    from oracle import frontend_oracle
+    g = json.load(open(os.path.join(GOLD, "cli_gps_l2cl.json")))
+    ms = int(g["argv"][1])
+    n = int(g["fs"] * 0.001 * (ms + 5))
+    raw = np.fromfile(os.path.join(GOLD, g["file"]), dtype=np.int8, count=2 * n).reshape(n, 2)
+    item, dop, cp = int(g["tail"][0]), float(g["tail"][1]), float(g["tail"][2])
+    a = longcode.search_l2cl(raw, item, dop, cp, ms, g["fs"], engine=engine, coffset=g["coffset"])
+    xc = frontend_oracle.mix_fixed_point(frontend_oracle.iq_to_complex(raw), -g["coffset"] / g["fs"], 0)
+    b = longcode.search_l2cl(xc, item, dop, cp, ms, g["fs"], engine=engine)
+    assert a[1] == b[1] and a[0] == pytest.approx(b[0], rel=1e-6)
+    with pytest.raises(ValueError):
+        longcode.search_l2cl(raw.astype(np.int16), item, dop, cp, ms, g["fs"], engine=engine, coffset=g["coffset"])
