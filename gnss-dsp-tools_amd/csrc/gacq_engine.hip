@@ -674,8 +674,9 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
   const bool fused16k = use_lds && lds_fused_supported(ctx, N, P, F);      // one carrier per item: no forward-spectra buffer at all
   const size_t x_epoch_bytes = sizeof(float2) * (size_t)F * D * B * N;
   int Ec = (int)std::max<size_t>(1, std::min<size_t>((size_t)nepoch, ctx->ws_limit / std::max<size_t>(1, x_epoch_bytes)));
-  if (fused16k) Ec = nepoch;            // nothing but the 16-byte row records is buffered
-  if (!fused16k && (rc = ensure(ctx, ctx->X, x_epoch_bytes * Ec)) != GACQ_OK) return rc;
+  const bool fused4k = use_lds && !fused16k && lds_fused4k_supported(ctx, N, B, F);
+  if (fused16k || fused4k) Ec = nepoch;            // nothing but the 16-byte row records is buffered
+  if (!fused16k && !fused4k && (rc = ensure(ctx, ctx->X, x_epoch_bytes * Ec)) != GACQ_OK) return rc;
   if ((rc = ensure(ctx, ctx->rows, sizeof(RowRec) * (size_t)Ec * P * D)) != GACQ_OK) return rc;
 
   const int chunksN = (N + kBlock * 8 - 1) / (kBlock * 8);
@@ -689,6 +690,11 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
       stage_begin(ctx, 6);
       rc = lds_fused_search(ctx, xe, nsamp, ne, n, N, sig->spectra_lds, (const int*)ctx->items.p, (const int*)ctx->fset.p,
                             (const double*)ctx->freq.p, (const float2*)ctx->tab.p, P, D, B, rows);
+      stage_end(ctx);
+      if (rc != GACQ_OK) return rc;
+    } else if (fused4k) {
+      stage_begin(ctx, 6);
+      rc = lds_fused4k_search(ctx, xe, nsamp, ne, sig->spectra_lds, (const int*)ctx->items.p, (const double*)ctx->freq.p, (const float2*)ctx->tab.p, P, D, rows);
       stage_end(ctx);
       if (rc != GACQ_OK) return rc;
     } else if (use_lds) {
@@ -833,7 +839,7 @@ int gacq_search_batch_dev(gacq_sig* sig, const void* d_x, size_t nsamp, int nepo
     F = (int)seen.size();
   }
   const size_t bin_bytes = (ctx->engine == 5 ? sizeof(double2) : sizeof(float2)) * (size_t)F * blocks * sig->N;
-  const bool no_x = (ctx->engine == 0 || ctx->engine == 2) && lds_fused_supported(ctx, sig->N, nitems, F);
+  const bool no_x = (ctx->engine == 0 || ctx->engine == 2) && (lds_fused_supported(ctx, sig->N, nitems, F) || lds_fused4k_supported(ctx, sig->N, blocks, F));
   if (!no_x && nd > 1 && bin_bytes * nd > ctx->ws_limit) {
     const int Dc = (int)std::max<size_t>(1, ctx->ws_limit / bin_bytes);
     const int nch = (nd + Dc - 1) / Dc;

@@ -683,6 +683,102 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float
   }
 }
 
+// ---- N = 4096, one block, one carrier: forward + correlate in ONE kernel ---------------------------------------------------
+// Workgroup = (epoch, Doppler bin, chunk of pch items).  Prologue: load the x window, table-NCO mix (fp64 index as in
+// lds_forward_kernel), forward FFT, conjugate -- the spectrum never leaves the registers: the transform's output lane/register
+// convention (register rev16(k2) of lane t holds X[t + 256 k2]) is the input convention of the inverse transform, so
+// xr[j] = conj(v[rev16(j)]) is a compile-time register renaming.  Then the item loop of lds_correlate_kernel<.., B1, CACHEX>.
+// No X buffer (84 MB at the bench shape), no forward launch, no launch boundary; the price is one forward transform per
+// workgroup instead of one per (epoch, Doppler bin), i.e. nchunk - 1 redundant ones per unit, which is why this kernel is
+// launched with larger item chunks (16-32) than the two-kernel path (8).  Same arithmetic in the same order as
+// lds_forward_kernel + lds_correlate_kernel: records are bit-identical (test_fused_4096_kernel_equals_two_kernel_path).
+template <int MINW>
+__global__ __launch_bounds__(kBlock, MINW) void lds_fused4k_kernel(const float2* __restrict__ x, size_t epoch_stride,
+                                                                    const float2* __restrict__ C, const int* __restrict__ items,
+                                                                    const double* __restrict__ freq, const float2* __restrict__ nco_tab,
+                                                                    const float2* __restrict__ tw, RowRec* __restrict__ rows, int E, int P,
+                                                                    int D, int pch, int nchunk) {
+  __shared__ v2 lds[kLdsElems];
+  __shared__ float s_peak[kBlock / 64];
+  __shared__ int s_idx[kBlock / 64];
+  __shared__ double s_sum[kBlock / 64];
+  const int t = threadIdx.x;
+  const int xcd = blockIdx.x & 7;                     // (epoch, Doppler) unit -> XCD, as in lds_correlate_kernel
+  const unsigned j = blockIdx.x >> 3;
+  const unsigned u = (j / (unsigned)nchunk) * 8 + xcd;
+  if (u >= (unsigned)E * (unsigned)D) return;
+  const long e = u / (unsigned)D;
+  const int d = (int)(u % (unsigned)D);
+  const int p0 = (int)(j % (unsigned)nchunk) * pch;
+  const int p1 = min(P, p0 + pch);
+  v2 wa = ld2(tw + t), wb = ld2(tw + 16 * (t & 15));
+  v2 xr[kR];
+  {
+    const double f = freq[d];
+    const float2* src = x + e * epoch_stride;
+    v2 v[kR], w[kR];
+#pragma unroll
+    for (int jj = 0; jj < kR; jj++) {
+      const int i = t + 256 * jj;
+      const int k = nco_index(f, i);                  // gnsstools/nco.py:6-9
+      v[jj] = ld2(src + i);
+      w[jj] = ld2(nco_tab + k);
+    }
+#pragma unroll
+    for (int jj = 0; jj < kR; jj++) v[jj] = cmul(v[jj], w[jj]);
+    fft4096<false>(v, lds, wa, wb);
+#pragma unroll
+    for (int jj = 0; jj < kR; jj++) { const v2 a = v[rev16(jj)]; xr[jj] = v2{a.x, -a.y}; }      // np.conj(fft.fft(b))  acquire-gps-l1.py:32
+    __syncthreads();                                  // the forward transform's exchange-2 reads are complete
+  }
+  const float inv_n = 1.0f / (float)kLdsN;
+  const unsigned lane_off = (unsigned)t * 16u;
+  for (int p = p0; p < p1; p++) {
+    const __amdgpu_buffer_rsrc_t cres = row_rsrc(C + (long)items[p] * kLdsN);
+    asm volatile("" : "+v"(wa.x), "+v"(wa.y), "+v"(wb.x), "+v"(wb.y));      // keep the twiddle powers out of the loop-invariant set
+    v2 v[kR];
+#pragma unroll
+    for (int jp = 0; jp < kR / 2; jp++) ld_pair(cres, lane_off, jp, v[2 * jp], v[2 * jp + 1]);
+#pragma unroll
+    for (int jj = 0; jj < kR; jj++) v[jj] = cmul(v[jj], xr[jj]);
+    fft4096<true>(v, lds, wa, wb);
+    const v2 r0 = v[rev16(0)];
+    float peak = __builtin_amdgcn_sqrtf(r0.x * r0.x + r0.y * r0.y);              // np.absolute(ifft(...)) * N
+    int bestk = 0;
+    float sum_f = peak;
+#pragma unroll
+    for (int k = 1; k < kR; k++) {
+      const v2 r = v[rev16(k)];
+      const float m = __builtin_amdgcn_sqrtf(r.x * r.x + r.y * r.y);
+      if (m > peak) { peak = m; bestk = k; }                                     // strict '>' keeps the first maximum
+      sum_f += m;
+    }
+    const int idx = t + 256 * bestk;
+    peak *= inv_n;
+    sum_f *= inv_n;
+    const unsigned pbits = __builtin_bit_cast(unsigned, peak);
+    const unsigned wmax = wave_max_u32(pbits);
+    const unsigned widx = wave_min_u32(pbits == wmax ? (unsigned)idx : 0xffffffffu);
+    const float wsum = wave_add_f32(sum_f);
+    if ((t & 63) == 0) { s_peak[t >> 6] = __builtin_bit_cast(float, wmax); s_idx[t >> 6] = (int)widx; s_sum[t >> 6] = (double)wsum; }
+    __syncthreads();   // also orders this item's exchange-2 reads before the next item's exchange-1 writes
+    if (t == 0) {
+      float bp = s_peak[0];
+      int bi = s_idx[0];
+      double bs = s_sum[0];
+      for (int w = 1; w < kBlock / 64; w++) {
+        if (s_peak[w] > bp || (s_peak[w] == bp && s_idx[w] < bi)) { bp = s_peak[w]; bi = s_idx[w]; }
+        bs += s_sum[w];
+      }
+      RowRec r;
+      r.peak = bp;
+      r.idx = bi;
+      r.sum = bs;
+      rows[(e * P + p) * (long)D + d] = r;
+    }
+  }
+}
+
 typedef void (*CorrKernel)(const float2*, const float2*, const int*, const int*, const float2*, RowRec*, int, int, int, int, int, int, int);
 
 struct CorrVariant { const char* name; CorrKernel b1; CorrKernel bn; };
@@ -756,6 +852,27 @@ int lds_fused_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, i
   GACQ_HIP(ctx, hipFuncSetAttribute((const void*)lds16k_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes));
   hipLaunchKernelGGL(lds16k_fused_kernel<false>, dim3((unsigned)((long)nepoch * D * nitems)), dim3(kBigThreads), kBigLdsBytes, ctx->stream, x,
                      nsamp, spectra, d_items, d_fset, d_freq, tab, twn, rows, n, nitems, D, B);
+  GACQ_HIP(ctx, hipGetLastError());
+  return GACQ_OK;
+}
+
+bool lds_fused4k_supported(const gacq_ctx* ctx, int N, int B, int F) { return N == kLdsN && B == 1 && F == 1 && ctx->opt[GACQ_OPT_FUSED_4K]; }
+
+int lds_fused4k_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, const float2* spectra, const int* d_items,
+                       const double* d_freq, const float2* tab, int nitems, int D, RowRec* rows) {
+  const float2* tw;
+  int rc = twiddle_table(ctx, &tw);
+  if (rc != GACQ_OK) return rc;
+  // one forward transform per workgroup: amortise it over up to 32 items while >= ~2048 workgroups remain
+  const long units = (long)nepoch * D;
+  int pch = 8;
+  while (pch < 32 && units * ((nitems + 2 * pch - 1) / (2 * pch)) >= 2048) pch *= 2;
+  if (ctx->opt[GACQ_OPT_LDS_PCH] >= 1) pch = (int)ctx->opt[GACQ_OPT_LDS_PCH];
+  pch = std::min(pch, nitems);
+  const int nchunk = (nitems + pch - 1) / pch;
+  const long units8 = (units + 7) / 8;
+  hipLaunchKernelGGL(lds_fused4k_kernel<2>, dim3((unsigned)(8 * units8 * nchunk)), dim3(kBlock), 0, ctx->stream, x, nsamp, spectra, d_items,
+                     d_freq, tab, tw, rows, nepoch, nitems, D, pch, nchunk);
   GACQ_HIP(ctx, hipGetLastError());
   return GACQ_OK;
 }

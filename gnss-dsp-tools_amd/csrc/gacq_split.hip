@@ -214,14 +214,15 @@ __device__ __forceinline__ void fill_pass_twiddles(v2* __restrict__ twp, const f
 // outputs overwrite the same buffer (autosort order).  One buffer instead of a ping-pong pair keeps the workgroup at
 // 2 M complex of LDS (row + twiddles) so five of them fit a CU.  LAST writes the row to global memory instead.
 template <int R, bool LAST, int M, int NT>
-__device__ __forceinline__ void stockham_pass(v2* __restrict__ buf, float2* __restrict__ gz, const v2* __restrict__ twp, int Ns) {
+__device__ __forceinline__ void stockham_pass(v2* __restrict__ buf, float2* __restrict__ gz, const v2* __restrict__ twp, int Ns, int tid,
+                                              bool live) {
   constexpr int nb = M / R;
   constexpr int iters = (nb + NT - 1) / NT;
   v2 x[iters][R];
 #pragma unroll
   for (int it = 0; it < iters; it++) {
-    const int j = threadIdx.x + it * NT;
-    if (j < nb) {
+    const int j = tid + it * NT;
+    if (j < nb && live) {
       const int k = j % Ns;
       v2 wv[R];
 #pragma unroll
@@ -234,8 +235,8 @@ __device__ __forceinline__ void stockham_pass(v2* __restrict__ buf, float2* __re
   if (!LAST) __syncthreads();                      // all inputs are in registers
 #pragma unroll
   for (int it = 0; it < iters; it++) {
-    const int j = threadIdx.x + it * NT;
-    if (j < nb) {
+    const int j = tid + it * NT;
+    if (j < nb && live) {
       const int k = j % Ns;
       const int j0 = (j / Ns) * Ns * R + k;
 #pragma unroll
@@ -247,17 +248,21 @@ __device__ __forceinline__ void stockham_pass(v2* __restrict__ buf, float2* __re
   }
 }
 
-// Workgroup = (k1, chunk of pch consecutive (epoch, item) pairs, Doppler bin, block): the twiddle table is staged into LDS
-// once and the first-pass operands of X[e,f,d,b][k1][.] stay in registers while the items change (they are reloaded only when
-// the row pointer changes, i.e. across an epoch or frequency-set boundary).  Consecutive workgroups share k1 and the item
-// chunk, so the pch code-spectrum rows they read stay in every XCD's L2.  [g0, g0+ng) is the range of (e,p,d) groups whose
-// Z rows exist in this workspace pass; anything outside is skipped.
-// R3 == 1: three passes (R0, R1, R2).  NT threads per workgroup, chosen close to the butterflies per pass:
+// Workgroup = (k1, chunk of pch consecutive (epoch, item) pairs, Doppler bin, block).  TEAMS teams of NT threads (whole waves)
+// share one set of per-pass twiddle tables in LDS and work on TEAMS consecutive items at a time, each team in its own row buffer;
+// a team keeps the first-pass operands of X[e,f,d,b][k1][.] in registers while its items change (reloaded only when the row
+// pointer changes, i.e. across an epoch or frequency-set boundary).  One team per workgroup (31.6 KB for M = 1980) lets five
+// workgroups = 15 waves share a CU, and the kernel waits on LDS round trips and barriers two thirds of the time; four teams
+// amortise the 15.7 KB of tables over four rows (79 KB per workgroup, two workgroups = 24 waves per CU, the register limit).
+// Consecutive workgroups share k1 and the item chunk, so the pch code-spectrum rows they read stay in every XCD's L2.
+// [g0, g0+ng) is the range of (e,p,d) groups whose Z rows exist in this workspace pass; anything outside is skipped (the team
+// idles through the barriers).
+// R3 == 1: three passes (R0, R1, R2).  NT threads per team, chosen close to the butterflies per pass:
 //   M = 1980 = 11 * 12 * 15: 180, 165, 132 butterflies -> 192 threads;   M = 990 = 11 * 9 * 10: 90, 110, 99 -> 128 threads.
 // Three passes instead of four (11 * 9 * 5 * 4|2) mean one LDS exchange, one twiddle stage and two barriers less per row; the
 // composite radices 10, 12 and 15 are coprime products (PfaDft), so they cost no internal twiddles either.
-template <int R0, int R1, int R2, int R3, int NT>
-__global__ __launch_bounds__(NT) void split_inner_corr_kernel(const float2* __restrict__ X, const float2* __restrict__ C,
+template <int R0, int R1, int R2, int R3, int NT, int TEAMS>
+__global__ __launch_bounds__(NT * TEAMS, ((TEAMS == 4 && R0 * R1 * R2 * R3 == 1980) ? 6 : 5)) void split_inner_corr_kernel(const float2* __restrict__ X, const float2* __restrict__ C,
                                                                    float2* __restrict__ Z, const int* __restrict__ items,
                                                                    const int* __restrict__ fset, const float2* __restrict__ twm_g,
                                                                    long g0, long ng, long ep_first, int nblk_ep, int pch, int P, int F,
@@ -265,14 +270,17 @@ __global__ __launch_bounds__(NT) void split_inner_corr_kernel(const float2* __re
   constexpr int M = R0 * R1 * R2 * R3;
   constexpr int nb0 = M / R0;
   static_assert(nb0 <= NT, "first pass: one radix-R0 butterfly per thread");
+  static_assert(NT % 64 == 0, "teams are whole waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  v2* buf0 = reinterpret_cast<v2*>(smem);
-  v2* tw1 = buf0 + M;                              // per-pass twiddle tables, M - R0 entries in all
+  const int team = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / NT));      // wave-uniform: keeps the row pointers in SGPRs
+  const int j = (int)threadIdx.x - team * NT;
+  v2* buf0 = reinterpret_cast<v2*>(smem) + team * M;
+  v2* tw1 = reinterpret_cast<v2*>(smem) + TEAMS * M;        // per-pass twiddle tables, M - R0 entries in all
   v2* tw2 = tw1 + (R1 - 1) * R0;
   v2* tw3 = tw2 + (R2 - 1) * R0 * R1;
-  fill_pass_twiddles<R1, NT>(tw1, twm_g, R0, M);
-  fill_pass_twiddles<R2, NT>(tw2, twm_g, R0 * R1, M);
-  if (R3 > 1) fill_pass_twiddles<R3, NT>(tw3, twm_g, R0 * R1 * R2, M);
+  fill_pass_twiddles<R1, NT * TEAMS>(tw1, twm_g, R0, M);
+  fill_pass_twiddles<R2, NT * TEAMS>(tw2, twm_g, R0 * R1, M);
+  if (R3 > 1) fill_pass_twiddles<R3, NT * TEAMS>(tw3, twm_g, R0 * R1 * R2, M);
   unsigned blk = blockIdx.x;                       // 32-bit index math: 64-bit divisions cost ~100 scalar ops each
   const int b = (int)(blk % (unsigned)B);
   blk /= (unsigned)B;
@@ -280,46 +288,49 @@ __global__ __launch_bounds__(NT) void split_inner_corr_kernel(const float2* __re
   blk /= (unsigned)D;
   const unsigned epc = blk % (unsigned)nblk_ep;
   const int k1 = (int)(blk / (unsigned)nblk_ep);
-  const int j = threadIdx.x;
   const bool act = j < nb0;
   const float2* have = nullptr;
   float2 xv[R0];
-  const long ep0 = ep_first + (long)epc * pch;
-  long e = ep0 / P;
-  int p = (int)(ep0 - e * P) - 1;
-  for (int i = 0; i < pch; i++) {
-    if (++p == P) { p = 0; e++; }
-    const long g = (ep0 + i) * D + d;
-    if (g < g0 || g >= g0 + ng) continue;          // uniform over the workgroup
-    const float2* gx = X + ((((e * F + fset[p]) * D + d) * (long)B + b) * R + k1) * (long)M;
-    const float2* gc = C + ((long)items[p] * R + k1) * (long)M;
-    float2* gz = Z + (((g - g0) * B + b) * R + k1) * (long)M;
-    if (act) {
-      float2 cv[R0];
+  const unsigned ep0 = (unsigned)ep_first + epc * (unsigned)pch;       // E * P < 2^31 (checked by the launcher)
+  for (int i0 = 0; i0 < pch; i0 += TEAMS) {
+    const unsigned ep = ep0 + (unsigned)(i0 + team);
+    const unsigned e = ep / (unsigned)P;
+    const int p = (int)(ep - e * (unsigned)P);
+    const long g = (long)ep * D + d;
+    const bool live = (i0 + team < pch) && g >= g0 && g < g0 + ng;       // uniform over the team
+    const float2* gx = nullptr;
+    float2* gz = nullptr;
+    if (live) {
+      gx = X + (((((long)e * F + fset[p]) * D + d) * (long)B + b) * R + k1) * (long)M;
+      const float2* gc = C + ((long)items[p] * R + k1) * (long)M;
+      gz = Z + (((g - g0) * B + b) * R + k1) * (long)M;
+      if (act) {
+        float2 cv[R0];
 #pragma unroll
-      for (int t = 0; t < R0; t++) cv[t] = gc[j + t * nb0];
-      if (gx != have) {
+        for (int t = 0; t < R0; t++) cv[t] = gc[j + t * nb0];
+        if (gx != have) {
 #pragma unroll
-        for (int t = 0; t < R0; t++) xv[t] = gx[j + t * nb0];
+          for (int t = 0; t < R0; t++) xv[t] = gx[j + t * nb0];
+        }
+        v2 x[R0];
+#pragma unroll
+        for (int t = 0; t < R0; t++)
+          x[t] = v2{cv[t].x * xv[t].x + cv[t].y * xv[t].y, cv[t].y * xv[t].x - cv[t].x * xv[t].y};      // C * conj(X)   acquire-gps-l1.py:32
+        SmallDft<R0, true>::run(x);
+#pragma unroll
+        for (int t = 0; t < R0; t++) buf0[j * R0 + t] = x[t];                                             // Ns = 1: k = 0, no twiddles
       }
-      v2 x[R0];
-#pragma unroll
-      for (int t = 0; t < R0; t++)
-        x[t] = v2{cv[t].x * xv[t].x + cv[t].y * xv[t].y, cv[t].y * xv[t].x - cv[t].x * xv[t].y};      // C * conj(X)   acquire-gps-l1.py:32
-      SmallDft<R0, true>::run(x);
-#pragma unroll
-      for (int t = 0; t < R0; t++) buf0[j * R0 + t] = x[t];                                             // Ns = 1: k = 0, no twiddles
+      have = gx;
     }
-    have = gx;
     __syncthreads();
-    stockham_pass<R1, false, M, NT>(buf0, nullptr, tw1, R0);
+    stockham_pass<R1, false, M, NT>(buf0, nullptr, tw1, R0, j, live);
     __syncthreads();
     if (R3 > 1) {
-      stockham_pass<R2, false, M, NT>(buf0, nullptr, tw2, R0 * R1);
+      stockham_pass<R2, false, M, NT>(buf0, nullptr, tw2, R0 * R1, j, live);
       __syncthreads();
-      stockham_pass<(R3 > 1 ? R3 : 2), true, M, NT>(buf0, gz, tw3, R0 * R1 * R2);
+      stockham_pass<(R3 > 1 ? R3 : 2), true, M, NT>(buf0, gz, tw3, R0 * R1 * R2, j, live);
     } else {
-      stockham_pass<R2, true, M, NT>(buf0, gz, tw2, R0 * R1);
+      stockham_pass<R2, true, M, NT>(buf0, gz, tw2, R0 * R1, j, live);
     }
     __syncthreads();                               // buf0 is rewritten by the next item's first pass
   }
@@ -397,22 +408,36 @@ int split_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* C, const
   const float2* twm;
   int rc = inner_twiddles(ctx, M, &twm);
   if (rc != GACQ_OK) return rc;
-  const size_t smem = sizeof(float2) * 2 * (size_t)M;
   // (epoch, item) rows touched by this pass, cut into chunks of pch per workgroup; >= ~2048 workgroups, <= 8 items each
   const long ep_first = g0 / D, ep_last = (g0 + ng - 1) / D;
   const long nep = ep_last - ep_first + 1;
   int pch = (int)std::max<long>(1, std::min<long>(8, nep * D * B * R / 2048));
   if (ctx->opt[GACQ_OPT_SPLIT_PCH] >= 1) pch = (int)ctx->opt[GACQ_OPT_SPLIT_PCH];
+  int teams = pch >= 4 ? 4 : pch >= 2 ? 2 : 1;
+  if (ctx->opt[GACQ_OPT_SPLIT_TEAMS] >= 1) teams = (int)ctx->opt[GACQ_OPT_SPLIT_TEAMS];
+  if (teams != 1 && teams != 2 && teams != 4) return set_error(ctx, GACQ_ERR_BAD_ARG, "split engine: teams per workgroup must be 1, 2 or 4");
+  pch = (pch + teams - 1) / teams * teams;
   const int nblk_ep = (int)((nep + pch - 1) / pch);
   const dim3 grid((unsigned)((long)R * nblk_ep * D * B));
-  if (M == 1980)
-    hipLaunchKernelGGL((split_inner_corr_kernel<11, 12, 15, 1, 192>), grid, dim3(192), smem, ctx->stream, X, C, Z, d_items, d_fset, twm, g0, ng,
-                       ep_first, nblk_ep, pch, P, F, D, B, R);
-  else if (M == 990)
-    hipLaunchKernelGGL((split_inner_corr_kernel<11, 9, 10, 1, 128>), grid, dim3(128), smem, ctx->stream, X, C, Z, d_items, d_fset, twm, g0, ng,
-                       ep_first, nblk_ep, pch, P, F, D, B, R);
-  else
+  const size_t smem = sizeof(float2) * ((size_t)teams * M + (size_t)M);
+#define GACQ_LAUNCH_INNER(KERN, NT)                                                                                                 \
+  do {                                                                                                                              \
+    GACQ_HIP(ctx, hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                   \
+    hipLaunchKernelGGL(KERN, grid, dim3((NT) * teams), smem, ctx->stream, X, C, Z, d_items, d_fset, twm, g0, ng, ep_first, nblk_ep, pch, P, F, D, \
+                       B, R);                                                                                                       \
+  } while (0)
+  if (M == 1980) {
+    if (teams == 4) GACQ_LAUNCH_INNER((split_inner_corr_kernel<11, 12, 15, 1, 192, 4>), 192);
+    else if (teams == 2) GACQ_LAUNCH_INNER((split_inner_corr_kernel<11, 12, 15, 1, 192, 2>), 192);
+    else GACQ_LAUNCH_INNER((split_inner_corr_kernel<11, 12, 15, 1, 192, 1>), 192);
+  } else if (M == 990) {
+    if (teams == 4) GACQ_LAUNCH_INNER((split_inner_corr_kernel<11, 9, 10, 1, 128, 4>), 128);
+    else if (teams == 2) GACQ_LAUNCH_INNER((split_inner_corr_kernel<11, 9, 10, 1, 128, 2>), 128);
+    else GACQ_LAUNCH_INNER((split_inner_corr_kernel<11, 9, 10, 1, 128, 1>), 128);
+  } else {
     return set_error(ctx, GACQ_ERR_UNSUPPORTED, "fused inner transforms: M=%d not supported", M);
+  }
+#undef GACQ_LAUNCH_INNER
   GACQ_HIP(ctx, hipGetLastError());
   return GACQ_OK;
 }

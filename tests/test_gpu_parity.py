@@ -930,3 +930,58 @@ def test_fp32_engines_agree_with_the_complex128_engine_on_near_ties(engine):
             np.testing.assert_array_equal(got["d_index"], ref["d_index"])
             np.testing.assert_allclose(got["metric"], ref["metric"], rtol=METRIC_RTOL)
         engine.set_engine(0)
+
+
+def test_fused_4096_kernel_equals_two_kernel_path(engine):
+    """N = 4096, one block, one carrier: forward + correlate in one kernel (option fused_4k) -- same arithmetic in the same
+    order as lds_forward_kernel + lds_correlate_kernel, so the peak records are bit-identical, for every item-chunk size."""
+    import torch
+    from gnss_dsp_tools_amd import acquire, signals, synth
+    sig = signals.get("gps-l1")
+    items = list(range(1, 33))
+    dop = acquire.doppler_grid([-5000.0, 5000.0, 250.0])
+    xs = synth.make_epochs(sig, 1, 1357, synth.default_sats(items), 5, nsamp=4096)
+    xd = torch.from_numpy(xs).cuda()
+    try:
+        plain = engine.search_batch_dev(sig, xd, items, dop, 1)
+        torch.cuda.synchronize()
+        plain = plain.cpu().numpy().tobytes()
+        engine.set_option("fused_4k", 1)
+        engine.set_profiling(True)
+        for pch in (0, 1, 5, 8, 32):
+            engine.set_option("lds_pch", pch)
+            engine.reset_stage_times()
+            fused = engine.search_batch_dev(sig, xd, items, dop, 1)
+            torch.cuda.synchronize()
+            assert engine.stage_times()["mix_nco"][1] == 0                 # no separate forward launch
+            assert fused.cpu().numpy().tobytes() == plain, pch
+        # a single item and a two-block search fall back / stay correct
+        one = engine.search_batch_dev(sig, xd, [7], dop, 1)
+        torch.cuda.synchronize()
+        engine.set_option("fused_4k", 0)
+        engine.set_option("lds_pch", 0)
+        one_plain = engine.search_batch_dev(sig, xd, [7], dop, 1)
+        torch.cuda.synchronize()
+        assert one.cpu().numpy().tobytes() == one_plain.cpu().numpy().tobytes()
+    finally:
+        engine.set_option("fused_4k", 0)
+        engine.set_option("lds_pch", 0)
+        engine.set_profiling(False)
+
+
+@pytest.mark.parametrize("cid", ["cfg4_l5i_subset", "gal_e6b", "bds_b2bq"])
+@pytest.mark.parametrize("teams", [1, 2, 4])
+def test_stockham_inner_kernel_teams_match_reference_golden(engine, golden_cases, cid, teams):
+    """The Stockham inner kernel with 1, 2 or 4 rows (teams of waves) per workgroup sharing one set of twiddle tables, incl. item
+    counts that are not multiples of the team count (idle teams walk through the barriers)."""
+    case = golden_cases[cid]
+    x = case_iq(case)
+    engine.set_option("split_teams", teams)
+    try:
+        for pch in (0, 3):
+            engine.set_option("split_pch", pch)
+            got = engine.search_all(case["script"], x, case["items"], case["doppler_search"], case["ms"])
+            _assert_results(got, case["results"], case)
+    finally:
+        engine.set_option("split_teams", 0)
+        engine.set_option("split_pch", 0)

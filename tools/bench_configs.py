@@ -44,10 +44,14 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--stages", action="store_true", help="also print per-stage HIP-event times")
     ap.add_argument("--ws", type=int, default=0, help="workspace limit in MiB (0 = library default)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="gacq_set_option tuning switch")
     ap.add_argument("cases", nargs="*")
     args = ap.parse_args()
     eng = acquire.Engine(0, engine=args.engine, workspace_bytes=(args.ws << 20) if args.ws else None)
     eng.use_torch_stream()
+    for kv in args.option:
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
     for cid in (args.cases or list(CASES)):
         name, items, ds, ms, E = CASES[cid]
         sig = signals.get(name)

@@ -22,10 +22,11 @@ def main():
     eng.use_torch_stream()
     base = synth.make_epochs(sig, 1, 77, synth.default_sats(items), 8, nsamp=4096)
     if "sweep" in what:
-        for E in (64, 128, 256, 512):
-            xd = torch.from_numpy(np.concatenate([base] * (E // 8))).cuda()
-            for pch in (0, 4, 8, 16, 32):
+        for E, fused, pch in [(E, fused, pch) for E in (8, 64, 256) for fused in (0, 1) for pch in (0, 8, 16, 32)]:
+            xd = torch.from_numpy(np.concatenate([base] * max(1, E // 8))[:E]).cuda()
+            if True:
                 eng.set_option("lds_pch", pch)
+                eng.set_option("fused_4k", fused)
                 for _ in range(10):
                     eng.search_batch_dev(sig, xd, items, dop, 1)
                 torch.cuda.synchronize()
@@ -35,8 +36,9 @@ def main():
                     eng.search_batch_dev(sig, xd, items, dop, 1)
                 torch.cuda.synchronize()
                 dt = (time.perf_counter() - t0) / n
-                print("E=%4d pch=%2d  %.4f ms/step  %.4f ms per 64 epochs  %.3e cells/s" % (E, pch, dt * 1e3, dt * 1e3 * 64 / E, E * 32 * 40 * 4096 / dt), flush=True)
+                print("E=%4d fused=%d pch=%2d  %.4f ms/step  %.4f ms per 64 epochs  %.3e cells/s" % (E, fused, pch, dt * 1e3, dt * 1e3 * 64 / E, E * 32 * 40 * 4096 / dt), flush=True)
         eng.set_option("lds_pch", 0)
+        eng.set_option("fused_4k", 0)
     if "timeline" in what:
         xd = torch.from_numpy(np.concatenate([base] * 8)).cuda()
         for idle in (0.0, 0.5):
