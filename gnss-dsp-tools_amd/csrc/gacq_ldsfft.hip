@@ -297,18 +297,20 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_correlate_kernel(const flo
     const __amdgpu_buffer_rsrc_t cres = big_rsrc(C + (long)items[p] * kBig);
     const float2* xs = X + (((e * F + fset[p]) * D + d) * (long)B) * kBig;
     float q[kR];
+    // the code spectrum of the item stays in registers for all B blocks: half the loads (and half the L2 traffic: the 63 x 128 KB
+    // of B1I code spectra do not fit the 4 MB L2 next to the forward spectra) of re-reading it per block
+    v2 c[kR];
+#pragma unroll
+    for (int jp = 0; jp < kR / 2; jp++) ld_pair_big(cres, lane_off, jp, c[2 * jp], c[2 * jp + 1]);
 #pragma unroll
     for (int k = 0; k < kR; k++) q[k] = 0.f;
     for (int b = 0; b < B; b++) {
       const __amdgpu_buffer_rsrc_t xres = big_rsrc(xs + (long)b * kBig);
-      v2 v[kR], xv[kR];
+      v2 v[kR];
 #pragma unroll
-      for (int jp = 0; jp < kR / 2; jp++) {          // loads first, asm afterwards
-        ld_pair_big(cres, lane_off, jp, v[2 * jp], v[2 * jp + 1]);
-        ld_pair_big(xres, lane_off, jp, xv[2 * jp], xv[2 * jp + 1]);
-      }
+      for (int jp = 0; jp < kR / 2; jp++) ld_pair_big(xres, lane_off, jp, v[2 * jp], v[2 * jp + 1]);      // loads first, asm afterwards
 #pragma unroll
-      for (int jj = 0; jj < kR; jj++) v[jj] = cmul(v[jj], xv[jj]);
+      for (int jj = 0; jj < kR; jj++) v[jj] = cmul(c[jj], v[jj]);
       if (b > 0 || p > p0) __syncthreads();          // previous transform's last LDS reads are complete
       fft16k<true>(v, lds, twn, base);
 #pragma unroll
@@ -599,6 +601,11 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float
       for (int k = 0; k < kR; k++) q[k] = 0.f;
     }
     const int nb = B1 ? 1 : B;
+    v2 cc[B1 ? 1 : kR];                    // B > 1: the item's code spectrum stays in registers for all blocks
+    if (!B1) {
+#pragma unroll
+      for (int jp = 0; jp < kR / 2; jp++) ld_pair(cres, lane_off, jp, cc[2 * jp], cc[2 * jp + 1]);
+    }
     for (int b = 0; b < nb; b++) {
       if (OPAQUE) asm volatile("" : "+v"(wa.x), "+v"(wa.y), "+v"(wb.x), "+v"(wb.y));
       v2 v[kR];
@@ -609,7 +616,7 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float
         for (int jp = 0; jp < kR / 2; jp++) ld_pair(cres, lane_off, jp, v[2 * jp], v[2 * jp + 1]);
 #pragma unroll
         for (int jj = 0; jj < kR; jj++) v[jj] = cmul(v[jj], xr[jj]);
-      } else {
+      } else if (B1) {
         const __amdgpu_buffer_rsrc_t xres = row_rsrc(xs + (long)b * kLdsN);
         v2 xv[kR];
 #pragma unroll
@@ -619,6 +626,12 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float
         }
 #pragma unroll
         for (int jj = 0; jj < kR; jj++) v[jj] = cmul(v[jj], xv[jj]);
+      } else {
+        const __amdgpu_buffer_rsrc_t xres = row_rsrc(xs + (long)b * kLdsN);
+#pragma unroll
+        for (int jp = 0; jp < kR / 2; jp++) ld_pair(xres, lane_off, jp, v[2 * jp], v[2 * jp + 1]);
+#pragma unroll
+        for (int jj = 0; jj < kR; jj++) v[jj] = cmul(cc[jj], v[jj]);
       }
       if (!B1 && b > 0) __syncthreads();   // previous transform's exchange-2 reads are complete
       if (PRETW) fft4096<true, true>(v, lds, wa, wb, reinterpret_cast<const v2(*)[15]>(pwa), reinterpret_cast<const v2(*)[15]>(pwb));

@@ -413,7 +413,7 @@ int split_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* C, const
   const long nep = ep_last - ep_first + 1;
   int pch = (int)std::max<long>(1, std::min<long>(8, nep * D * B * R / 2048));
   if (ctx->opt[GACQ_OPT_SPLIT_PCH] >= 1) pch = (int)ctx->opt[GACQ_OPT_SPLIT_PCH];
-  int teams = pch >= 4 ? 4 : pch >= 2 ? 2 : 1;
+  int teams = 1;      // measured (profiles/r02_stockham_teams_sweep.log): 2 or 4 rows per workgroup are 5-10 % slower despite 24 instead of 15 waves per CU
   if (ctx->opt[GACQ_OPT_SPLIT_TEAMS] >= 1) teams = (int)ctx->opt[GACQ_OPT_SPLIT_TEAMS];
   if (teams != 1 && teams != 2 && teams != 4) return set_error(ctx, GACQ_ERR_BAD_ARG, "split engine: teams per workgroup must be 1, 2 or 4");
   pch = (pch + teams - 1) / teams * teams;
