@@ -194,7 +194,7 @@ def main():
     ap.add_argument("--no-latency", action="store_true",
                     help="skip the single-epoch host-call latency probe (profiling runs: keeps every launch the bench workload)")
     ap.add_argument("--sustained-s", type=float, default=1.5, help="length of the second, sustained timed region (0 = skip)")
-    ap.add_argument("--preroll-s", type=float, default=0.4, help="untimed load before the warm-up steps so the GPU has clocked up (0 = none)")
+    ap.add_argument("--preroll-s", type=float, default=0.3, help="untimed load before the warm-up steps so the GPU has clocked up (0 = none)")
     ap.add_argument("--no-self-check", action="store_true", help="ablation builds compute garbage on purpose (tools/ablate.sh)")
     ap.add_argument("--force-gather", action="store_true", help="run the all-gather + merge even on 1 rank (test aid)")
     args = ap.parse_args()
@@ -298,11 +298,17 @@ def main():
     # W warm-up steps and the K timed steps; its length is reported in the JSON line.
     preroll = {"seconds": 0.0, "steps": 0}
     if args.preroll_s > 0:
+        run_steps(1)                                     # first call: code spectra, FFT plans, workspaces (not load, not counted)
+        torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
+        per = 16
         while time.perf_counter() - t0 < args.preroll_s:
-            run_steps(4)
+            t1 = time.perf_counter()
+            run_steps(per)                               # long uninterrupted stretches: the ramp needs tens of ms of continuous load
             torch.cuda.synchronize(dev)
-            preroll["steps"] += 4
+            preroll["steps"] += per
+            if time.perf_counter() - t1 < 0.05:
+                per *= 2
         preroll["seconds"] = time.perf_counter() - t0
     run_steps(args.warmup)
     merged, dt = timed(args.steps)
