@@ -51,7 +51,7 @@ struct gacq_ctx {
   size_t ws_limit = (size_t)4 << 30;
   std::map<std::pair<long, long>, gacq::FftPlan> plans;   // (N * 2 + inverse, batch)
   gacq::DevBuf tab, xstage, X, Y, rows, freq, fset, items, out_peaks, d0, partial, fe_a, fe_b, fe_taps, chunk_peaks;
-  long opt[GACQ_NOPTS] = {1, 1, -1, 0, 0, 0, 0, 1};   // gacq_set_option values (defaults documented in include/gacq.h)
+  long opt[GACQ_NOPTS] = {1, 1, -1, 0, 0, 0, 1};   // gacq_set_option values (defaults documented in include/gacq.h)
   gacq::DevBuf pin_x, pin_peaks;       // pinned host staging for the host-buffer entry point (gacq_search)
   gacq::BatchRing* ring = nullptr;     // staging ring of gacq_search_batch / gacq_group_search_batch, created on first use
   bool profiling = false;
@@ -107,7 +107,7 @@ bool lds_fused_supported(const gacq_ctx* ctx, int N, int P, int F);
 int lds_fused_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n, int N, const float2* spectra, const int* d_items,
                      const int* d_fset, const double* d_freq, const float2* tab, int nitems, int D, int B, RowRec* rows);
 // N = 4096, B == 1, one carrier: forward + correlate in one kernel, no X buffer
-bool lds_fused4k_supported(const gacq_ctx* ctx, int N, int B, int F);
+bool lds_fused4k_supported(const gacq_ctx* ctx, int N, int B, int F, long units);
 int lds_fused4k_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, const float2* spectra, const int* d_items,
                        const double* d_freq, const float2* tab, int nitems, int D, RowRec* rows);
 int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const int* d_items, const int* d_fset,

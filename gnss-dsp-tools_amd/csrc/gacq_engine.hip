@@ -674,7 +674,7 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
   const bool fused16k = use_lds && lds_fused_supported(ctx, N, P, F);      // one carrier per item: no forward-spectra buffer at all
   const size_t x_epoch_bytes = sizeof(float2) * (size_t)F * D * B * N;
   int Ec = (int)std::max<size_t>(1, std::min<size_t>((size_t)nepoch, ctx->ws_limit / std::max<size_t>(1, x_epoch_bytes)));
-  const bool fused4k = use_lds && !fused16k && lds_fused4k_supported(ctx, N, B, F);
+  const bool fused4k = use_lds && !fused16k && lds_fused4k_supported(ctx, N, B, F, (long)nepoch * D);
   if (fused16k || fused4k) Ec = nepoch;            // nothing but the 16-byte row records is buffered
   if (!fused16k && !fused4k && (rc = ensure(ctx, ctx->X, x_epoch_bytes * Ec)) != GACQ_OK) return rc;
   if ((rc = ensure(ctx, ctx->rows, sizeof(RowRec) * (size_t)Ec * P * D)) != GACQ_OK) return rc;
@@ -839,7 +839,7 @@ int gacq_search_batch_dev(gacq_sig* sig, const void* d_x, size_t nsamp, int nepo
     F = (int)seen.size();
   }
   const size_t bin_bytes = (ctx->engine == 5 ? sizeof(double2) : sizeof(float2)) * (size_t)F * blocks * sig->N;
-  const bool no_x = (ctx->engine == 0 || ctx->engine == 2) && (lds_fused_supported(ctx, sig->N, nitems, F) || lds_fused4k_supported(ctx, sig->N, blocks, F));
+  const bool no_x = (ctx->engine == 0 || ctx->engine == 2) && (lds_fused_supported(ctx, sig->N, nitems, F) || lds_fused4k_supported(ctx, sig->N, blocks, F, (long)nepoch * nd));
   if (!no_x && nd > 1 && bin_bytes * nd > ctx->ws_limit) {
     const int Dc = (int)std::max<size_t>(1, ctx->ws_limit / bin_bytes);
     const int nch = (nd + Dc - 1) / Dc;

@@ -869,7 +869,11 @@ int lds_fused_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, i
   return GACQ_OK;
 }
 
-bool lds_fused4k_supported(const gacq_ctx* ctx, int N, int B, int F) { return N == kLdsN && B == 1 && F == 1 && ctx->opt[GACQ_OPT_FUSED_4K]; }
+// Worth it for batches only: with few (epoch, Doppler) units every workgroup's own forward transform sits on the critical path
+// (single epoch: 32 us fused against 19 us for the two kernels), with many it replaces a launch, 84 MB of X traffic and a tail.
+bool lds_fused4k_supported(const gacq_ctx* ctx, int N, int B, int F, long units) {
+  return N == kLdsN && B == 1 && F == 1 && (ctx->opt[GACQ_OPT_FUSED_4K] >= 2 || (ctx->opt[GACQ_OPT_FUSED_4K] == 1 && units >= 1024));
+}
 
 int lds_fused4k_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, const float2* spectra, const int* d_items,
                        const double* d_freq, const float2* tab, int nitems, int D, RowRec* rows) {

@@ -111,10 +111,10 @@ int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes);
 #define GACQ_OPT_LDS_VARIANT 2  /* [-1 = built-in choice] register/occupancy variant of lds_correlate_kernel            */
 #define GACQ_OPT_LDS_PCH 3      /* [0 = auto] items per workgroup of the LDS correlate kernels                          */
 #define GACQ_OPT_SPLIT_PCH 4    /* [0 = auto] (epoch, item) rows per workgroup of the split engines' inner kernels      */
-#define GACQ_OPT_GRAPH 5        /* [0] 1: gacq_search replays a captured hipGraph when the call shape repeats           */
-#define GACQ_OPT_SPLIT_TEAMS 6  /* [0 = auto] rows (teams of waves) per workgroup of the Stockham inner kernel: 1, 2 or 4  */
-#define GACQ_OPT_FUSED_4K 7     /* [1] N = 4096, B = 1, one carrier: forward + correlate in one kernel (no forward-spectra buffer) */
-#define GACQ_NOPTS 8
+#define GACQ_OPT_SPLIT_TEAMS 5  /* [0 = auto] rows (teams of waves) per workgroup of the Stockham inner kernel: 1, 2 or 4  */
+#define GACQ_OPT_FUSED_4K 6     /* [1] N = 4096, B = 1, one carrier, >= 1024 (epoch, Doppler) units: forward + correlate in  */
+                                /*     one kernel (no forward-spectra buffer); 2 = also for small batches                    */
+#define GACQ_NOPTS 7
 int gacq_set_option(gacq_ctx* ctx, int option, long value);
 int gacq_get_option(gacq_ctx* ctx, int option, long* value);
 

@@ -943,10 +943,11 @@ def test_fused_4096_kernel_equals_two_kernel_path(engine):
     xs = synth.make_epochs(sig, 1, 1357, synth.default_sats(items), 5, nsamp=4096)
     xd = torch.from_numpy(xs).cuda()
     try:
+        engine.set_option("fused_4k", 0)
         plain = engine.search_batch_dev(sig, xd, items, dop, 1)
         torch.cuda.synchronize()
         plain = plain.cpu().numpy().tobytes()
-        engine.set_option("fused_4k", 1)
+        engine.set_option("fused_4k", 2)                                   # 2: also for batches this small
         engine.set_profiling(True)
         for pch in (0, 1, 5, 8, 32):
             engine.set_option("lds_pch", pch)
@@ -964,7 +965,7 @@ def test_fused_4096_kernel_equals_two_kernel_path(engine):
         torch.cuda.synchronize()
         assert one.cpu().numpy().tobytes() == one_plain.cpu().numpy().tobytes()
     finally:
-        engine.set_option("fused_4k", 0)
+        engine.set_option("fused_4k", 1)
         engine.set_option("lds_pch", 0)
         engine.set_profiling(False)
 

@@ -26,7 +26,7 @@ def main():
             xd = torch.from_numpy(np.concatenate([base] * max(1, E // 8))[:E]).cuda()
             if True:
                 eng.set_option("lds_pch", pch)
-                eng.set_option("fused_4k", fused)
+                eng.set_option("fused_4k", 2 * fused)
                 for _ in range(10):
                     eng.search_batch_dev(sig, xd, items, dop, 1)
                 torch.cuda.synchronize()
@@ -38,7 +38,7 @@ def main():
                 dt = (time.perf_counter() - t0) / n
                 print("E=%4d fused=%d pch=%2d  %.4f ms/step  %.4f ms per 64 epochs  %.3e cells/s" % (E, fused, pch, dt * 1e3, dt * 1e3 * 64 / E, E * 32 * 40 * 4096 / dt), flush=True)
         eng.set_option("lds_pch", 0)
-        eng.set_option("fused_4k", 0)
+        eng.set_option("fused_4k", 1)
     if "timeline" in what:
         xd = torch.from_numpy(np.concatenate([base] * 8)).cuda()
         for idle in (0.0, 0.5):
