@@ -62,6 +62,27 @@ __device__ __forceinline__ void apply_table(v2 (&v)[kR], const v2 (&pw)[15]) {
   for (int k = 1; k < kR; k++) v[rev16(k)] = cmul(v[rev16(k)], pw[k - 1]);
 }
 
+// (max, first argmax) of the 16 x 64 magnitudes a wave holds; lane l of the wave holds lag base + mult * l + kstride * k in
+// m[k], with kstride > 63 * mult so that lags grow with k first.  The maximum is found first -- per lane with max3, over the
+// wave on DPP -- and only then located: for every k one v_cmp against the wave-uniform maximum gives a lane mask in SGPRs; the
+// smallest k with a non-empty mask and its lowest lane are the smallest lag attaining the maximum (np.argmax returns the first
+// maximum, acquire-gps-l1.py:34).  24 VALU instructions instead of the 47 of a running (value, index) pair per lane; the
+// bookkeeping runs on the scalar unit.  Magnitudes are >= 0, so their bit patterns order like the values.
+__device__ __forceinline__ void wave_first_max(const float (&m)[kR], unsigned base, unsigned mult, unsigned kstride, float& wmaxf,
+                                               unsigned& widx) {
+  float lmax = __builtin_fmaxf(__builtin_fmaxf(m[0], m[1]), m[2]);
+#pragma unroll
+  for (int k = 3; k + 1 < kR; k += 2) lmax = __builtin_fmaxf(__builtin_fmaxf(lmax, m[k]), m[k + 1]);
+  lmax = __builtin_fmaxf(lmax, m[kR - 1]);
+  wmaxf = __builtin_bit_cast(float, wave_max_u32(__builtin_bit_cast(unsigned, lmax)));
+  widx = 0xffffffffu;
+#pragma unroll
+  for (int k = kR - 1; k >= 0; k--) {                                            // descending: the last assignment is the smallest k
+    const unsigned long long mk = __builtin_amdgcn_ballot_w64(m[k] == wmaxf);
+    if (mk) widx = kstride * k + base + mult * (unsigned)__builtin_ctzll(mk);
+  }
+}
+
 // Length-4096 transform of the 16 values per lane. In: v[j] = x[t + 256 j]; out: v[rev16(k2)] = X[t + 256 k2].
 // wa = W_4096^t, wb = W_256^(t & 15) (forward values; conjugated here when INV).
 template <bool INV, bool PRE = false>
@@ -319,19 +340,14 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_correlate_kernel(const flo
         q[k] += __builtin_amdgcn_sqrtf(r.x * r.x + r.y * r.y) * inv_n;
       }
     }
-    float peak = q[0];
-    int idx = lag0;
     float sum_f = q[0];
 #pragma unroll
-    for (int k = 1; k < kR; k++) {
-      if (q[k] > peak) { peak = q[k]; idx = lag0 + 1024 * k; }
-      sum_f += q[k];
-    }
-    // wave64 reduce on DPP (see lds_correlate_kernel): non-negative floats order like their bit patterns, ties -> smallest lag
-    const unsigned pbits = __builtin_bit_cast(unsigned, peak);
-    const unsigned wmax = wave_max_u32(pbits);
-    idx = (int)wave_min_u32(pbits == wmax ? (unsigned)idx : 0xffffffffu);
-    peak = __builtin_bit_cast(float, wmax);
+    for (int k = 1; k < kR; k++) sum_f += q[k];
+    // lane l of a wave holds lags lag0 + 1024 k with lag0 = g + 4 (tl_base + l): first maximum as in lds_correlate_kernel
+    float peak;
+    unsigned widx;
+    wave_first_max(q, (unsigned)__builtin_amdgcn_readfirstlane(lag0), 4u, 1024u, peak, widx);
+    int idx = (int)widx;
     double sum = (double)wave_add_f32(sum_f);
     if ((t & 63) == 0) { s_peak[t >> 6] = peak; s_idx[t >> 6] = idx; s_sum[t >> 6] = sum; }
     __syncthreads();
@@ -416,18 +432,13 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_fused_kernel(const float2*
     }
     __syncthreads();                                  // the inverse transform's last LDS reads are complete
   }
-  float peak = q[0];
-  int idx = lane;
   float sum_f = q[0];
 #pragma unroll
-  for (int k = 1; k < kR; k++) {
-    if (q[k] > peak) { peak = q[k]; idx = lane + 1024 * k; }
-    sum_f += q[k];
-  }
-  const unsigned pbits = __builtin_bit_cast(unsigned, peak);
-  const unsigned wmax = wave_max_u32(pbits);
-  idx = (int)wave_min_u32(pbits == wmax ? (unsigned)idx : 0xffffffffu);
-  peak = __builtin_bit_cast(float, wmax);
+  for (int k = 1; k < kR; k++) sum_f += q[k];
+  float peak;
+  unsigned widx;
+  wave_first_max(q, (unsigned)__builtin_amdgcn_readfirstlane(lane), 4u, 1024u, peak, widx);      // lane l of the wave: lags lane + 4 l + 1024 k
+  int idx = (int)widx;
   double sum = (double)wave_add_f32(sum_f);
   if ((t & 63) == 0) { s_peak[t >> 6] = peak; s_idx[t >> 6] = idx; s_sum[t >> 6] = sum; }
   __syncthreads();
@@ -593,9 +604,7 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float
   for (int p = p0; p < p1; p++) {
     const __amdgpu_buffer_rsrc_t cres = row_rsrc(C + (long)items[p] * kLdsN);
     const float2* xs = X + (((e * F + fset[p]) * D + d) * (long)B) * kLdsN;
-    float peak, sum_f = 0.f;
-    int idx;
-    float q[B1 ? 1 : kR];
+    float q[kR];                           // B1: the magnitudes of the one block; else the sum over blocks
     if (!B1) {
 #pragma unroll
       for (int k = 0; k < kR; k++) q[k] = 0.f;
@@ -637,22 +646,13 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float
       if (PRETW) fft4096<true, true>(v, lds, wa, wb, reinterpret_cast<const v2(*)[15]>(pwa), reinterpret_cast<const v2(*)[15]>(pwb));
       else fft4096<true>(v, lds, wa, wb);
       if (B1) {
-        // (max, first argmax, sum) straight from the transform output; lane holds lags t + 256 k.  The 1/N of ifft is a
-        // power of two: it is applied once to the reduced values below instead of to all 16 magnitudes.
-        const v2 r0 = v[rev16(0)];
-        peak = __builtin_amdgcn_sqrtf(r0.x * r0.x + r0.y * r0.y);              // np.absolute(ifft(...)) * N
-        int bestk = 0;
-        sum_f = peak;
+        // magnitudes straight from the transform output; lane holds lags t + 256 k.  The 1/N of ifft is a power of two: it is
+        // applied once to the reduced values below instead of to all 16 magnitudes.
 #pragma unroll
-        for (int k = 1; k < kR; k++) {
+        for (int k = 0; k < kR; k++) {
           const v2 r = v[rev16(k)];
-          const float m = __builtin_amdgcn_sqrtf(r.x * r.x + r.y * r.y);
-          if (m > peak) { peak = m; bestk = k; }                                // strict '>' keeps the first maximum
-          sum_f += m;
+          q[k] = __builtin_amdgcn_sqrtf(r.x * r.x + r.y * r.y);                  // np.absolute(ifft(...)) * N
         }
-        idx = t + 256 * bestk;
-        peak *= inv_n;
-        sum_f *= inv_n;
       } else {
 #pragma unroll
         for (int k = 0; k < kR; k++) {
@@ -661,22 +661,14 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float
         }
       }
     }
-    if (!B1) {
-      peak = q[0];
-      idx = t;
-      sum_f = q[0];
+    float sum_f = q[0];
 #pragma unroll
-      for (int k = 1; k < kR; k++) {
-        if (q[k] > peak) { peak = q[k]; idx = t + 256 * k; }
-        sum_f += q[k];
-      }
-    }
-    // wave64 reduce on DPP: magnitudes are >= 0, so their bit patterns order like unsigned integers; ties go to the
-    // smallest lag (np.argmax returns the first maximum)
-    const unsigned pbits = __builtin_bit_cast(unsigned, peak);
-    const unsigned wmax = wave_max_u32(pbits);
-    const unsigned widx = wave_min_u32(pbits == wmax ? (unsigned)idx : 0xffffffffu);
-    const float wsum = wave_add_f32(sum_f);
+    for (int k = 1; k < kR; k++) sum_f += q[k];
+    float wmaxf;
+    unsigned widx;
+    wave_first_max(q, (unsigned)__builtin_amdgcn_readfirstlane(t & ~63), 1u, 256u, wmaxf, widx);      // first maximum, like np.argmax
+    const unsigned wmax = __builtin_bit_cast(unsigned, B1 ? wmaxf * inv_n : wmaxf);
+    const float wsum = wave_add_f32(B1 ? sum_f * inv_n : sum_f);
     if ((t & 63) == 0) { s_peak[t >> 6] = __builtin_bit_cast(float, wmax); s_idx[t >> 6] = (int)widx; s_sum[t >> 6] = (double)wsum; }
     __syncthreads();   // also orders this item's exchange-2 reads before the next item's exchange-1 writes
     if (t == 0) {
@@ -755,24 +747,21 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_fused4k_kernel(const float2*
 #pragma unroll
     for (int jj = 0; jj < kR; jj++) v[jj] = cmul(v[jj], xr[jj]);
     fft4096<true>(v, lds, wa, wb);
-    const v2 r0 = v[rev16(0)];
-    float peak = __builtin_amdgcn_sqrtf(r0.x * r0.x + r0.y * r0.y);              // np.absolute(ifft(...)) * N
-    int bestk = 0;
-    float sum_f = peak;
+    // lane t holds lags t + 256 k.  The 1/N of ifft is a power of two: applied once to the reduced values.
+    float m[kR];
 #pragma unroll
-    for (int k = 1; k < kR; k++) {
+    for (int k = 0; k < kR; k++) {
       const v2 r = v[rev16(k)];
-      const float m = __builtin_amdgcn_sqrtf(r.x * r.x + r.y * r.y);
-      if (m > peak) { peak = m; bestk = k; }                                     // strict '>' keeps the first maximum
-      sum_f += m;
+      m[k] = __builtin_amdgcn_sqrtf(r.x * r.x + r.y * r.y);                      // np.absolute(ifft(...)) * N
     }
-    const int idx = t + 256 * bestk;
-    peak *= inv_n;
-    sum_f *= inv_n;
-    const unsigned pbits = __builtin_bit_cast(unsigned, peak);
-    const unsigned wmax = wave_max_u32(pbits);
-    const unsigned widx = wave_min_u32(pbits == wmax ? (unsigned)idx : 0xffffffffu);
-    const float wsum = wave_add_f32(sum_f);
+    float sum_f = m[0];
+#pragma unroll
+    for (int k = 1; k < kR; k++) sum_f += m[k];
+    float wmaxf;
+    unsigned widx;
+    wave_first_max(m, (unsigned)__builtin_amdgcn_readfirstlane(t & ~63), 1u, 256u, wmaxf, widx);
+    const unsigned wmax = __builtin_bit_cast(unsigned, wmaxf * inv_n);
+    const float wsum = wave_add_f32(sum_f * inv_n);
     if ((t & 63) == 0) { s_peak[t >> 6] = __builtin_bit_cast(float, wmax); s_idx[t >> 6] = (int)widx; s_sum[t >> 6] = (double)wsum; }
     __syncthreads();   // also orders this item's exchange-2 reads before the next item's exchange-1 writes
     if (t == 0) {
