@@ -371,6 +371,7 @@ def test_full_size_properties_config2(engine):
     xd = torch.from_numpy(xs).to("cuda:0")
     xd_shift = torch.roll(xd, s, dims=1).contiguous()
     xd_scale = (xd * 3.0).contiguous()
+    torch.cuda.synchronize()            # torch wrote these on its stream; the engine launches on its own (non-blocking) stream
 
     def run(t, eng):
         engine.set_engine(eng)
@@ -445,7 +446,9 @@ def test_full_size_properties_configs_3_4_5(engine, name, items, ds, ms):
     np.testing.assert_array_equal(auto["idx"], ref["idx"])
     np.testing.assert_array_equal(auto["d_index"], ref["d_index"])
     np.testing.assert_allclose(auto["metric"], ref["metric"], rtol=5e-6)
-    scaled = run((xd * 2.5).contiguous(), 0)
+    xs25 = (xd * 2.5).contiguous()
+    torch.cuda.synchronize()            # written on torch's stream, read on the engine's own stream: order them
+    scaled = run(xs25, 0)
     np.testing.assert_array_equal(scaled["idx"], auto["idx"])
     np.testing.assert_array_equal(scaled["d_index"], auto["d_index"])
     # raw metrics scale with the samples; the normalised max/mean metric (GPS L1) does not change at all
