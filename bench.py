@@ -354,18 +354,28 @@ def main():
                     assert got % n == (-delay) % n, ("bench self-check failed", job["sig"].name, it, got, delay)
 
     # ---- per-kernel durations: HIP events on the launch stream, separate profiled pass, one job at a time -------------
+    # (the engine, stream and call path of the timed region: lane 0; one signal at a time so that stage times can be attributed)
     bounds_of = lambda D: sharded.doppler_bounds(D, world)
-    eng.set_profiling(True)
+    st0, eng0, sh0 = lanes[0]
+    eng0.set_profiling(True)
     prof_steps = max(3, min(10, args.steps))
     per_job = []
     for job in jobs:
         b = bounds_of(len(job["dop"]))
         D_local = b[rank + 1] - b[rank]
-        eng.reset_stage_times()
-        for _ in range(prof_steps):
-            eng.search_batch_dev(job["sig"], job["x"], job["items"], job["dop"][b[rank]:b[rank + 1]], job["B"])
+        with torch.cuda.stream(st0):
+            sh0.search_jobs_async([job]).wait()          # settle (grid upload) before the events start
+            torch.cuda.synchronize(dev)
+            eng0.reset_stage_times()
+            pend = None
+            for _ in range(prof_steps):
+                nxt = sh0.search_jobs_async([job])
+                if pend is not None:
+                    pend.wait()
+                pend = nxt
+            pend.wait()
         torch.cuda.synchronize(dev)
-        stages = eng.stage_times()
+        stages = eng0.stage_times()
         N, P, B, F = job["sig"].nfft, len(job["items"]), job["B"], job["F"]
         fused16k = job["kind"] == "lds" and N == 16384 and F == P
         st_out = {}
@@ -376,7 +386,7 @@ def main():
             st_out[sname] = {"avg_ms": tot_ms / nl, "launches_per_step": nl / prof_steps, "ms_per_step": tot_ms / prof_steps,
                              "bound": bound, "work_per_step": work}
         per_job.append({"signal": job["sig"].name, "engine": job["kind"], "P": P, "D_local": D_local, "B": B, "N": N, "F": F, "stages": st_out})
-    eng.set_profiling(False)
+    eng0.set_profiling(False)
 
     # dominant kernel = the (signal, stage) with the most time per step
     cand = [(s["ms_per_step"], pj, sname) for pj in per_job for sname, s in pj["stages"].items() if s["bound"]]
