@@ -7,8 +7,8 @@ n = N = 4096 code-phase lags -> 5 242 880 cells per 1 ms epoch.  One "step" = on
 EPOCHS independent sample blocks that are already resident in HBM (synthetic seeded IQ):
 table-NCO mix -> forward FFT -> x conj code spectrum -> inverse FFT -> |.| -> peak/mean per Doppler bin -> best per PRN.
 
---config 4 / 5 run the multi-signal shapes of BASELINE configs[3] / configs[4] (L5I + B2aD; GPS L1 + E1B + B1I + GLONASS)
-through ShardedSearch.search_jobs: every signal's Doppler grid is sliced over the ranks, ONE all-gather carries all
+--config 3 runs BASELINE configs[2] (E1B + E1C as one 72-row family with shared forward transforms); --config 4 / 5 run the
+multi-signal shapes of configs[3] / configs[4] (L5I + B2aD; GPS L1 + E1B + B1I + GLONASS) through ShardedSearch.search_jobs: every signal's Doppler grid is sliced over the ranks, ONE all-gather carries all
 signals' peak records.
 
 N GPUs (one process per GPU, torch.distributed/RCCL): --scaling weak (default) keeps per-GPU work fixed (N x EPOCHS epochs,
@@ -40,6 +40,10 @@ CONFIGS = {
     2: {"label": "GPS L1 C/A all 32 PRNs, 1 ms coherent (B=1), fs=4.096 MS/s, n=N=4096, Doppler arange(-5000,5000,250)=40 bins",
         "epochs": 256, "seed": 2,
         "jobs": [("gps-l1", list(range(1, 33)), [-5000.0, 5000.0, 250.0], 1)]},
+    3: {"label": "Galileo E1B + E1C as one family (forward transforms shared), PRN 1-36 each, BOC(1,1), 4092-chip memory codes, fs=8.192 MS/s, "
+                 "n=32768, N=65536 (padded), ms=8 (B=1), Doppler arange(-4000,4000,125)=64 bins",
+        "epochs": 2, "seed": 3,
+        "jobs": [(("galileo-e1b", "galileo-e1c"), (list(range(1, 37)), list(range(1, 37))), [-4000.0, 4000.0, 125.0], 8)]},
     4: {"label": "GPS L5I PRN 1-32 + BeiDou B2aD PRN 1-63, 10.23 Mcps, fs=30.69 MS/s, n=30690, N=61380 (padded), B=1, "
                  "Doppler arange(-7000,7000,200)=70 bins",
         "epochs": 2, "seed": 4,
@@ -128,10 +132,10 @@ def cpu_baseline(jobs, budget_s=14.0):
     while True:
         for ji, job in enumerate(jobs):
             sig = job["sig"]
-            it = job["items"][k % len(job["items"])]
+            oname, it = job["cpu_items"][k % len(job["cpu_items"])]
             x = job["host"][k % job["host"].shape[0]].astype(np.complex128)
             t1 = time.perf_counter()
-            acq_oracle.search_script_blocks(sig.name, x, it, job["ds"], job["B"])
+            acq_oracle.search_script_blocks(oname, x, it, job["ds"], job["B"])
             t_job[ji] += time.perf_counter() - t1
             c_job[ji] += len(job["dop"]) * sig.nfft
             n_job[ji] += 1
@@ -139,13 +143,13 @@ def cpu_baseline(jobs, budget_s=14.0):
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    cells_epoch = [len(j["items"]) * len(j["dop"]) * j["sig"].nfft for j in jobs]
+    cells_epoch = [j["P"] * len(j["dop"]) * j["sig"].nfft for j in jobs]
     t_epoch = sum(c / (cj / tj) for c, cj, tj in zip(cells_epoch, c_job, t_job))
     return {"value": sum(cells_epoch) / t_epoch, "unit": "cells/s", "cores": 1, "kind": "port",
-            "per_signal_cells_per_s": {j["sig"].name: cj / tj for j, cj, tj in zip(jobs, c_job, t_job)},
+            "per_signal_cells_per_s": {j["label"]: cj / tj for j, cj, tj in zip(jobs, c_job, t_job)},
             "sample": "%s, numpy/scipy fp64 oracle in the reference's loop order (per-item forward FFTs), %.1f s on 1 of %d "
                       "cores; whole-workload rate = cells per epoch / sum over signals of (cells / measured rate)"
-                      % (", ".join("%d item search(es) of %s (%d Doppler bins x %d lags x B=%d)" % (n, j["sig"].name, len(j["dop"]), j["sig"].nfft, j["B"])
+                      % (", ".join("%d item search(es) of %s (%d Doppler bins x %d lags x B=%d)" % (n, j["label"], len(j["dop"]), j["sig"].nfft, j["B"])
                                    for j, n in zip(jobs, n_job)), dt, os.cpu_count())}
 
 
@@ -182,7 +186,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json config (2 = the headline metric)")
-    ap.add_argument("--epochs", type=int, default=0, help="epochs per GPU per step (default: 256 / 2 / 1 for config 2 / 4 / 5)")
+    ap.add_argument("--epochs", type=int, default=0, help="epochs per GPU per step (default: 256 / 2 / 2 / 1 for config 2 / 3 / 4 / 5)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: N x EPOCHS epochs per step; strong: EPOCHS epochs per step whatever N is")
     ap.add_argument("--engine", type=int, default=0, help="0 auto, 1 rocFFT pipeline, 2 LDS FFT kernels, 3/4 split engines")
@@ -220,19 +224,23 @@ def main():
     # ---- workload: one job per signal, samples resident in HBM ------------------------------------------------------
     jobs = []
     for name, items, ds, ms in cfg["jobs"]:
-        sig = signals.get(name)
+        family = name if isinstance(name, tuple) else None           # signals that share everything but their code tables
+        sig = signals.get(family[0] if family else name)
         B = ms[1] if isinstance(ms, tuple) else sig.blocks(ms)
         dop = acquire.doppler_grid(ds)
-        sats = synth.default_sats(items)
+        cpu_items = [(n, it) for n, lst in zip(family, items) for it in lst] if family else [(sig.name, it) for it in items]
+        flat = [it for lst in items for it in lst] if family else list(items)
+        sats = synth.default_sats(items[0] if family else items)     # family: satellites of the first signal (first rows of the stack)
         nsamp = sig.samples_needed(B)
         # a few distinct seeded epochs tiled to the batch (content does not change the work)
         base = synth.make_epochs(sig, B, synth.BASE_SEED + cfg["seed"] + 100 * len(jobs), sats, min(8 if sig.nfft <= 4096 else 2, E_total), nsamp=nsamp)
         xs = np.concatenate([base] * ((E_total + len(base) - 1) // len(base)))[:E_total]
-        jobs.append({"sig": sig, "name": sig, "items": items, "ds": ds, "ms": ms, "B": B, "dop": dop, "dopplers": dop, "blocks": B,
-                     "sats": sats, "host": base, "xs": xs, "x": torch.from_numpy(np.ascontiguousarray(xs)).to(dev),
-                     "F": len(items) if sig.bias_hz else 1, "kind": engine_kind(sig.nfft)})
-    cells_step = sum(E_total * len(j["items"]) * len(j["dop"]) * j["sig"].nfft for j in jobs)
-    cell_blocks_step = sum(E_total * len(j["items"]) * len(j["dop"]) * j["sig"].nfft * j["B"] for j in jobs)
+        jobs.append({"sig": sig, "name": sig, "family": family, "items": items, "flat": flat, "P": len(flat), "cpu_items": cpu_items, "ds": ds, "ms": ms,
+                     "B": B, "dop": dop, "dopplers": dop, "blocks": B, "sats": sats, "host": base, "xs": xs,
+                     "x": torch.from_numpy(np.ascontiguousarray(xs)).to(dev), "F": len(flat) if sig.bias_hz else 1, "kind": engine_kind(sig.nfft),
+                     "label": "+".join(family) if family else sig.name})
+    cells_step = sum(E_total * j["P"] * len(j["dop"]) * j["sig"].nfft for j in jobs)
+    cell_blocks_step = sum(E_total * j["P"] * len(j["dop"]) * j["sig"].nfft * j["B"] for j in jobs)
 
     def make_engine():
         e = acquire.Engine(local_rank, engine=args.engine)
@@ -346,11 +354,11 @@ def main():
     # (b) the strong injected satellites sit at their delays in epoch 0 (padded searches see two code periods: n-d or 2n-d)
     if not args.no_self_check:
         for job, m in zip(jobs, merged):
-            pk = m[:1].cpu().numpy().view(acquire.PEAK_DTYPE).reshape(len(job["items"]))
+            pk = m[:1].cpu().numpy().view(acquire.PEAK_DTYPE).reshape(job["P"])
             n = job["sig"].n
             for it, amp, f, delay in job["sats"]:
                 if amp >= 0.25:
-                    got = int(pk["idx"][job["items"].index(it)])
+                    got = int(pk["idx"][job["flat"].index(it)])
                     assert got % n == (-delay) % n, ("bench self-check failed", job["sig"].name, it, got, delay)
 
     # ---- per-kernel durations: HIP events on the launch stream, separate profiled pass, one job at a time -------------
@@ -376,7 +384,7 @@ def main():
             pend.wait()
         torch.cuda.synchronize(dev)
         stages = eng0.stage_times()
-        N, P, B, F = job["sig"].nfft, len(job["items"]), job["B"], job["F"]
+        N, P, B, F = job["sig"].nfft, job["P"], job["B"], job["F"]
         fused16k = job["kind"] == "lds" and N == 16384 and F == P
         st_out = {}
         for sname, (tot_ms, nl) in stages.items():
@@ -385,7 +393,7 @@ def main():
             bound, work = stage_model(job["kind"], sname, N, P, D_local, B, F, E_total, fused16k)
             st_out[sname] = {"avg_ms": tot_ms / nl, "launches_per_step": nl / prof_steps, "ms_per_step": tot_ms / prof_steps,
                              "bound": bound, "work_per_step": work}
-        per_job.append({"signal": job["sig"].name, "engine": job["kind"], "P": P, "D_local": D_local, "B": B, "N": N, "F": F, "stages": st_out})
+        per_job.append({"signal": job["label"], "engine": job["kind"], "P": P, "D_local": D_local, "B": B, "N": N, "F": F, "stages": st_out})
     eng0.set_profiling(False)
 
     # dominant kernel = the (signal, stage) with the most time per step
@@ -428,7 +436,7 @@ def main():
             pass
     # the SURVEY 8d stage-boundary figure, kept as a secondary number: how a perfect HBM-bound five-stage pipeline would
     # have to perform to match the measured step (it exceeds the HBM peak for the fused engines, i.e. it is not a fraction)
-    a_pipe_step = sum(a_pipe_bytes(j["sig"].nfft, len(j["items"]), len(j["dop"]), j["B"], j["F"]) for j in jobs) * E_total
+    a_pipe_step = sum(a_pipe_bytes(j["sig"].nfft, j["P"], len(j["dop"]), j["B"], j["F"]) for j in jobs) * E_total
     roofline["pipeline_equivalent"] = {"a_pipe_bytes_per_step": a_pipe_step, "GBps": a_pipe_step / (dt / args.steps) / 1e9,
                                        "times_hbm_peak": a_pipe_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS}
     if use_dist:
@@ -477,7 +485,7 @@ def main():
                                                       "epochs_per_batch": E_total, "h2d_bytes_per_batch": int(xs.nbytes)}
 
     if rank == 0:
-        names = "+".join(j["sig"].name for j in jobs)
+        names = "+".join(j["label"] for j in jobs)
         if world == 1 and not exchanged:
             sharding = "none: single rank, whole Doppler grid, no exchange"
         else:
@@ -498,8 +506,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE config %d: %s; %d epoch(s)/step%s batched, inputs resident in HBM"
                                    % (args.config, cfg["label"], epochs, "/GPU" if args.scaling == "weak" else " in total"),
-                       "baseline_config": args.config, "signals": [j["sig"].name for j in jobs],
-                       "items": [len(j["items"]) for j in jobs], "doppler_bins": [len(j["dop"]) for j in jobs],
+                       "baseline_config": args.config, "signals": [j["label"] for j in jobs],
+                       "items": [j["P"] for j in jobs], "doppler_bins": [len(j["dop"]) for j in jobs],
                        "lags": [j["sig"].nfft for j in jobs], "blocks": [j["B"] for j in jobs], "epochs_per_step": E_total,
                        "cells_per_step": cells_step, "cell_blocks_per_step": cell_blocks_step, "sharding": sharding,
                        "shards_seen_by_every_rank": shards_seen,
@@ -509,7 +517,7 @@ def main():
             "sustained": sustained,
             "roofline": roofline,
             "host_call_latency": latency,
-            "pipeline": {"a_min_bytes_per_step": sum(a_min_bytes(j["sig"].nfft, len(j["items"]), j["B"], j["xs"].shape[1]) for j in jobs) * E_total,
+            "pipeline": {"a_min_bytes_per_step": sum(a_min_bytes(j["sig"].nfft, j["P"], j["B"], j["xs"].shape[1]) for j in jobs) * E_total,
                          "us_per_search": dt / args.steps / E_total * 1e6, "cell_blocks_per_s": cell_blocks_step * args.steps / dt,
                          "per_signal": per_job},
         }

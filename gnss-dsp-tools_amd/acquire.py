@@ -241,16 +241,15 @@ class Engine:
             bias.ctypes.data_as(nat.c_double_p) if bias is not None else None, blocks, res), self._ctx)
         return [_as_tuple(r) for r in res]
 
-    def search_family(self, names, x, items, doppler_search, ms):
-        """Signals that differ only in their code tables -- E1B + E1C, L5I + L5Q, E5aI + E5aQ, L1Cd + L1Cp ... -- searched
-        in ONE pass over x: the mix and the forward transforms are shared by all of them (BASELINE config 3 counts them
-        once), only the correlation rows multiply.  `items` is a list of item lists, one per name.  Returns one result list
-        per name, each identical to search_all(name, x, items_k, doppler_search, ms)."""
+    def _family(self, names, items, ms=None):
+        """(base descriptor, stacked AcqSignal or None, per-signal item lists) for signals that differ only in their code
+        tables; the stacked signal holds one row per (signal, item) in order and is cached."""
         sigs = [_signals.get(n) if isinstance(n, str) else n for n in names]
         if len(sigs) != len(items) or not sigs:
             raise ValueError("search_family: one item list per signal name")
         base = sigs[0]
-        shape = lambda g: (g.fs, g.n, g.pad, g.boc, g.normalised, g.fold, g.bias_hz, g.blocks(int(ms)), nat.check(nat.lib.gacq_code_length(g.code.encode())))
+        shape = lambda g: (g.fs, g.n, g.pad, g.boc, g.normalised, g.fold, g.bias_hz, None if ms is None else g.blocks(int(ms)),
+                           nat.check(nat.lib.gacq_code_length(g.code.encode())))
         for g in sigs[1:]:
             if shape(g) != shape(base):
                 raise ValueError("search_family: %s and %s differ in more than their code tables" % (base.name, g.name))
@@ -258,14 +257,19 @@ class Engine:
             raise ValueError("search_family: FDMA signals share one code; use search_all")
         lists = [[int(i) for i in it] for it in items]
         key = (tuple(g.name for g in sigs), tuple(tuple(it) for it in lists))
-        fam = self._families.get(key)
-        if fam is None:
+        if key not in self._families:
             rows = [codes.chips(g.code, p) for g, it in zip(sigs, lists) for p in it]
-            total = len(rows)
-            fam = AcqSignal(self, base, list(range(total)), np.stack(rows).astype(np.uint8)) if total else None
-            self._families[key] = fam
+            self._families[key] = AcqSignal(self, base, list(range(len(rows))), np.stack(rows).astype(np.uint8)) if rows else None
+        return base, self._families[key], lists
+
+    def search_family(self, names, x, items, doppler_search, ms):
+        """Signals that differ only in their code tables -- E1B + E1C, L5I + L5Q, E5aI + E5aQ, L1Cd + L1Cp ... -- searched
+        in ONE pass over x: the mix and the forward transforms are shared by all of them (BASELINE config 3 counts them
+        once), only the correlation rows multiply.  `items` is a list of item lists, one per name.  Returns one result list
+        per name, each identical to search_all(name, x, items_k, doppler_search, ms)."""
+        base, fam, lists = self._family(names, items, ms)
         if fam is None:
-            return [[] for _ in sigs]
+            return [[] for _ in lists]
         total = len(fam.prns)
         dopplers = doppler_grid(doppler_search)
         blocks = max(base.blocks(int(ms)), 0)
@@ -285,6 +289,15 @@ class Engine:
             at += len(it)
         return out
 
+    def search_family_batch_dev(self, names, x_dev, items, dopplers, blocks, out=None):
+        """Device-resident, batched form of search_family: x_dev [nepoch, nsamp] complex64 on the GPU -> peaks tensor
+        [nepoch, sum(len(items_k)), 2] (gacq_peak records, signals concatenated in order).  Asynchronous."""
+        import torch
+        base, fam, lists = self._family(names, items)
+        if fam is None:
+            return torch.empty((x_dev.shape[0], 0, 2), dtype=torch.float64, device=x_dev.device)
+        return self.search_batch_dev(fam.sig, x_dev, fam.prns, dopplers, blocks, out=out, _signal=fam)
+
     def debug_row(self, name, x, item, doppler, blocks):
         """Accumulated magnitude row q[0:N] of one (item, doppler) via the rocFFT pipeline."""
         sig = _signals.get(name) if isinstance(name, str) else name
@@ -300,7 +313,7 @@ class Engine:
         return q
 
     # -- device-resident batched form (bench / sharded path) --------------------------------------
-    def search_batch_dev(self, name, x_dev, items, dopplers, blocks, out=None):
+    def search_batch_dev(self, name, x_dev, items, dopplers, blocks, out=None, _signal=None):
         """x_dev: torch complex64 CUDA tensor [nepoch, nsamp]; returns a torch tensor [nepoch, nitems, 2]
         of float64 whose 16-byte rows are gacq_peak records (view with PEAK_DTYPE on the host).
         Asynchronous on the engine's stream."""
@@ -310,7 +323,10 @@ class Engine:
             raise ValueError("x_dev must be a contiguous 2-D complex64 CUDA tensor")
         if len(items) == 0:
             return torch.empty((x_dev.shape[0], 0, 2), dtype=torch.float64, device=x_dev.device)
-        s, idx, bias = self._plan(sig, items)
+        if _signal is not None:                # a stacked family signal: items are its row numbers
+            s, idx, bias = _signal, np.array([_signal._index[i] for i in items], dtype=np.int32), None
+        else:
+            s, idx, bias = self._plan(sig, items)
         dopplers = np.ascontiguousarray(dopplers, dtype=np.float64)
         nepoch, nsamp = x_dev.shape
         if out is None:

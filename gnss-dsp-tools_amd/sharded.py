@@ -123,6 +123,11 @@ class ShardedSearch:
             lo, hi = b[self.rank], b[self.rank + 1]
             if self.local_fn is not None:
                 loc = self.local_fn(job["name"], job["x"], job["items"], dop[lo:hi], job["blocks"])
+            elif job.get("family"):
+                # several signals sharing everything but their code tables (E1B + E1C): `family` = signal names, `items` = one
+                # item list per signal; one stacked signal, forward transforms shared
+                self.engine.use_torch_stream(job["x"].device)
+                loc = self.engine.search_family_batch_dev(job["family"], job["x"], job["items"], dop[lo:hi], job["blocks"])
             else:
                 self.engine.use_torch_stream(job["x"].device)
                 loc = self.engine.search_batch_dev(job["name"], job["x"], job["items"], dop[lo:hi], job["blocks"])

@@ -239,6 +239,17 @@ def test_search_family_shares_forward_transforms_and_equals_separate_searches(en
         assert got == want, name
     again = engine.search_family(names, x, items, ds, ms)            # cached family signal
     assert again == fam
+    # device-resident batched form (what bench.py --config 3 and sharded family jobs run): same records
+    import torch
+    from gnss_dsp_tools_amd import acquire
+    dop = acquire.doppler_grid(ds)
+    xd = torch.from_numpy(np.stack([x[:sig.samples_needed(B)]] * 2)).cuda()
+    pk = engine.search_family_batch_dev(names, xd, items, dop, B)
+    torch.cuda.synchronize()
+    pk = pk.cpu().numpy().view(acquire.PEAK_DTYPE).reshape(2, -1)
+    flat = [r for f in fam for r in f]
+    for e in range(2):
+        assert acquire.finalize(sig, list(range(len(flat))), pk[e], dop) == flat
     with pytest.raises(ValueError):
         engine.search_family(("gps-l1", "gps-l5i"), x, ([1], [1]), ds, 1)
 
@@ -460,7 +471,7 @@ def test_full_size_properties_configs_3_4_5(engine, name, items, ds, ms):
             assert auto["idx"][items.index(it)] % n == (n - delay % n) % n, (it, delay)
 
 
-@pytest.mark.parametrize("config,extra", [(2, ["--epochs", "8"]), (4, ["--epochs", "1"]), (5, ["--epochs", "1"])])
+@pytest.mark.parametrize("config,extra", [(2, ["--epochs", "8"]), (3, ["--epochs", "1"]), (4, ["--epochs", "1"]), (5, ["--epochs", "1"])])
 def test_bench_under_torchrun_single_rank_exercises_rccl_path(config, extra):
     """The driver launches N>1 through torch.distributed.run; with one GPU the same launcher + --force-gather still
     exercises RCCL init, the single all-gather of every signal's peak records on the engine's stream, the device-side
