@@ -79,7 +79,7 @@ def engine_kind(N):
     return "split_lds"               # outer DFT-R + 4096-point LDS inner transforms, one Z' round trip through HBM
 
 
-def stage_model(kind, stage, N, P, D, B, F, E, fused16k):
+def stage_model(kind, stage, N, P, D, B, F, E, fused16k, fused4k=False):
     """What bounds a launch of `stage` and its algorithmic work for E epochs of one job:
     ("valu", useful FP32 flop) for the LDS-resident transform kernels, ("hbm", bytes) for the kernels on either side of the
     split engines' one unavoidable round trip (inner IFFT rows Z' written once, read once: 8*N bytes each way per
@@ -92,7 +92,9 @@ def stage_model(kind, stage, N, P, D, B, F, E, fused16k):
             per_row = fft + 6.0 * N + 4.0 * N                 # inverse FFT + C*X + |.|
             if fused16k:
                 per_row += fft + 6.0 * N                      # + mix + forward FFT in the same kernel
-            return "valu", rows * per_row
+            # fused 4096 kernel: ONE forward transform per (epoch, Doppler bin) is useful work; the copies the other item
+            # chunks of the same unit recompute are overhead and do not count
+            return "valu", rows * per_row + (frows * (fft + 6.0 * N) if fused4k else 0.0)
         if stage == "mix_nco":
             return "valu", frows * (fft + 6.0 * N)
     else:
@@ -386,14 +388,16 @@ def main():
         stages = eng0.stage_times()
         N, P, B, F = job["sig"].nfft, job["P"], job["B"], job["F"]
         fused16k = job["kind"] == "lds" and N == 16384 and F == P
+        fused4k = job["kind"] == "lds" and N == 4096 and not stages["mix_nco"][1] and stages["lds_correlate"][1] > 0
         st_out = {}
         for sname, (tot_ms, nl) in stages.items():
             if not nl:
                 continue
-            bound, work = stage_model(job["kind"], sname, N, P, D_local, B, F, E_total, fused16k)
+            bound, work = stage_model(job["kind"], sname, N, P, D_local, B, F, E_total, fused16k, fused4k)
             st_out[sname] = {"avg_ms": tot_ms / nl, "launches_per_step": nl / prof_steps, "ms_per_step": tot_ms / prof_steps,
                              "bound": bound, "work_per_step": work}
-        per_job.append({"signal": job["label"], "engine": job["kind"], "P": P, "D_local": D_local, "B": B, "N": N, "F": F, "stages": st_out})
+        per_job.append({"signal": job["label"], "engine": job["kind"], "P": P, "D_local": D_local, "B": B, "N": N, "F": F, "stages": st_out,
+                        "fused_forward": bool(fused16k or fused4k)})
     eng0.set_profiling(False)
 
     # dominant kernel = the (signal, stage) with the most time per step
@@ -407,6 +411,9 @@ def main():
                    ("split31", "mag_peak"): "split_outer_inverse_kernel<31>", ("split_lds", "mag_peak"): "split_outer_inverse_kernel",
                    ("split31", "mix_nco"): "split_outer_forward_kernel<31> + rocFFT inner", ("split_lds", "mix_nco"): "split_outer_forward_kernel + lds_inner_forward_kernel"}
     kname = kernel_name.get((dj["engine"], dstage, dj["N"])) or kernel_name.get((dj["engine"], dstage)) or dstage
+    if dj["engine"] == "lds" and dstage == "lds_correlate":
+        kname = {(4096, True): "lds_fused4k_kernel", (4096, False): "lds_correlate_kernel", (16384, True): "lds16k_fused_kernel",
+                 (16384, False): "lds16k_correlate_kernel"}[(dj["N"], dj["fused_forward"])]
     if dk["bound"] == "valu":
         achieved = work_launch / (dk["avg_ms"] * 1e-3) / 1e12
         roofline = {"bound": "valu", "kernel": kname, "signal": dj["signal"], "achieved": achieved, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
