@@ -38,7 +38,7 @@ S = 8                           # bytes per complex64
 # name, items, doppler_search, ms (int) or ("B", blocks) for an engine-level block count
 CONFIGS = {
     2: {"label": "GPS L1 C/A all 32 PRNs, 1 ms coherent (B=1), fs=4.096 MS/s, n=N=4096, Doppler arange(-5000,5000,250)=40 bins",
-        "epochs": 256, "seed": 2,
+        "epochs": 1024, "seed": 2,
         "jobs": [("gps-l1", list(range(1, 33)), [-5000.0, 5000.0, 250.0], 1)]},
     3: {"label": "Galileo E1B + E1C as one family (forward transforms shared), PRN 1-36 each, BOC(1,1), 4092-chip memory codes, fs=8.192 MS/s, "
                  "n=32768, N=65536 (padded), ms=8 (B=1), Doppler arange(-4000,4000,125)=64 bins",
@@ -188,7 +188,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json config (2 = the headline metric)")
-    ap.add_argument("--epochs", type=int, default=0, help="epochs per GPU per step (default: 256 / 2 / 2 / 1 for config 2 / 3 / 4 / 5)")
+    ap.add_argument("--epochs", type=int, default=0, help="epochs per GPU per step (default: 1024 / 2 / 2 / 1 for config 2 / 3 / 4 / 5)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: N x EPOCHS epochs per step; strong: EPOCHS epochs per step whatever N is")
     ap.add_argument("--engine", type=int, default=0, help="0 auto, 1 rocFFT pipeline, 2 LDS FFT kernels, 3/4 split engines")
