@@ -161,3 +161,32 @@ int main(void) {
     assert run.returncode == 0, run.stderr[-2000:]
     chips, rc, null = run.stdout.split()
     assert chips == "1100100000" and int(rc) < 0 and null == "1"
+
+
+def test_new_entry_points_fail_loudly_without_crashing():
+    """Round-2 entry points: NULL handles come back as GACQ_ERR_BAD_ARG, a device group cannot be created without a GPU
+    (GACQ_ERR_NO_DEVICE, like gacq_create), option numbers are checked -- all without touching a device."""
+    lib = nat.lib
+    res = (nat.Result * 2)()
+    x = np.zeros(8, dtype=np.complex64)
+    items = np.zeros(2, dtype=np.int32)
+    dop = np.array([0.0, 250.0])
+    args = (x.ctypes.data_as(nat.c_float_p), 4, 1, items.ctypes.data_as(nat.c_int_p), 2, dop.ctypes.data_as(nat.c_double_p), 2, None, 1, res)
+    assert lib.gacq_search_batch(None, *args) == -1
+    assert lib.gacq_group_search_batch(None, *args) == -1
+    assert lib.gacq_group_size(None) == -1 and lib.gacq_group_member(None, 0) is None
+    h = ctypes.c_void_p()
+    assert lib.gacq_group_create(None, 1, ctypes.byref(h)) == -1
+    ids = (ctypes.c_int * 2)(0, 1)
+    if lib.gacq_device_count() == 0:
+        assert lib.gacq_group_create(ids, 2, ctypes.byref(h)) == -7 and not h.value
+        with pytest.raises(nat.GacqError):
+            acquire.DeviceGroup([0])
+    assert lib.gacq_set_option(None, 0, 1) == -1 and lib.gacq_get_option(None, 0, None) == -1
+    assert lib.gacq_debug_nco_indices(None, 1, 0.0, 0.0, None) == -1
+    assert lib.gacq_longcode_search_int8(None, None, 0, 1.0, 0.0, b"gps.l2cl", 1, 0.0, None, 1, 1, 1, None) == -1
+    assert set(nat.OPTIONS.values()) == set(range(len(nat.OPTIONS)))          # GACQ_OPT_* numbering is dense
+    hdr = open(os.path.join(ROOT, "include", "gacq.h")).read()
+    for name, num in nat.OPTIONS.items():
+        assert re.search(r"#define GACQ_OPT_%s %d\b" % (name.upper(), num), hdr), name
+    assert re.search(r"#define GACQ_NOPTS %d\b" % len(nat.OPTIONS), hdr)

@@ -144,6 +144,15 @@ def main():
     fs, coff, ms = 10.0e6, 250000.0, 8
     iq = recording_by_delay(fs, coff, ms, [("galileo.e1b", 11, 1023000.0, 4092, 8.0, 1537.0, 0.00121, True)], SEED + 97)
     write_case("galileo-e1b", "cli_galileo_e1b_int8.iq", iq, fs, coff, ["--prn", "10-11", "--doppler-search", "1000,2000,50", "--time", str(ms)])
+    # BeiDou B1I: padded search, raw metric, folded code phase; 2046-chip code at 2.046 Mcps, front-end to 8.192 MS/s
+    fs, coff, ms = 12.0e6, -400000.0, 3
+    iq = recording_by_delay(fs, coff, ms, [("beidou.b1i", 6, 2046000.0, 2046, 8.0, 1537.0, 0.000412, False),
+                                           ("beidou.b1i", 33, 2046000.0, 2046, 6.0, -409.0, 0.00077, False)], SEED + 96)
+    write_case("beidou-b1i", "cli_beidou_b1i_int8.iq", iq, fs, coff, ["--prn", "5-7,33", "--doppler-search", "-2000,2000,250", "--time", str(ms)])
+    # GPS L5I: the 10.23 Mcps family (N = 61380 split engine), internal rate 30.69 MS/s from a 40 MS/s recording
+    fs, coff, ms = 40.0e6, 1250000.0, 1
+    iq = recording_by_delay(fs, coff, ms, [("gps.l5i", 7, 10230000.0, 10230, 9.0, 1537.0, 0.000293, False)], SEED + 95)
+    write_case("gps-l5i", "cli_gps_l5i_int8.iq", iq, fs, coff, ["--prn", "6-8", "--doppler-search", "1000,2000,200", "--time", str(ms)])
     # long-code scripts: FILE FS COFFSET ITEM DOPPLER CODE_PHASE
     fs, coff, ms = 4092000.0, -127126.0, 40
     iq = recording_by_start_chips(fs, coff, ms, "gps.l2cl", 30, 511500.0, 767250, 3.0, 1618.0, 10230.0 * 42 + 8317.2, SEED + 601)
