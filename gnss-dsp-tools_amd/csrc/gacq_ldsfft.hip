@@ -85,13 +85,16 @@ __device__ __forceinline__ void wave_first_max(const float (&m)[kR], unsigned ba
 
 // Length-4096 transform of the 16 values per lane. In: v[j] = x[t + 256 j]; out: v[rev16(k2)] = X[t + 256 k2].
 // wa = W_4096^t, wb = W_256^(t & 15) (forward values; conjugated here when INV).
-template <bool INV, bool PRE = false>
+// PRE: bit 0 = the pass-1 powers (W_4096^t)^k, bit 1 = the pass-2 powers (W_256^(t&15))^k come precomputed in *pa / *pb (already
+// conjugated for an inverse transform) instead of being rebuilt from wa / wb by 14 complex products per pass.
+template <bool INV, int PRE = 0>
 __device__ __forceinline__ void fft4096(v2 (&v)[kR], v2* lds, v2 wa, v2 wb, const v2 (*pa)[15] = nullptr, const v2 (*pb)[15] = nullptr,
                                         int t = -1) {
   if (t < 0) t = threadIdx.x;                       // lane index within the 256-lane group that owns this transform
-  if (INV && !PRE) { wa.y = -wa.y; wb.y = -wb.y; }
+  if (INV && !(PRE & 1)) wa.y = -wa.y;
+  if (INV && !(PRE & 2)) wb.y = -wb.y;
   dft16<INV>(v);
-  if (!(GACQ_ABL & 8)) { if (PRE) apply_table(v, *pa); else apply_powers(v, wa); }
+  if (!(GACQ_ABL & 8)) { if (PRE & 1) apply_table(v, *pa); else apply_powers(v, wa); }
   {  // exchange 1: (n0,n1;k0) -> (n0,k0;n1)
     const int wbase = (t & 15) + 256 * (t >> 4);
     if (!(GACQ_ABL & 1)) {
@@ -103,7 +106,7 @@ _Pragma("unroll") for (int j = 0; j < kR; j++) v[j] = lds[t + 256 * j];
     }
   }
   dft16<INV>(v);
-  if (!(GACQ_ABL & 8)) { if (PRE) apply_table(v, *pb); else apply_powers(v, wb); }
+  if (!(GACQ_ABL & 8)) { if (PRE & 2) apply_table(v, *pb); else apply_powers(v, wb); }
   if (!(GACQ_ABL & 2)) __syncthreads();   // all exchange-1 reads done before the buffer is reused
   {  // exchange 2: (n0,k0;k1) -> (k0,k1;n0)
     const int wbase = (t >> 4) + kPitch * (t & 15);
@@ -643,7 +646,7 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float
         for (int jj = 0; jj < kR; jj++) v[jj] = cmul(cc[jj], v[jj]);
       }
       if (!B1 && b > 0) __syncthreads();   // previous transform's exchange-2 reads are complete
-      if (PRETW) fft4096<true, true>(v, lds, wa, wb, reinterpret_cast<const v2(*)[15]>(pwa), reinterpret_cast<const v2(*)[15]>(pwb));
+      if (PRETW) fft4096<true, 3>(v, lds, wa, wb, reinterpret_cast<const v2(*)[15]>(pwa), reinterpret_cast<const v2(*)[15]>(pwb));
       else fft4096<true>(v, lds, wa, wb);
       if (B1) {
         // magnitudes straight from the transform output; lane holds lags t + 256 k.  The 1/N of ifft is a power of two: it is
@@ -697,7 +700,9 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float
 // workgroup instead of one per (epoch, Doppler bin), i.e. nchunk - 1 redundant ones per unit, which is why this kernel is
 // launched with larger item chunks (16-32) than the two-kernel path (8).  Same arithmetic in the same order as
 // lds_forward_kernel + lds_correlate_kernel: records are bit-identical (test_fused_4096_kernel_equals_two_kernel_path).
-template <int MINW>
+// PREA: keep the 15 pass-1 twiddle powers of the inverse transform in registers for the whole item loop (30 VGPRs, 14 complex
+// products per row less); the maximum-first peak search freed exactly that much of the 128-register budget of 4 waves per SIMD.
+template <int MINW, bool PREA>
 __global__ __launch_bounds__(kBlock, MINW) void lds_fused4k_kernel(const float2* __restrict__ x, size_t epoch_stride,
                                                                     const float2* __restrict__ C, const int* __restrict__ items,
                                                                     const double* __restrict__ freq, const float2* __restrict__ nco_tab,
@@ -738,15 +743,20 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_fused4k_kernel(const float2*
   }
   const float inv_n = 1.0f / (float)kLdsN;
   const unsigned lane_off = (unsigned)t * 16u;
+  v2 pwa[PREA ? 15 : 1];
+  if (PREA) make_powers(reinterpret_cast<v2(&)[15]>(pwa), v2{wa.x, -wa.y});      // conjugate: inverse transform
   for (int p = p0; p < p1; p++) {
     const __amdgpu_buffer_rsrc_t cres = row_rsrc(C + (long)items[p] * kLdsN);
-    asm volatile("" : "+v"(wa.x), "+v"(wa.y), "+v"(wb.x), "+v"(wb.y));      // keep the twiddle powers out of the loop-invariant set
+    // keep the (remaining) twiddle powers out of the loop-invariant set
+    if (PREA) asm volatile("" : "+v"(wb.x), "+v"(wb.y));
+    else asm volatile("" : "+v"(wa.x), "+v"(wa.y), "+v"(wb.x), "+v"(wb.y));
     v2 v[kR];
 #pragma unroll
     for (int jp = 0; jp < kR / 2; jp++) ld_pair(cres, lane_off, jp, v[2 * jp], v[2 * jp + 1]);
 #pragma unroll
     for (int jj = 0; jj < kR; jj++) v[jj] = cmul(v[jj], xr[jj]);
-    fft4096<true>(v, lds, wa, wb);
+    if (PREA) fft4096<true, 1>(v, lds, wa, wb, reinterpret_cast<const v2(*)[15]>(pwa), nullptr);
+    else fft4096<true>(v, lds, wa, wb);
     // lane t holds lags t + 256 k.  The 1/N of ifft is a power of two: applied once to the reduced values.
     float m[kR];
 #pragma unroll
@@ -877,8 +887,12 @@ int lds_fused4k_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch,
   pch = std::min(pch, nitems);
   const int nchunk = (nitems + pch - 1) / pch;
   const long units8 = (units + 7) / 8;
-  hipLaunchKernelGGL(lds_fused4k_kernel<2>, dim3((unsigned)(8 * units8 * nchunk)), dim3(kBlock), 0, ctx->stream, x, nsamp, spectra, d_items,
-                     d_freq, tab, tw, rows, nepoch, nitems, D, pch, nchunk);
+  if (ctx->opt[GACQ_OPT_LDS_VARIANT] == 100)
+    hipLaunchKernelGGL((lds_fused4k_kernel<4, false>), dim3((unsigned)(8 * units8 * nchunk)), dim3(kBlock), 0, ctx->stream, x, nsamp, spectra, d_items,
+                       d_freq, tab, tw, rows, nepoch, nitems, D, pch, nchunk);
+  else
+    hipLaunchKernelGGL((lds_fused4k_kernel<4, true>), dim3((unsigned)(8 * units8 * nchunk)), dim3(kBlock), 0, ctx->stream, x, nsamp, spectra, d_items,
+                       d_freq, tab, tw, rows, nepoch, nitems, D, pch, nchunk);
   GACQ_HIP(ctx, hipGetLastError());
   return GACQ_OK;
 }
