@@ -508,8 +508,16 @@ __global__ __launch_bounds__(kBlock, 4) void lds_inner_correlate_kernel(const fl
   v2 base = ld2(twn + k1 * t), step = ld2(twn + 256 * k1);
   base.y = -base.y;
   step.y = -step.y;
-  TwPow tp;
-  tp.init<15>(step);
+  // the 16 output twiddles of this lane depend on (k1, t) only: built once per workgroup (multiplication depth <= 5), one product
+  // per output afterwards instead of up to three (base, step^(k&3), step^(k&~3))
+  v2 tk[kR];
+  {
+    TwPow tp;
+    tp.init<15>(step);
+    tk[0] = base;
+#pragma unroll
+    for (int k = 1; k < kR; k++) tk[k] = tp.apply(base, k);
+  }
   const float2* have = nullptr;
   v2 xr[kR];
   for (int i = 0; i < pch; i++) {
@@ -537,7 +545,7 @@ __global__ __launch_bounds__(kBlock, 4) void lds_inner_correlate_kernel(const fl
     } else {
 #pragma unroll
       for (int k = 0; k < kR; k++) {
-        const v2 o = tp.apply(cmul(v[rev16(k)], base), k);
+        const v2 o = cmul(v[rev16(k)], tk[k]);
         dst[256 * k] = make_float2(o.x, o.y);
       }
     }
