@@ -129,16 +129,59 @@ template <bool INV, int M> __device__ __forceinline__ v2 w16() {
 // (base-4 digit reversal) -- callers index outputs through rev16().  64 + 16 packed instructions.
 __device__ __forceinline__ constexpr int rev16(int k) { return 4 * (k & 3) + (k >> 2); }
 
+// a -+ i*(h*b) with the real scale h = hh.lo = -hh.hi folded into one packed FMA (hh in an SGPR pair):
+//   sub_ih(a, b, hh) = (a.re + h b.im, a.im - h b.re)      add_ih(a, b, hh) = (a.re - h b.im, a.im + h b.re)
+__device__ __forceinline__ v2 sub_ih(v2 a, v2 b, v2 hh) {
+  v2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(b), "s"(hh), "v"(a));
+  return r;
+}
+__device__ __forceinline__ v2 add_ih(v2 a, v2 b, v2 hh) {
+  v2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(b), "s"(hh), "v"(a));
+  return r;
+}
+
+// The four W16^2 / W16^6 twiddles are (1 -+ i)/sqrt2 rotations: the rotation is one packed add with operand swaps, and its
+// 1/sqrt2 rides on the butterfly that consumes it as a packed FMA (fma_lo / fma_hi with hh = (h, -h)) -- 4 instructions per
+// 16-point transform less than multiplying them out (76 instead of 80).
 template <bool INV> __device__ __forceinline__ void dft16(v2 (&v)[16]) {
 #pragma unroll
   for (int n0 = 0; n0 < 4; n0++) dft4<INV, false>(v[n0], v[n0 + 4], v[n0 + 8], v[n0 + 12]);   // -> A[n0][k0] at v[n0+4k0]
-  v[5] = cmul_k(v[5], w16<INV, 1>());   v[9] = cmul_k(v[9], w16<INV, 2>());   v[13] = cmul_k(v[13], w16<INV, 3>());
-  v[6] = cmul_k(v[6], w16<INV, 2>());   /* v[10]: W16^4 folded into dft4<ROTC> */ v[14] = cmul_k(v[14], w16<INV, 6>());
-  v[7] = cmul_k(v[7], w16<INV, 3>());   v[11] = cmul_k(v[11], w16<INV, 6>()); v[15] = cmul_k(v[15], w16<INV, 9>());
+  const v2 hh = {0.70710678118654752f, -0.70710678118654752f};
+  v[5] = cmul_k(v[5], w16<INV, 1>());   v[13] = cmul_k(v[13], w16<INV, 3>());
+  v[7] = cmul_k(v[7], w16<INV, 3>());   v[15] = cmul_k(v[15], w16<INV, 9>());
+  // v6 W16^2 = h c1, v9 W16^2 = h b2, v11 W16^6 = -h d2, v14 W16^6 = -h c3   (forward W16^2 = h(1 - i), W16^6 = -h(1 + i); inverse: conjugates)
+  const v2 c1 = INV ? add_i(v[6], v[6]) : sub_i(v[6], v[6]);
+  const v2 b2 = INV ? add_i(v[9], v[9]) : sub_i(v[9], v[9]);
+  const v2 d2 = INV ? sub_i(v[11], v[11]) : add_i(v[11], v[11]);
+  const v2 c3 = INV ? sub_i(v[14], v[14]) : add_i(v[14], v[14]);
   dft4<INV, false>(v[0], v[1], v[2], v[3]);
-  dft4<INV, false>(v[4], v[5], v[6], v[7]);
-  dft4<INV, true>(v[8], v[9], v[10], v[11]);
-  dft4<INV, false>(v[12], v[13], v[14], v[15]);                                               // -> X[k0+4k1] at v[4k0+k1]
+  {  // row k0 = 1: a = v4, b = v5, c = h c1, d = v7
+    const v2 s0 = fma_lo(v[4], c1, hh), d0 = fma_hi(v[4], c1, hh);
+    const v2 s1 = v[5] + v[7], t = v[5] - v[7];
+    v[4] = s0 + s1;
+    v[6] = s0 - s1;
+    v[5] = INV ? add_i(d0, t) : sub_i(d0, t);
+    v[7] = INV ? sub_i(d0, t) : add_i(d0, t);
+  }
+  {  // row k0 = 2: a = v8, b = h b2, c = v10 with its -/+i (W16^4) folded into the adds, d = -h d2
+    const v2 s0 = INV ? add_i(v[8], v[10]) : sub_i(v[8], v[10]);
+    const v2 d0 = INV ? sub_i(v[8], v[10]) : add_i(v[8], v[10]);
+    const v2 s1 = b2 - d2, t = b2 + d2;                    // true values: h s1, h t
+    v[8] = fma_lo(s0, s1, hh);
+    v[10] = fma_hi(s0, s1, hh);
+    v[9] = INV ? add_ih(d0, t, hh) : sub_ih(d0, t, hh);
+    v[11] = INV ? sub_ih(d0, t, hh) : add_ih(d0, t, hh);
+  }
+  {  // row k0 = 3: a = v12, b = v13, c = -h c3, d = v15
+    const v2 s0 = fma_hi(v[12], c3, hh), d0 = fma_lo(v[12], c3, hh);
+    const v2 s1 = v[13] + v[15], t = v[13] - v[15];
+    v[12] = s0 + s1;
+    v[14] = s0 - s1;
+    v[13] = INV ? add_i(d0, t) : sub_i(d0, t);
+    v[15] = INV ? sub_i(d0, t) : add_i(d0, t);
+  }                                                                                           // -> X[k0+4k1] at v[4k0+k1]
 }
 
 // cos/sin(2 pi m / P) for the odd primes used as outer radices
