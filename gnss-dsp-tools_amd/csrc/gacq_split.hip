@@ -192,6 +192,26 @@ __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_i
   }
 }
 
+// Phase timing (diagnostic builds only, -DGACQ_PHASE_TIMING; tools/phase_timing.sh): thread 0 of every workgroup accumulates the
+// shader-clock cycles between marks and adds them to gacq_phase_cycles[] once at the end (read back with
+// gacq_debug_phase_cycles).  Never defined in the product build.
+#ifdef GACQ_PHASE_TIMING
+__device__ unsigned long long gacq_phase_cycles[32];
+struct PhaseAcc { unsigned long long t[16]; };
+#define GACQ_MARK(i)                                                                              \
+  do {                                                                                            \
+    const unsigned long long now_ = __builtin_readcyclecounter();                                 \
+    acc_.t[i] += now_ - mark_;                                                                    \
+    mark_ = now_;                                                                                 \
+  } while (0)
+#define GACQ_MARK_ARG , unsigned long long& mark_, PhaseAcc& acc_, int mark_base_
+#define GACQ_MARK_PASS(b) , mark_, acc_, b
+#else
+#define GACQ_MARK(i) do { } while (0)
+#define GACQ_MARK_ARG
+#define GACQ_MARK_PASS(b)
+#endif
+
 // ---- inner inverse transforms fused with the conj-multiply (engine 3, M = 1980 / 990) ---------------------------------
 // Z[ry][n2] = IFFT_M( C_p[k1][.] * conj(X[e,f,d,b][k1][.]) )[n2]  (unnormalised), one workgroup per (group, block, k1) row.
 // Stockham autosort in LDS (one buffer, see stockham_pass), mixed radices R0*R1*R2*R3 = M; the first pass reads the two spectra from global
@@ -215,7 +235,7 @@ __device__ __forceinline__ void fill_pass_twiddles(v2* __restrict__ twp, const f
 // 2 M complex of LDS (row + twiddles) so five of them fit a CU.  LAST writes the row to global memory instead.
 template <int R, bool LAST, int M, int NT>
 __device__ __forceinline__ void stockham_pass(v2* __restrict__ buf, float2* __restrict__ gz, const v2* __restrict__ twp, int Ns, int tid,
-                                              bool live) {
+                                              bool live GACQ_MARK_ARG) {
   constexpr int nb = M / R;
   constexpr int iters = (nb + NT - 1) / NT;
   v2 x[iters][R];
@@ -232,7 +252,9 @@ __device__ __forceinline__ void stockham_pass(v2* __restrict__ buf, float2* __re
       SmallDft<R, true>::run(x[it]);
     }
   }
+  GACQ_MARK(mark_base_);                           // LDS reads, twiddle products, R-point DFT
   if (!LAST) __syncthreads();                      // all inputs are in registers
+  GACQ_MARK(mark_base_ + 1);
 #pragma unroll
   for (int it = 0; it < iters; it++) {
     const int j = tid + it * NT;
@@ -261,8 +283,12 @@ __device__ __forceinline__ void stockham_pass(v2* __restrict__ buf, float2* __re
 //   M = 1980 = 11 * 12 * 15: 180, 165, 132 butterflies -> 192 threads;   M = 990 = 11 * 9 * 10: 90, 110, 99 -> 128 threads.
 // Three passes instead of four (11 * 9 * 5 * 4|2) mean one LDS exchange, one twiddle stage and two barriers less per row; the
 // composite radices 10, 12 and 15 are coprime products (PfaDft), so they cost no internal twiddles either.
-template <int R0, int R1, int R2, int R3, int NT, int TEAMS>
-__global__ __launch_bounds__(NT * TEAMS, ((TEAMS == 4 && R0 * R1 * R2 * R3 == 1980) ? 6 : 5)) void split_inner_corr_kernel(const float2* __restrict__ X, const float2* __restrict__ C,
+// DT consecutive Doppler bins per workgroup: the first-pass operands of DT rows X[e,f,d..d+DT-1,b][k1][.] stay in registers and
+// every code-spectrum row fetched for an item serves DT correlation rows.  Phase timing (profiles/r02_stockham_phase_timing*.log)
+// shows a row spending 44 % of its time waiting for the 16 KB of C it reads and 20 % issuing the 16 KB of Z' it writes -- the
+// CU's memory pipeline, not arithmetic or LDS, paces this kernel -- so halving the C traffic per row is what pays.
+template <int R0, int R1, int R2, int R3, int NT, int TEAMS, int DT>
+__global__ __launch_bounds__(NT * TEAMS, (DT == 1 ? 5 : (DT == 2 && R0 * R1 * R2 * R3 == 990 ? 4 : 3))) void split_inner_corr_kernel(const float2* __restrict__ X, const float2* __restrict__ C,
                                                                    float2* __restrict__ Z, const int* __restrict__ items,
                                                                    const int* __restrict__ fset, const float2* __restrict__ twm_g,
                                                                    long g0, long ng, long ep_first, int nblk_ep, int pch, int P, int F,
@@ -284,56 +310,85 @@ __global__ __launch_bounds__(NT * TEAMS, ((TEAMS == 4 && R0 * R1 * R2 * R3 == 19
   unsigned blk = blockIdx.x;                       // 32-bit index math: 64-bit divisions cost ~100 scalar ops each
   const int b = (int)(blk % (unsigned)B);
   blk /= (unsigned)B;
-  const int d = (int)(blk % (unsigned)D);
-  blk /= (unsigned)D;
+  const int DG = (D + DT - 1) / DT;                // Doppler groups
+  const int d0 = (int)(blk % (unsigned)DG) * DT;
+  blk /= (unsigned)DG;
   const unsigned epc = blk % (unsigned)nblk_ep;
   const int k1 = (int)(blk / (unsigned)nblk_ep);
   const bool act = j < nb0;
-  const float2* have = nullptr;
-  float2 xv[R0];
+  const float2* have[DT];
+  float2 xv[DT][R0];
+#pragma unroll
+  for (int dd = 0; dd < DT; dd++) have[dd] = nullptr;
   const unsigned ep0 = (unsigned)ep_first + epc * (unsigned)pch;       // E * P < 2^31 (checked by the launcher)
+#ifdef GACQ_PHASE_TIMING
+  PhaseAcc acc_;
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc_.t[i] = 0;
+  unsigned long long mark_ = __builtin_readcyclecounter();
+#endif
   for (int i0 = 0; i0 < pch; i0 += TEAMS) {
     const unsigned ep = ep0 + (unsigned)(i0 + team);
     const unsigned e = ep / (unsigned)P;
     const int p = (int)(ep - e * (unsigned)P);
-    const long g = (long)ep * D + d;
-    const bool live = (i0 + team < pch) && g >= g0 && g < g0 + ng;       // uniform over the team
-    const float2* gx = nullptr;
-    float2* gz = nullptr;
-    if (live) {
-      gx = X + (((((long)e * F + fset[p]) * D + d) * (long)B + b) * R + k1) * (long)M;
-      const float2* gc = C + ((long)items[p] * R + k1) * (long)M;
-      gz = Z + (((g - g0) * B + b) * R + k1) * (long)M;
-      if (act) {
-        float2 cv[R0];
+    const bool item_ok = i0 + team < pch;
+    float2 cv[R0];
+    bool have_c = false;
 #pragma unroll
-        for (int t = 0; t < R0; t++) cv[t] = gc[j + t * nb0];
-        if (gx != have) {
+    for (int dd = 0; dd < DT; dd++) {
+      const int d = d0 + dd;
+      const long g = (long)ep * D + d;
+      const bool live = item_ok && d < D && g >= g0 && g < g0 + ng;       // uniform over the team
+      float2* gz = nullptr;
+      if (live) {
+        const float2* gx = X + (((((long)e * F + fset[p]) * D + d) * (long)B + b) * R + k1) * (long)M;
+        gz = Z + (((g - g0) * B + b) * R + k1) * (long)M;
+        if (act) {
+          if (!have_c) {
+            const float2* gc = C + ((long)items[p] * R + k1) * (long)M;
 #pragma unroll
-          for (int t = 0; t < R0; t++) xv[t] = gx[j + t * nb0];
+            for (int t = 0; t < R0; t++) cv[t] = gc[j + t * nb0];
+          }
+          if (gx != have[dd]) {
+#pragma unroll
+            for (int t = 0; t < R0; t++) xv[dd][t] = gx[j + t * nb0];
+          }
+          v2 x[R0];
+#pragma unroll
+          for (int t = 0; t < R0; t++)
+            x[t] = v2{cv[t].x * xv[dd][t].x + cv[t].y * xv[dd][t].y, cv[t].y * xv[dd][t].x - cv[t].x * xv[dd][t].y};      // C * conj(X)   acquire-gps-l1.py:32
+          SmallDft<R0, true>::run(x);
+#pragma unroll
+          for (int t = 0; t < R0; t++) buf0[j * R0 + t] = x[t];                                             // Ns = 1: k = 0, no twiddles
         }
-        v2 x[R0];
-#pragma unroll
-        for (int t = 0; t < R0; t++)
-          x[t] = v2{cv[t].x * xv[t].x + cv[t].y * xv[t].y, cv[t].y * xv[t].x - cv[t].x * xv[t].y};      // C * conj(X)   acquire-gps-l1.py:32
-        SmallDft<R0, true>::run(x);
-#pragma unroll
-        for (int t = 0; t < R0; t++) buf0[j * R0 + t] = x[t];                                             // Ns = 1: k = 0, no twiddles
+        have_c = true;
+        have[dd] = gx;
       }
-      have = gx;
-    }
-    __syncthreads();
-    stockham_pass<R1, false, M, NT>(buf0, nullptr, tw1, R0, j, live);
-    __syncthreads();
-    if (R3 > 1) {
-      stockham_pass<R2, false, M, NT>(buf0, nullptr, tw2, R0 * R1, j, live);
+      GACQ_MARK(0);                                // (wait for C, X) C conj(X), DFT-R0, LDS writes
       __syncthreads();
-      stockham_pass<(R3 > 1 ? R3 : 2), true, M, NT>(buf0, gz, tw3, R0 * R1 * R2, j, live);
-    } else {
-      stockham_pass<R2, true, M, NT>(buf0, gz, tw2, R0 * R1, j, live);
+      GACQ_MARK(1);
+      stockham_pass<R1, false, M, NT>(buf0, nullptr, tw1, R0, j, live GACQ_MARK_PASS(2));
+      GACQ_MARK(4);                                // pass-2 outputs written to LDS
+      __syncthreads();
+      GACQ_MARK(5);
+      if (R3 > 1) {
+        stockham_pass<R2, false, M, NT>(buf0, nullptr, tw2, R0 * R1, j, live GACQ_MARK_PASS(10));
+        __syncthreads();
+        stockham_pass<(R3 > 1 ? R3 : 2), true, M, NT>(buf0, gz, tw3, R0 * R1 * R2, j, live GACQ_MARK_PASS(12));
+      } else {
+        stockham_pass<R2, true, M, NT>(buf0, gz, tw2, R0 * R1, j, live GACQ_MARK_PASS(6));
+      }
+      GACQ_MARK(8);                                // last pass: row stored to global memory
+      __syncthreads();                             // buf0 is rewritten by the next row's first pass
+      GACQ_MARK(9);
     }
-    __syncthreads();                               // buf0 is rewritten by the next item's first pass
   }
+#ifdef GACQ_PHASE_TIMING
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) if (acc_.t[i]) atomicAdd(&gacq_phase_cycles[i], acc_.t[i]);
+  }
+#endif
 }
 
 // partial[(g, chunk)] -> rows[g0 + g]
@@ -401,6 +456,17 @@ namespace gacq {
 
 bool split_inner_fused_supported(int N) { return N == 61380 || N == 30690; }
 
+#ifdef GACQ_PHASE_TIMING
+extern "C" int gacq_debug_phase_cycles(unsigned long long* out32, int reset) {
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(gacq_phase_cycles), sizeof(unsigned long long) * 32) != hipSuccess) return GACQ_ERR_HIP;
+  if (reset) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(gacq_phase_cycles), z, sizeof z) != hipSuccess) return GACQ_ERR_HIP;
+  }
+  return GACQ_OK;
+}
+#endif
+
 // K2 + inner inverse transforms in one kernel (no Y round trip); Z gets the unnormalised, untwiddled inner IFFTs
 int split_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* C, const int* d_items, const int* d_fset, long g0, long ng,
                           int P, int F, int D, int B, int N, float2* Z) {
@@ -418,7 +484,11 @@ int split_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* C, const
   if (teams != 1 && teams != 2 && teams != 4) return set_error(ctx, GACQ_ERR_BAD_ARG, "split engine: teams per workgroup must be 1, 2 or 4");
   pch = (pch + teams - 1) / teams * teams;
   const int nblk_ep = (int)((nep + pch - 1) / pch);
-  const dim3 grid((unsigned)((long)R * nblk_ep * D * B));
+  int dt = (teams == 1 && D >= 8) ? (M == 1980 ? 3 : 2) : 1;       // Doppler bins per workgroup (profiles/r02_stockham_doppler_tile_sweep.log)
+  if (ctx->opt[GACQ_OPT_SPLIT_DT] >= 1) dt = (int)ctx->opt[GACQ_OPT_SPLIT_DT];
+  if (dt < 1 || dt > 3) return set_error(ctx, GACQ_ERR_BAD_ARG, "split engine: Doppler bins per workgroup must be 1, 2 or 3");
+  const int DG = (D + dt - 1) / dt;
+  const dim3 grid((unsigned)((long)R * nblk_ep * DG * B));
   const size_t smem = sizeof(float2) * ((size_t)teams * M + (size_t)M);
 #define GACQ_LAUNCH_INNER(KERN, NT)                                                                                                 \
   do {                                                                                                                              \
@@ -426,17 +496,25 @@ int split_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* C, const
     hipLaunchKernelGGL(KERN, grid, dim3((NT) * teams), smem, ctx->stream, X, C, Z, d_items, d_fset, twm, g0, ng, ep_first, nblk_ep, pch, P, F, D, \
                        B, R);                                                                                                       \
   } while (0)
+#define GACQ_LAUNCH_DT(R1_, R2_, NT_, TEAMS_)                                                                                        \
+  do {                                                                                                                              \
+    if (dt == 3) GACQ_LAUNCH_INNER((split_inner_corr_kernel<11, R1_, R2_, 1, NT_, TEAMS_, 3>), NT_);                                \
+    else if (dt == 2) GACQ_LAUNCH_INNER((split_inner_corr_kernel<11, R1_, R2_, 1, NT_, TEAMS_, 2>), NT_);                           \
+    else GACQ_LAUNCH_INNER((split_inner_corr_kernel<11, R1_, R2_, 1, NT_, TEAMS_, 1>), NT_);                                        \
+  } while (0)
+  if (teams != 1 && dt != 1) return set_error(ctx, GACQ_ERR_BAD_ARG, "split engine: teams > 1 and Doppler tiles > 1 are not combined");
   if (M == 1980) {
-    if (teams == 4) GACQ_LAUNCH_INNER((split_inner_corr_kernel<11, 12, 15, 1, 192, 4>), 192);
-    else if (teams == 2) GACQ_LAUNCH_INNER((split_inner_corr_kernel<11, 12, 15, 1, 192, 2>), 192);
-    else GACQ_LAUNCH_INNER((split_inner_corr_kernel<11, 12, 15, 1, 192, 1>), 192);
+    if (teams == 4) GACQ_LAUNCH_INNER((split_inner_corr_kernel<11, 12, 15, 1, 192, 4, 1>), 192);
+    else if (teams == 2) GACQ_LAUNCH_INNER((split_inner_corr_kernel<11, 12, 15, 1, 192, 2, 1>), 192);
+    else GACQ_LAUNCH_DT(12, 15, 192, 1);
   } else if (M == 990) {
-    if (teams == 4) GACQ_LAUNCH_INNER((split_inner_corr_kernel<11, 9, 10, 1, 128, 4>), 128);
-    else if (teams == 2) GACQ_LAUNCH_INNER((split_inner_corr_kernel<11, 9, 10, 1, 128, 2>), 128);
-    else GACQ_LAUNCH_INNER((split_inner_corr_kernel<11, 9, 10, 1, 128, 1>), 128);
+    if (teams == 4) GACQ_LAUNCH_INNER((split_inner_corr_kernel<11, 9, 10, 1, 128, 4, 1>), 128);
+    else if (teams == 2) GACQ_LAUNCH_INNER((split_inner_corr_kernel<11, 9, 10, 1, 128, 2, 1>), 128);
+    else GACQ_LAUNCH_DT(9, 10, 128, 1);
   } else {
     return set_error(ctx, GACQ_ERR_UNSUPPORTED, "fused inner transforms: M=%d not supported", M);
   }
+#undef GACQ_LAUNCH_DT
 #undef GACQ_LAUNCH_INNER
   GACQ_HIP(ctx, hipGetLastError());
   return GACQ_OK;

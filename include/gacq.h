@@ -114,7 +114,9 @@ int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes);
 #define GACQ_OPT_SPLIT_TEAMS 5  /* [0 = auto] rows (teams of waves) per workgroup of the Stockham inner kernel: 1, 2 or 4  */
 #define GACQ_OPT_FUSED_4K 6     /* [1] N = 4096, B = 1, one carrier, >= 1024 (epoch, Doppler) units: forward + correlate in  */
                                 /*     one kernel (no forward-spectra buffer); 2 = also for small batches                    */
-#define GACQ_NOPTS 7
+#define GACQ_OPT_SPLIT_DT 7      /* [0 = auto] Doppler bins per workgroup of the Stockham inner kernel (1, 2 or 3): every      */
+                                /*     code-spectrum row fetched serves that many correlation rows                           */
+#define GACQ_NOPTS 8
 int gacq_set_option(gacq_ctx* ctx, int option, long value);
 int gacq_get_option(gacq_ctx* ctx, int option, long* value);
 
