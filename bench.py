@@ -182,6 +182,48 @@ def cpu_baseline_pool(job, reps=60):
                       "acquire-gps-l1.py:105-108), %.2f s" % (reps, min(cores, len(items)), len(items), dt)}
 
 
+def pmc_passes(argv, kernel, passes, timeout_s=240):
+    """Hardware counters of `kernel` for this very command line, collected live: one `rocprofv3 --pmc` child run of bench.py per
+    counter group (counter passes are never combined with tracing; FETCH_SIZE and WRITE_SIZE need separate passes --
+    MI355X_MICROARCH.md, HBM / rocprofv3 section).  Returns {counter: average per launch of the kernels whose name contains
+    `kernel`} plus the launch count; raises on any failure so that the caller can fall back and say so."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        raise RuntimeError("rocprofv3 not found")
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="gacq_pmc_", dir="/tmp")
+    try:
+        for counters in passes:
+            d = os.path.join(tmp, counters[0])
+            cmd = [exe, "--pmc"] + counters + ["--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__)] + argv
+            env = dict(os.environ, TMPDIR="/tmp", GACQ_BENCH_PMC_CHILD="1")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+                env.pop(k, None)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            if r.returncode != 0:
+                raise RuntimeError("rocprofv3 --pmc %s: rc %d: %s" % (counters[0], r.returncode, (r.stderr or r.stdout)[-300:]))
+            per = {}
+            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(path)):
+                    if kernel in row["Kernel_Name"]:
+                        key = (row["Counter_Name"], row["Dispatch_Id"])
+                        per[key] = per.get(key, 0.0) + float(row["Counter_Value"] or 0)
+            for c in counters:
+                vals = [v for (cn, _), v in per.items() if cn == c]
+                if not vals:
+                    raise RuntimeError("no %s rows for kernel %s" % (c, kernel))
+                out[c] = sum(vals) / len(vals)
+                out["launches"] = len(vals)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -203,6 +245,8 @@ def main():
     ap.add_argument("--preroll-s", type=float, default=0.3, help="untimed load before the warm-up steps so the GPU has clocked up (0 = none)")
     ap.add_argument("--no-self-check", action="store_true", help="ablation builds compute garbage on purpose (tools/ablate.sh)")
     ap.add_argument("--force-gather", action="store_true", help="run the all-gather + merge even on 1 rank (test aid)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the live rocprofv3 --pmc child runs that measure the dominant kernel's HBM traffic (N = 1 only; ~15 s each)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -427,18 +471,47 @@ def main():
                     "frac": achieved / HBM_PEAK_GBPS, "avg_kernel_ms": dk["avg_ms"], "alg_bytes_per_launch": work_launch,
                     "model": "bytes this kernel must move through HBM: its side of the split engine's one round trip (8 N per correlation "
                              "row), or x in + X out for the forward stage, over the kernel's HIP-event duration"}
-    # Measured HBM traffic of the dominant kernel cannot be collected from inside this process (rocprofv3 --pmc wraps the
-    # command); the figure below is REPLAYED from the PMC summary of this same command committed under profiles/ and is
-    # labelled as such.  It is dropped when the file describes another kernel, batch size or world size.
+    # Measured HBM traffic of the dominant kernel: rocprofv3 --pmc wraps a command, so rank 0 of a single-GPU run re-runs this
+    # very command line (3 steps, no baselines) under it, one counter group per child run, and reads the kernel's FETCH_SIZE /
+    # WRITE_SIZE (KiB; FETCH_SIZE doubled: on gfx950 it counts half of a wide coalesced read -- MI355X_MICROARCH.md, HBM
+    # section).  If that cannot be done here (no rocprofv3, child failed) the committed PMC summary of the same command under
+    # profiles/ is replayed instead and labelled as such; it is dropped when it describes another kernel, batch or world size.
     roofline["traffic"] = None
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ)       # never nest profilers
+    if world == 1 and rank == 0 and not args.no_pmc and not under_profiler and not os.environ.get("GACQ_BENCH_PMC_CHILD"):
+        child = ["--gpus", "1", "--config", str(args.config), "--epochs", str(epochs), "--steps", "3", "--warmup", "1", "--engine", str(args.engine),
+                 "--no-cpu-baseline", "--no-latency", "--sustained-s", "0", "--preroll-s", "0", "--no-pmc", "--lanes", str(args.lanes)]
+        for kv in args.option:
+            child += ["--option", kv]
+        if args.no_self_check:
+            child.append("--no-self-check")
+        passes = [["FETCH_SIZE"], ["WRITE_SIZE"]]
+        if dk["bound"] == "valu":
+            passes.append(["GRBM_GUI_ACTIVE", "SQ_ACTIVE_INST_VALU"])
+        t_pmc = time.perf_counter()
+        try:
+            pm = pmc_passes(child, kname.split("<")[0].split(" ")[0], passes)
+            roofline["traffic"] = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
+            roofline["traffic_source"] = {"measured_in_this_run": True, "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child runs of this "
+                                          "command (separate passes), bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch",
+                                          "fetch_size_kib_raw": pm["FETCH_SIZE"], "write_size_kib": pm["WRITE_SIZE"], "launches_averaged": pm["launches"],
+                                          "seconds": None}
+            if "SQ_ACTIVE_INST_VALU" in pm and pm.get("GRBM_GUI_ACTIVE"):
+                # GRBM_GUI_ACTIVE sums the 8 XCDs; SQ_ACTIVE_INST_VALU counts quad-cycles over 1024 SIMDs (tools/pmc_profile.py)
+                roofline["traffic_source"]["valu_pipe_busy_pmc"] = 4.0 * pm["SQ_ACTIVE_INST_VALU"] / (pm["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+            roofline["traffic_source"]["seconds"] = time.perf_counter() - t_pmc
+        except Exception as exc:
+            roofline["traffic_source"] = {"measured_in_this_run": False, "live_error": repr(exc)[:300]}
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath) and world == 1:
+    if roofline["traffic"] is None and os.path.exists(tpath) and world == 1:
         try:
             tj = json.load(open(tpath))
             if tj.get("config", 2) == args.config and tj.get("kernel_stage") == dstage and tj.get("epochs") == E_total:
                 roofline["traffic"] = tj.get("hbm_bytes_per_launch")
-                roofline["traffic_source"] = {"measured_in_this_run": False, "file": "profiles/traffic_latest.json",
-                                              "from": tj.get("source"), "valu_pipe_busy_pmc": tj.get("valu_pipe_busy")}
+                src = roofline.get("traffic_source") or {}
+                src.update({"measured_in_this_run": False, "file": "profiles/traffic_latest.json",
+                            "from": tj.get("source"), "valu_pipe_busy_pmc": tj.get("valu_pipe_busy")})
+                roofline["traffic_source"] = src
         except Exception:
             pass
     # the SURVEY 8d stage-boundary figure, kept as a secondary number: how a perfect HBM-bound five-stage pipeline would

@@ -489,7 +489,7 @@ def test_bench_under_torchrun_single_rank_exercises_rccl_path(config, extra):
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-           "--config", str(config), "--force-gather", "--no-cpu-baseline", "--sustained-s", "0.2"] + extra
+           "--config", str(config), "--force-gather", "--no-cpu-baseline", "--no-pmc", "--sustained-s", "0.2"] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -498,6 +498,32 @@ def test_bench_under_torchrun_single_rank_exercises_rccl_path(config, extra):
     assert j["roofline"]["bound"] in ("valu", "hbm") and 0.0 < j["roofline"]["frac"] < 1.0        # a fraction of a real ceiling
     assert j["config"]["baseline_config"] == config and j["config"]["shards_seen_by_every_rank"] == 1
     assert j["sustained"]["seconds"] >= 0.2 and len(j["roofline"]["per_rank"]) == 1
+
+
+def test_bench_measures_hbm_traffic_live_with_pmc_child_runs():
+    """bench.py's roofline.traffic is measured in the run itself: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of the same
+    command (separate passes).  The fused N = 4096 kernel must read each epoch's samples and write 16-byte peak records: the
+    measured bytes per launch lie between the algorithmic floor (x in) and a few times it (code spectra + twiddle re-reads)."""
+    import json
+    import os
+    import shutil
+    import subprocess
+    import sys
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("rocprofv3 not installed")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    E = 1024
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--epochs", str(E), "--no-cpu-baseline", "--no-latency",
+           "--sustained-s", "0", "--preroll-s", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    src = j["roofline"]["traffic_source"]
+    assert src["measured_in_this_run"] is True, src
+    x_bytes = E * 4096 * 8
+    assert x_bytes <= j["roofline"]["traffic"] <= 40 * x_bytes, (j["roofline"]["traffic"], x_bytes)
+    assert 0.3 < src["valu_pipe_busy_pmc"] <= 1.0
+    assert src["launches_averaged"] >= 3
 
 
 R31_CASES = ["cfg4_l5i_subset", "l5q_subset", "cfg4_b2ad_b80", "gal_e6b", "gal_e5bq", "bds_b3i", "bds_b2bi", "glo_l3ocd",

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B the LDS correlate kernel variants on the GPU box: prints avg kernel ms + cells/s per variant.
 for v in ${VARIANTS:-0 1 2 3 4 5}; do
-  timeout 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --option lds_variant=$v "$@" 2>/dev/null | python -c "
+  timeout 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-pmc --option lds_variant=$v "$@" 2>/dev/null | python -c "
 import sys, json
 for line in sys.stdin:
     if line.startswith('{'):

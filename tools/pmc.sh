@@ -3,7 +3,7 @@
 TAG=$1; CNT=$2; shift 2
 OUT=$(pwd)/gpurun_out/pmc_$TAG
 mkdir -p $OUT; export TMPDIR=/tmp; REPO=$(pwd); cd /tmp
-rocprofv3 --pmc $CNT --output-format csv -d $OUT -o p -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $OUT/bench.log 2>&1
+rocprofv3 --pmc $CNT --output-format csv -d $OUT -o p -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pmc "$@" > $OUT/bench.log 2>&1
 cd $REPO
 python - $OUT <<'PY'
 import csv, glob, sys, os
