@@ -30,7 +30,8 @@ constexpr int kPitch = 257;            // exchange-2 row pitch in complex elemen
 constexpr int kLdsElems = 16 * kPitch; // 4112 complex = 32.9 KB -> 4 workgroups per CU
 
 // Ablation builds for profiling only (tools/ablate.sh): bit 0 drops the LDS traffic, bit 1 the barriers, bit 2 the
-// magnitude/reduce tail, bit 3 the twiddle multiplies.  Results are wrong by construction; never set in the product build.
+// magnitude/reduce tail, bit 3 the twiddle multiplies, bit 4 the X loads of lds16k_correlate_kernel, bit 5 the workgroup-wide
+// barriers of fft16k.  Results are wrong by construction; never set in the product build.
 #ifndef GACQ_ABL
 #define GACQ_ABL 0
 #endif
@@ -219,11 +220,11 @@ __device__ __forceinline__ void fft16k(v2 (&v)[kR], v2* lds, const float2* __res
 #pragma unroll
     for (int jj = 0; jj < 4; jj++) lds[ka * kLdsElems + t + 1024 * jj] = v[jj + 4 * ka];
   }
-  __syncthreads();
+  if (!(GACQ_ABL & 32)) __syncthreads();
   v2* region = lds + g * kLdsElems;
 #pragma unroll
   for (int j = 0; j < kR; j++) v[j] = region[tl + 256 * j];
-  __syncthreads();                                   // exchange-0 reads complete before the regions are reused
+  if (!(GACQ_ABL & 32)) __syncthreads();             // exchange-0 reads complete before the regions are reused
   fft4096<INV>(v, region, wa, wb, nullptr, nullptr, tl);
 }
 
@@ -332,10 +333,13 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_correlate_kernel(const flo
       const __amdgpu_buffer_rsrc_t xres = big_rsrc(xs + (long)b * kBig);
       v2 v[kR];
 #pragma unroll
-      for (int jp = 0; jp < kR / 2; jp++) ld_pair_big(xres, lane_off, jp, v[2 * jp], v[2 * jp + 1]);      // loads first, asm afterwards
+      for (int jp = 0; jp < kR / 2; jp++) {
+        if (GACQ_ABL & 16) { v[2 * jp] = c[2 * jp + 1]; v[2 * jp + 1] = c[2 * jp]; continue; }      // ablation: no X loads
+        ld_pair_big(xres, lane_off, jp, v[2 * jp], v[2 * jp + 1]);      // loads first, asm afterwards
+      }
 #pragma unroll
       for (int jj = 0; jj < kR; jj++) v[jj] = cmul(c[jj], v[jj]);
-      if (b > 0 || p > p0) __syncthreads();          // previous transform's last LDS reads are complete
+      if (!(GACQ_ABL & 32) && (b > 0 || p > p0)) __syncthreads();          // previous transform's last LDS reads are complete
       fft16k<true>(v, lds, twn, base);
 #pragma unroll
       for (int k = 0; k < kR; k++) {
