@@ -81,6 +81,21 @@ __global__ __launch_bounds__(kBlock) void split_outer_forward_kernel(const float
   });
 }
 
+// Ablation builds for profiling only (tools/ablate.sh sN): bit 0 = the outer inverse kernel keeps its loads and its reduction but
+// skips the twiddles and the DFT; bit 1 = it reads one contiguous R x 256 tile instead of R row segments, bit 2 = with 16-byte loads, bit 3 = groups in reverse order
+// (last written first), bit 4 = plain instead of non-temporal Z' loads, bit 5 = non-temporal Z' stores in the Stockham kernel (bits 3-5 compute correctly).  Results are wrong by construction; never set in the product build.
+#ifndef GACQ_ABL_SPLIT
+#define GACQ_ABL_SPLIT 0
+#endif
+
+// Z' is read exactly once: non-temporal loads (`global_load_dwordx2 ... nt`) keep the 1-2 GB stream from displacing the code spectra
+// and twiddles in L2 and measured 3-17 % faster than plain loads on the reading side (profiles/r02_split_nontemporal_experiment.log).
+template <bool NT>
+__device__ __forceinline__ v2 ld_stream(const float2* p) {
+  if (!NT || (GACQ_ABL_SPLIT & 16)) { const float2 z = *p; return v2{z.x, z.y}; }
+  return __builtin_bit_cast(v2, __builtin_nontemporal_load(reinterpret_cast<const double*>(p)));
+}
+
 // ---- inverse outer stage + magnitude + reduce ------------------------------------------------------------
 // Z: [group][b][k1][n2] after the inner inverse transforms (unnormalised).  One workgroup handles 256 values of n2
 // of one group and emits a partial (peak, idx, sum) record; idx = M n1 + n2.
@@ -93,9 +108,10 @@ __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_i
   __shared__ float s_peak[kBlock / 64];
   __shared__ int s_idx[kBlock / 64];
   __shared__ double s_sum[kBlock / 64];
+  constexpr bool kNT = B1 || R != 31;              // the multi-block R = 31 kernel (E6B, B3I, E5: 0.94 -> 0.99 ms) is the one case that loses
   const unsigned blk = blockIdx.x;
   const int chunk = (int)(blk % (unsigned)chunks);
-  const long g = blk / (unsigned)chunks;
+  const long g = (GACQ_ABL_SPLIT & 8) ? (long)(gridDim.x / (unsigned)chunks) - 1 - (long)(blk / (unsigned)chunks) : (long)(blk / (unsigned)chunks);
   const int n2 = chunk * kBlock + threadIdx.x;
   float peak = -1.0f;
   int idx = 0x7fffffff;
@@ -105,8 +121,26 @@ __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_i
     v2 v[R];
     {
       const float2* src = Z + (g * B) * (long)(R * M) + n2;
+      if (GACQ_ABL_SPLIT & 4) {        // ablation: the same bytes as 16-byte loads from one contiguous tile (wrong elements)
+        const float4* s4 = reinterpret_cast<const float4*>(Z + ((g * B) * (long)(R * M) & ~1L));
+        long base4 = ((long)chunk * R * kBlock) / 2;
+        if ((base4 + (R + 1) / 2 * kBlock) * 2 >= (long)R * M) base4 -= (long)R * kBlock;
 #pragma unroll
-      for (int k1 = 0; k1 < R; k1++) { const float2 zf = src[(long)k1 * M]; v[k1] = v2{zf.x, zf.y}; }
+        for (int h = 0; h < (R + 1) / 2; h++) {
+          const float4 q4 = s4[base4 + h * kBlock + threadIdx.x];
+          v[2 * h] = v2{q4.x, q4.y};
+          if (2 * h + 1 < R) v[2 * h + 1] = v2{q4.z, q4.w};
+        }
+      } else
+#pragma unroll
+      for (int k1 = 0; k1 < R; k1++) {
+        long off = (long)k1 * M;
+        if (GACQ_ABL_SPLIT & 2) {      // ablation: the same bytes as one contiguous R x 256 tile per workgroup (wrong elements)
+          off = ((long)chunk * R + k1) * kBlock + threadIdx.x - n2;
+          if (off + n2 >= (long)R * M) off -= (long)R * kBlock;
+        }
+        v[k1] = ld_stream<kNT>(src + off);
+      }
     }
     TwPow tp;
     if (TW) {
@@ -114,7 +148,16 @@ __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_i
       const v2 wv = {wf.x, -wf.y};      // conj: W_N^{-n2}
       tp.init<R - 1>(wv);
     }
-    if (B1) {
+    if (GACQ_ABL_SPLIT & 1) {        // ablation: the loads and the reduction only (no twiddles, no DFT)
+      float sum_f = 0.f;
+#pragma unroll
+      for (int n1 = 0; n1 < R; n1++) {
+        const float m = v[n1].x * v[n1].x + v[n1].y * v[n1].y;
+        if (m > peak) { peak = m; idx = M * n1 + n2; }
+        sum_f += m;
+      }
+      sum = (double)sum_f;
+    } else if (B1) {
       if (TW) {
 #pragma unroll
         for (int k1 = 1; k1 < R; k1++) v[k1] = tp.apply(v[k1], k1);
@@ -150,7 +193,7 @@ __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_i
       if (b > 0) {
         const float2* src = Z + (g * B + b) * (long)(R * M) + n2;
 #pragma unroll
-        for (int k1 = 0; k1 < R; k1++) { const float2 zf = src[(long)k1 * M]; v[k1] = v2{zf.x, zf.y}; }
+        for (int k1 = 0; k1 < R; k1++) v[k1] = ld_stream<kNT>(src + (long)k1 * M);
       }
       if (TW) {
 #pragma unroll
@@ -188,7 +231,7 @@ __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_i
     r.peak = peak;
     r.idx = idx;
     r.sum = sum;
-    partial[blk] = r;
+    partial[g * chunks + chunk] = r;      // = blockIdx.x
   }
 }
 
@@ -263,7 +306,8 @@ __device__ __forceinline__ void stockham_pass(v2* __restrict__ buf, float2* __re
       const int j0 = (j / Ns) * Ns * R + k;
 #pragma unroll
       for (int t = 0; t < R; t++) {
-        if (LAST) gz[j0 + t * Ns] = make_float2(x[it][t].x, x[it][t].y);
+        if (LAST && (GACQ_ABL_SPLIT & 32)) __builtin_nontemporal_store(__builtin_bit_cast(double, x[it][t]), reinterpret_cast<double*>(gz + j0 + t * Ns));
+        else if (LAST) gz[j0 + t * Ns] = make_float2(x[it][t].x, x[it][t].y);
         else buf[j0 + t * Ns] = x[it][t];
       }
     }
