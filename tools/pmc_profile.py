@@ -52,7 +52,7 @@ def main():
     for k, cs in sorted(acc.items()):
         if not rx.search(k):
             continue
-        short = re.sub(r"\(.*", "", k.replace("void (anonymous namespace)::", ""))[:110]
+        short = re.sub(r"\(.*", "", k.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", ""))[:110]
         avg = {c: sum(v.values()) / len(v) for c, v in cs.items()}
         n = max(len(v) for v in cs.values())
         print("== %s   (%d launches per pass)" % (short, n))

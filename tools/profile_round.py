@@ -55,7 +55,7 @@ def main():
     os.makedirs(out, exist_ok=True)
     py = sys.executable
     bench = [py, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-latency", "--no-pmc"]
-    for cfg in (2, 4, 5):
+    for cfg in (2, 3, 4, 5):
         trace(out, "config%d" % cfg, bench + ["--config", str(cfg)])
     txt = pmc(out, "config2", bench + ["--steps", "2", "--warmup", "1", "--preroll-s", "0", "--sustained-s", "0"], "fused4k|lds_correlate|lds_forward|best_doppler")
     # measured HBM traffic of the dominant kernel of the bench command -> profiles/traffic_latest.json (bench.py measures this live; the file is its labelled fall-back)
