@@ -755,6 +755,35 @@ def test_epoch_chunking_with_small_workspace():
         small.close()
 
 
+@pytest.mark.parametrize("name,items,B", [("gps-l5i", [7, 8, 9], 1), ("galileo-e6b", [2, 3, 4], 2)])
+@pytest.mark.parametrize("dt", [1, 2, 3])
+def test_stockham_doppler_tiles_with_group_chunks_not_aligned_to_the_tile(engine, name, items, B, dt):
+    """GACQ_OPT_SPLIT_DT: a workgroup of the Stockham inner kernel serves dt consecutive Doppler bins.  13 bins (not a multiple of 2
+    or 3) and a workspace that holds the forward spectra plus a handful of correlation rows, so that the (epoch, item, Doppler)
+    group chunks start and end inside a tile: byte-identical records to the roomy single pass with one bin per workgroup."""
+    import torch
+    from gnss_dsp_tools_amd import acquire, signals, synth
+    sig = signals.get(name)
+    dop = acquire.doppler_grid([-1200.0, 1400.0, 200.0])
+    assert len(dop) == 13
+    xs = synth.make_epochs(sig, B, 5151, [(items[0], 0.4, 537.0, 1201), (items[2], 0.3, -871.0, 333)], 2)
+    xd = torch.from_numpy(xs).cuda()
+    x_bytes = 8 * len(dop) * B * sig.nfft * 2                                 # both epochs' forward spectra
+    small = acquire.Engine(0, workspace_bytes=x_bytes + 5 * 8 * B * sig.nfft + (1 << 16))
+    try:
+        engine.set_option("split_dt", 1)
+        want = engine.search_batch_dev(sig, xd, items, dop, B)
+        torch.cuda.synchronize()
+        for e in (engine, small):
+            e.set_option("split_dt", dt)
+            got = e.search_batch_dev(sig, xd, items, dop, B)
+            torch.cuda.synchronize()
+            assert got.cpu().numpy().tobytes() == want.cpu().numpy().tobytes(), (name, dt, e is small)
+    finally:
+        engine.set_option("split_dt", 0)
+        small.close()
+
+
 @pytest.mark.parametrize("name,ms", [("galileo-e1b", 4), ("gps-l2cm", 20), ("beidou-b1i", 0), ("gps-l1", 0)])
 def test_zero_blocks_never_reads_x(engine, name, ms):
     """ms -> B == 0 (galileo-e1b ms < 8, gps-l2cm ms < 40): the reference's block loop is empty, it returns its untouched

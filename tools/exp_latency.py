@@ -20,6 +20,10 @@ def main():
     dop = acquire.doppler_grid(ds)
     x = synth.make_iq(sig, 1, 5, synth.default_sats(items), nsamp=4096)
     eng = acquire.Engine(0)
+    for kv in sys.argv[1:]:                       # tuning switches: name=value (gacq_set_option)
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
+    print("options:", sys.argv[1:])
     for _ in range(20):
         eng.search_all(sig, x, items, ds, 1)
     ts = []
