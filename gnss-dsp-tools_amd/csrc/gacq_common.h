@@ -130,7 +130,9 @@ int split_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, long rows, int n
 int split_radix(int N);
 bool split_inner_fused_supported(int N);
 int split_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* C, const int* d_items, const int* d_fset, long g0, long ng,
-                          int P, int F, int D, int B, int N, float2* Z);
+                          int P, int F, int D, int B, int N, float2* Z, int Mp = 0);
+// row pitch (complex elements) of the Z' buffer between the fused inner kernel and the outer inverse kernel of engine 3; 0 = none
+int split_row_pitch(int N);
 // inner stages of the split engine on the LDS FFT kernels (M = 4096)
 int lds_inner_forward(gacq_ctx* ctx, float2* rows, long nrows, bool conj);
 int lds_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const int* d_items, const int* d_fset, long g0,
@@ -138,7 +140,7 @@ int lds_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, c
 // inner inverse transforms on Y (in place), then twiddle + inverse DFT-31 + |.|/N + sum over B + reduce -> rows[g0..g0+ng)
 // inner == false: Y already holds the twiddled inner inverse transforms (LDS inner path)
 int split_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng, int B, int N, float* q_out, bool inner = true,
-                       bool twiddle_only = false);
+                       bool twiddle_only = false, int Mp = 0);
 
 // Makes ctx's device current for the duration of an entry point and restores the caller's device afterwards
 // (a library must not leave a different current device behind in a multi-GPU process).

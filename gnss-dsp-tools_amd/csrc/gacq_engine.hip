@@ -727,7 +727,9 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
       }
       // correlation workspace: chunks of whole (e,p,d) groups, B rows each
       const long groups = (long)ne * P * D;
-      const size_t group_bytes = sizeof(float2) * (size_t)B * N;
+      const bool fused_r31 = use_split && split_inner_fused_supported(N) && ctx->opt[GACQ_OPT_FUSED_INNER];
+      const int zpitch = fused_r31 ? split_row_pitch(N) : 0;       // engine 3: Z' rows padded to whole 128-byte lines
+      const size_t group_bytes = sizeof(float2) * (size_t)B * (zpitch ? (size_t)zpitch * R : (size_t)N);
       long gc = (long)std::max<size_t>(1, std::min<size_t>((size_t)groups, ctx->ws_limit / group_bytes));
       if ((rc = ensure(ctx, ctx->Y, group_bytes * gc)) != GACQ_OK) return rc;
       float2* Y = (float2*)ctx->Y.p;
@@ -745,14 +747,14 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
           if (rc != GACQ_OK) return rc;
           continue;
         }
-        if (use_split && split_inner_fused_supported(N) && ctx->opt[GACQ_OPT_FUSED_INNER]) {
+        if (fused_r31) {
           stage_begin(ctx, 6);
           rc = split_inner_correlate(ctx, X, sig->spectra_r31, (const int*)ctx->items.p, (const int*)ctx->fset.p, g0, ng, P, F, D, B, N,
-                                     Y);                                        // K2 + inner inverse FFTs (Stockham in LDS)
+                                     Y, zpitch);                                // K2 + inner inverse FFTs (Stockham in LDS)
           stage_end(ctx);
           if (rc != GACQ_OK) return rc;
           stage_begin(ctx, 4);
-          rc = split_inverse_reduce(ctx, Y, rows, g0, ng, B, N, d_qrow, false, true);   // twiddle + outer DFT-31 + |.| + reduce
+          rc = split_inverse_reduce(ctx, Y, rows, g0, ng, B, N, d_qrow, false, true, zpitch);   // twiddle + outer DFT-31 + |.| + reduce
           stage_end(ctx);
           if (rc != GACQ_OK) return rc;
           continue;

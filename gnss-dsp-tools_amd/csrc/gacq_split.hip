@@ -83,7 +83,8 @@ __global__ __launch_bounds__(kBlock) void split_outer_forward_kernel(const float
 
 // Ablation builds for profiling only (tools/ablate.sh sN): bit 0 = the outer inverse kernel keeps its loads and its reduction but
 // skips the twiddles and the DFT; bit 1 = it reads one contiguous R x 256 tile instead of R row segments, bit 2 = with 16-byte loads, bit 3 = groups in reverse order
-// (last written first), bit 4 = plain instead of non-temporal Z' loads, bit 5 = non-temporal Z' stores in the Stockham kernel (bits 3-5 compute correctly).  Results are wrong by construction; never set in the product build.
+// (last written first), bit 4 = plain instead of non-temporal Z' loads, bit 5 = non-temporal Z' stores in the Stockham kernel bit 6 = unpadded Z' rows
+// (bits 3-6 compute correctly).  Results are wrong by construction; never set in the product build.
 #ifndef GACQ_ABL_SPLIT
 #define GACQ_ABL_SPLIT 0
 #endif
@@ -103,7 +104,7 @@ __device__ __forceinline__ v2 ld_stream(const float2* p) {
 // and the 3-waves-per-SIMD register budget let a third wave hide the R strided loads of the other two.
 template <int R, bool TW, bool B1>
 __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_inverse_kernel(
-    const float2* __restrict__ Z, RowRec* __restrict__ partial, const float2* __restrict__ tw, int M, int B, int chunks, float inv_n,
+    const float2* __restrict__ Z, RowRec* __restrict__ partial, const float2* __restrict__ tw, int M, int Mp, int B, int chunks, float inv_n,
     float* __restrict__ q_out) {
   __shared__ float s_peak[kBlock / 64];
   __shared__ int s_idx[kBlock / 64];
@@ -120,9 +121,9 @@ __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_i
     // loads first, asm afterwards: the machine scheduler does not move loads across inline asm
     v2 v[R];
     {
-      const float2* src = Z + (g * B) * (long)(R * M) + n2;
+      const float2* src = Z + (g * B) * (long)(R * Mp) + n2;      // rows are Mp apart (128-byte aligned pitch)
       if (GACQ_ABL_SPLIT & 4) {        // ablation: the same bytes as 16-byte loads from one contiguous tile (wrong elements)
-        const float4* s4 = reinterpret_cast<const float4*>(Z + ((g * B) * (long)(R * M) & ~1L));
+        const float4* s4 = reinterpret_cast<const float4*>(Z + ((g * B) * (long)(R * Mp) & ~1L));
         long base4 = ((long)chunk * R * kBlock) / 2;
         if ((base4 + (R + 1) / 2 * kBlock) * 2 >= (long)R * M) base4 -= (long)R * kBlock;
 #pragma unroll
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_i
       } else
 #pragma unroll
       for (int k1 = 0; k1 < R; k1++) {
-        long off = (long)k1 * M;
+        long off = (long)k1 * Mp;
         if (GACQ_ABL_SPLIT & 2) {      // ablation: the same bytes as one contiguous R x 256 tile per workgroup (wrong elements)
           off = ((long)chunk * R + k1) * kBlock + threadIdx.x - n2;
           if (off + n2 >= (long)R * M) off -= (long)R * kBlock;
@@ -191,9 +192,9 @@ __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_i
     for (int k = 0; k < R; k++) q[k] = 0.f;
     for (int b = 0; b < B; b++) {
       if (b > 0) {
-        const float2* src = Z + (g * B + b) * (long)(R * M) + n2;
+        const float2* src = Z + (g * B + b) * (long)(R * Mp) + n2;
 #pragma unroll
-        for (int k1 = 0; k1 < R; k1++) v[k1] = ld_stream<kNT>(src + (long)k1 * M);
+        for (int k1 = 0; k1 < R; k1++) v[k1] = ld_stream<kNT>(src + (long)k1 * Mp);
       }
       if (TW) {
 #pragma unroll
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(NT * TEAMS, (DT == 1 ? 5 : (DT == 2 && R0 * R1 * R2
                                                                    float2* __restrict__ Z, const int* __restrict__ items,
                                                                    const int* __restrict__ fset, const float2* __restrict__ twm_g,
                                                                    long g0, long ng, long ep_first, int nblk_ep, int pch, int P, int F,
-                                                                   int D, int B, int R) {
+                                                                   int D, int B, int R, int Mp) {
   constexpr int M = R0 * R1 * R2 * R3;
   constexpr int nb0 = M / R0;
   static_assert(nb0 <= NT, "first pass: one radix-R0 butterfly per thread");
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(NT * TEAMS, (DT == 1 ? 5 : (DT == 2 && R0 * R1 * R2
       float2* gz = nullptr;
       if (live) {
         const float2* gx = X + (((((long)e * F + fset[p]) * D + d) * (long)B + b) * R + k1) * (long)M;
-        gz = Z + (((g - g0) * B + b) * R + k1) * (long)M;
+        gz = Z + (((g - g0) * B + b) * R + k1) * (long)Mp;
         if (act) {
           if (!have_c) {
             const float2* gc = C + ((long)items[p] * R + k1) * (long)M;
@@ -473,19 +474,19 @@ int launch_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, long rows, int 
 }
 
 template <int R>
-int launch_inverse(gacq_ctx* ctx, const float2* Z, RowRec* partial, const float2* tw, int M, int B, long ng, float inv_n,
+int launch_inverse(gacq_ctx* ctx, const float2* Z, RowRec* partial, const float2* tw, int M, int Mp, int B, long ng, float inv_n,
                    float* q_out, bool twiddle) {
   const int chunks = (M + kBlock - 1) / kBlock;
   const dim3 grid((unsigned)(ng * chunks));
   const bool b1 = (B == 1) && !q_out;
   if (twiddle && b1)
-    hipLaunchKernelGGL((split_outer_inverse_kernel<R, true, true>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, B, chunks, inv_n, q_out);
+    hipLaunchKernelGGL((split_outer_inverse_kernel<R, true, true>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, Mp, B, chunks, inv_n, q_out);
   else if (twiddle)
-    hipLaunchKernelGGL((split_outer_inverse_kernel<R, true, false>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, B, chunks, inv_n, q_out);
+    hipLaunchKernelGGL((split_outer_inverse_kernel<R, true, false>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, Mp, B, chunks, inv_n, q_out);
   else if (b1)
-    hipLaunchKernelGGL((split_outer_inverse_kernel<R, false, true>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, B, chunks, inv_n, q_out);
+    hipLaunchKernelGGL((split_outer_inverse_kernel<R, false, true>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, Mp, B, chunks, inv_n, q_out);
   else
-    hipLaunchKernelGGL((split_outer_inverse_kernel<R, false, false>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, B, chunks, inv_n, q_out);
+    hipLaunchKernelGGL((split_outer_inverse_kernel<R, false, false>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, Mp, B, chunks, inv_n, q_out);
   GACQ_HIP(ctx, hipGetLastError());
   return GACQ_OK;
 }
@@ -512,9 +513,16 @@ extern "C" int gacq_debug_phase_cycles(unsigned long long* out32, int reset) {
 #endif
 
 // K2 + inner inverse transforms in one kernel (no Y round trip); Z gets the unnormalised, untwiddled inner IFFTs
+int split_row_pitch(int N) {
+  if (!split_inner_fused_supported(N)) return 0;
+  if (GACQ_ABL_SPLIT & 64) return N / 31;          // A/B builds: unpadded rows
+  return (N / 31 + 15) & ~15;                      // 1980 -> 1984, 990 -> 992 complex: rows of Z' start on 128-byte lines
+}
+
 int split_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* C, const int* d_items, const int* d_fset, long g0, long ng,
-                          int P, int F, int D, int B, int N, float2* Z) {
+                          int P, int F, int D, int B, int N, float2* Z, int Mp) {
   const int R = 31, M = N / R;
+  if (Mp < M) Mp = M;
   const float2* twm;
   int rc = inner_twiddles(ctx, M, &twm);
   if (rc != GACQ_OK) return rc;
@@ -538,7 +546,7 @@ int split_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* C, const
   do {                                                                                                                              \
     GACQ_HIP(ctx, hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                   \
     hipLaunchKernelGGL(KERN, grid, dim3((NT) * teams), smem, ctx->stream, X, C, Z, d_items, d_fset, twm, g0, ng, ep_first, nblk_ep, pch, P, F, D, \
-                       B, R);                                                                                                       \
+                       B, R, Mp);                                                                                                   \
   } while (0)
 #define GACQ_LAUNCH_DT(R1_, R2_, NT_, TEAMS_)                                                                                        \
   do {                                                                                                                              \
@@ -619,10 +627,13 @@ int split_debug_nco(gacq_ctx* ctx, int N, int n, const double* d_freq, int* d_id
   return GACQ_OK;
 }
 
-int split_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng, int B, int N, float* q_out, bool inner, bool twiddle_only) {
+int split_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng, int B, int N, float* q_out, bool inner, bool twiddle_only,
+                         int Mp) {
   const int R = split_radix(N);
   if (!R) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "split engine: N=%d not supported", N);
   const int M = N / R;
+  if (Mp <= 0) Mp = M;
+  if (Mp != M && !twiddle_only) return set_error(ctx, GACQ_ERR_BAD_ARG, "split engine: padded rows need the fused inner kernel");
   const float2* tw;
   int rc = base_twiddles(ctx, N, M, &tw);
   if (rc != GACQ_OK) return rc;
@@ -633,11 +644,11 @@ int split_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long n
   RowRec* partial = (RowRec*)ctx->partial.p;
   const float inv_n = 1.0f / (float)N;
   switch (R) {
-    case 31: rc = launch_inverse<31>(ctx, Y, partial, tw, M, B, ng, inv_n, q_out, inner); break;
-    case 40: rc = launch_inverse<40>(ctx, Y, partial, tw, M, B, ng, inv_n, q_out, inner); break;
-    case 20: rc = launch_inverse<20>(ctx, Y, partial, tw, M, B, ng, inv_n, q_out, inner); break;
-    case 16: rc = launch_inverse<16>(ctx, Y, partial, tw, M, B, ng, inv_n, q_out, inner); break;
-    default: rc = launch_inverse<4>(ctx, Y, partial, tw, M, B, ng, inv_n, q_out, inner); break;
+    case 31: rc = launch_inverse<31>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner); break;
+    case 40: rc = launch_inverse<40>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner); break;
+    case 20: rc = launch_inverse<20>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner); break;
+    case 16: rc = launch_inverse<16>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner); break;
+    default: rc = launch_inverse<4>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner); break;
   }
   if (rc != GACQ_OK) return rc;
   hipLaunchKernelGGL(split_combine_kernel, dim3((unsigned)((ng + 127) / 128)), dim3(128), 0, ctx->stream, (const RowRec*)partial, rows,
