@@ -31,7 +31,8 @@ constexpr int kLdsElems = 16 * kPitch; // 4112 complex = 32.9 KB -> 4 workgroups
 
 // Ablation builds for profiling only (tools/ablate.sh): bit 0 drops the LDS traffic, bit 1 the barriers, bit 2 the
 // magnitude/reduce tail, bit 3 the twiddle multiplies, bit 4 the X loads of lds16k_correlate_kernel, bit 5 the workgroup-wide
-// barriers of fft16k.  Results are wrong by construction; never set in the product build.
+// barriers of fft16k; bit 6 keeps engine 4's Z' rows in natural order (A/B against the lane-pair stores, correct results with
+// -DGACQ_ABL_SPLIT=128 in gacq_split.hip).  Results are wrong by construction; never set in the product build.
 #ifndef GACQ_ABL
 #define GACQ_ABL 0
 #endif
@@ -542,15 +543,23 @@ __global__ __launch_bounds__(kBlock, 4) void lds_inner_correlate_kernel(const fl
 #pragma unroll
     for (int jj = 0; jj < kR; jj++) v[jj] = cmul(v[jj], xr[jj]);
     fft4096<true>(v, lds, twa, twb);
-    float2* dst = Z + (((g - g0) * B + b) * R + k1) * (long)kLdsN + t;
-    if (k1 == 0) {
+    // the row goes out in the lane-pair layout (n2 = t + 256 k at (k >> 1) * 512 + 2 t + (k & 1)): one 16-byte store per two
+    // outputs, 1 KiB per wave and instruction; split_outer_inverse_kernel (paired) undoes the permutation in its index arithmetic
+    float2* dst = Z + (((g - g0) * B + b) * R + k1) * (long)kLdsN;
+    if (GACQ_ABL & 64) {                        // A/B builds: natural order, 8-byte stores
 #pragma unroll
-      for (int k = 0; k < kR; k++) { const v2 o = v[rev16(k)]; dst[256 * k] = make_float2(o.x, o.y); }
+      for (int k = 0; k < kR; k++) { const v2 o = k1 == 0 ? v[rev16(k)] : cmul(v[rev16(k)], tk[k]); dst[t + 256 * k] = make_float2(o.x, o.y); }
+    } else if (k1 == 0) {
+#pragma unroll
+      for (int kp = 0; kp < kR / 2; kp++) {
+        const v2 a = v[rev16(2 * kp)], c = v[rev16(2 * kp + 1)];
+        *reinterpret_cast<float4*>(dst + kp * 512 + 2 * t) = make_float4(a.x, a.y, c.x, c.y);
+      }
     } else {
 #pragma unroll
-      for (int k = 0; k < kR; k++) {
-        const v2 o = cmul(v[rev16(k)], tk[k]);
-        dst[256 * k] = make_float2(o.x, o.y);
+      for (int kp = 0; kp < kR / 2; kp++) {
+        const v2 a = cmul(v[rev16(2 * kp)], tk[2 * kp]), c = cmul(v[rev16(2 * kp + 1)], tk[2 * kp + 1]);
+        *reinterpret_cast<float4*>(dst + kp * 512 + 2 * t) = make_float4(a.x, a.y, c.x, c.y);
       }
     }
     __syncthreads();                           // exchange-2 reads done before the next item's exchange-1 writes

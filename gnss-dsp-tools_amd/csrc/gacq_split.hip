@@ -83,8 +83,8 @@ __global__ __launch_bounds__(kBlock) void split_outer_forward_kernel(const float
 
 // Ablation builds for profiling only (tools/ablate.sh sN): bit 0 = the outer inverse kernel keeps its loads and its reduction but
 // skips the twiddles and the DFT; bit 1 = it reads one contiguous R x 256 tile instead of R row segments, bit 2 = with 16-byte loads, bit 3 = groups in reverse order
-// (last written first), bit 4 = plain instead of non-temporal Z' loads, bit 5 = non-temporal Z' stores in the Stockham kernel bit 6 = unpadded Z' rows
-// (bits 3-6 compute correctly).  Results are wrong by construction; never set in the product build.
+// (last written first), bit 4 = plain instead of non-temporal Z' loads, bit 5 = non-temporal Z' stores in the Stockham kernel bit 6 = unpadded Z' rows,
+// bit 7 = engine 4 keeps Z' in natural order (needs -DGACQ_ABL=64 in gacq_ldsfft.hip as well) (bits 3-7 compute correctly).  Results are wrong by construction; never set in the product build.
 #ifndef GACQ_ABL_SPLIT
 #define GACQ_ABL_SPLIT 0
 #endif
@@ -105,7 +105,7 @@ __device__ __forceinline__ v2 ld_stream(const float2* p) {
 template <int R, bool TW, bool B1>
 __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_inverse_kernel(
     const float2* __restrict__ Z, RowRec* __restrict__ partial, const float2* __restrict__ tw, int M, int Mp, int B, int chunks, float inv_n,
-    float* __restrict__ q_out) {
+    float* __restrict__ q_out, int paired) {
   __shared__ float s_peak[kBlock / 64];
   __shared__ int s_idx[kBlock / 64];
   __shared__ double s_sum[kBlock / 64];
@@ -113,7 +113,12 @@ __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_i
   const unsigned blk = blockIdx.x;
   const int chunk = (int)(blk % (unsigned)chunks);
   const long g = (GACQ_ABL_SPLIT & 8) ? (long)(gridDim.x / (unsigned)chunks) - 1 - (long)(blk / (unsigned)chunks) : (long)(blk / (unsigned)chunks);
-  const int n2 = chunk * kBlock + threadIdx.x;
+  // position of this thread's column inside a row of Z'.  paired (engine 4, M = 4096): the LDS inner kernel stores a row in its
+  // lane-pair layout (n2 = t + 256 j at (j >> 1) * 512 + 2 t + (j & 1), 16 bytes per lane and store); columns are independent here,
+  // so the thread simply serves whichever n2 lives at its position.  (The same layout for the Stockham kernel's last pass -- 7 x 16 + 8
+  // instead of 15 x 8 bytes per lane -- changed nothing on the writing side and cost the reader 4 %: not kept.)
+  const int pos = chunk * kBlock + threadIdx.x;
+  const int n2 = paired ? ((pos & 511) >> 1) + 256 * (((pos >> 9) << 1) | (pos & 1)) : pos;
   float peak = -1.0f;
   int idx = 0x7fffffff;
   double sum = 0.0;
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_i
     // loads first, asm afterwards: the machine scheduler does not move loads across inline asm
     v2 v[R];
     {
-      const float2* src = Z + (g * B) * (long)(R * Mp) + n2;      // rows are Mp apart (128-byte aligned pitch)
+      const float2* src = Z + (g * B) * (long)(R * Mp) + pos;     // rows are Mp apart (128-byte aligned pitch)
       if (GACQ_ABL_SPLIT & 4) {        // ablation: the same bytes as 16-byte loads from one contiguous tile (wrong elements)
         const float4* s4 = reinterpret_cast<const float4*>(Z + ((g * B) * (long)(R * Mp) & ~1L));
         long base4 = ((long)chunk * R * kBlock) / 2;
@@ -137,8 +142,8 @@ __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_i
       for (int k1 = 0; k1 < R; k1++) {
         long off = (long)k1 * Mp;
         if (GACQ_ABL_SPLIT & 2) {      // ablation: the same bytes as one contiguous R x 256 tile per workgroup (wrong elements)
-          off = ((long)chunk * R + k1) * kBlock + threadIdx.x - n2;
-          if (off + n2 >= (long)R * M) off -= (long)R * kBlock;
+          off = ((long)chunk * R + k1) * kBlock + threadIdx.x - pos;
+          if (off + pos >= (long)R * M) off -= (long)R * kBlock;
         }
         v[k1] = ld_stream<kNT>(src + off);
       }
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_i
     for (int k = 0; k < R; k++) q[k] = 0.f;
     for (int b = 0; b < B; b++) {
       if (b > 0) {
-        const float2* src = Z + (g * B + b) * (long)(R * Mp) + n2;
+        const float2* src = Z + (g * B + b) * (long)(R * Mp) + pos;
 #pragma unroll
         for (int k1 = 0; k1 < R; k1++) v[k1] = ld_stream<kNT>(src + (long)k1 * Mp);
       }
@@ -475,18 +480,18 @@ int launch_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, long rows, int 
 
 template <int R>
 int launch_inverse(gacq_ctx* ctx, const float2* Z, RowRec* partial, const float2* tw, int M, int Mp, int B, long ng, float inv_n,
-                   float* q_out, bool twiddle) {
+                   float* q_out, bool twiddle, int paired) {
   const int chunks = (M + kBlock - 1) / kBlock;
   const dim3 grid((unsigned)(ng * chunks));
   const bool b1 = (B == 1) && !q_out;
   if (twiddle && b1)
-    hipLaunchKernelGGL((split_outer_inverse_kernel<R, true, true>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, Mp, B, chunks, inv_n, q_out);
+    hipLaunchKernelGGL((split_outer_inverse_kernel<R, true, true>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, Mp, B, chunks, inv_n, q_out, paired);
   else if (twiddle)
-    hipLaunchKernelGGL((split_outer_inverse_kernel<R, true, false>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, Mp, B, chunks, inv_n, q_out);
+    hipLaunchKernelGGL((split_outer_inverse_kernel<R, true, false>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, Mp, B, chunks, inv_n, q_out, paired);
   else if (b1)
-    hipLaunchKernelGGL((split_outer_inverse_kernel<R, false, true>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, Mp, B, chunks, inv_n, q_out);
+    hipLaunchKernelGGL((split_outer_inverse_kernel<R, false, true>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, Mp, B, chunks, inv_n, q_out, paired);
   else
-    hipLaunchKernelGGL((split_outer_inverse_kernel<R, false, false>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, Mp, B, chunks, inv_n, q_out);
+    hipLaunchKernelGGL((split_outer_inverse_kernel<R, false, false>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, Mp, B, chunks, inv_n, q_out, paired);
   GACQ_HIP(ctx, hipGetLastError());
   return GACQ_OK;
 }
@@ -633,6 +638,8 @@ int split_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long n
   if (!R) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "split engine: N=%d not supported", N);
   const int M = N / R;
   if (Mp <= 0) Mp = M;
+  // Y written by lds_inner_correlate_kernel (inner == false, M == 4096): rows in the lane-pair layout
+  const int paired = (!inner && !twiddle_only && M == 4096 && !(GACQ_ABL_SPLIT & 128)) ? 1 : 0;
   if (Mp != M && !twiddle_only) return set_error(ctx, GACQ_ERR_BAD_ARG, "split engine: padded rows need the fused inner kernel");
   const float2* tw;
   int rc = base_twiddles(ctx, N, M, &tw);
@@ -644,11 +651,11 @@ int split_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long n
   RowRec* partial = (RowRec*)ctx->partial.p;
   const float inv_n = 1.0f / (float)N;
   switch (R) {
-    case 31: rc = launch_inverse<31>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner); break;
-    case 40: rc = launch_inverse<40>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner); break;
-    case 20: rc = launch_inverse<20>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner); break;
-    case 16: rc = launch_inverse<16>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner); break;
-    default: rc = launch_inverse<4>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner); break;
+    case 31: rc = launch_inverse<31>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner, paired); break;
+    case 40: rc = launch_inverse<40>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner, paired); break;
+    case 20: rc = launch_inverse<20>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner, paired); break;
+    case 16: rc = launch_inverse<16>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner, paired); break;
+    default: rc = launch_inverse<4>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner, paired); break;
   }
   if (rc != GACQ_OK) return rc;
   hipLaunchKernelGGL(split_combine_kernel, dim3((unsigned)((ng + 127) / 128)), dim3(128), 0, ctx->stream, (const RowRec*)partial, rows,
