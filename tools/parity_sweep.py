@@ -24,6 +24,8 @@ PLAN = [
     ("gps-l5i", [1, 7, 30], [-1000.0, 1000.0, 200.0], 2, 20),
     ("galileo-e6b", [2, 9], [-1000.0, 1000.0, 200.0], 2, 20),
     ("gps-l1cd", [9], [1400.0, 1700.0, 50.0], 10, 3),
+    ("gps-l2cm", [3, 17], [-400.0, 400.0, 100.0], 40, 3),
+    ("xona-x5p", [0], [-1000.0, 1000.0, 200.0], 3, 10),
 ]
 
 
