@@ -1055,3 +1055,16 @@ def test_stockham_inner_kernel_teams_match_reference_golden(engine, golden_cases
     finally:
         engine.set_option("split_teams", 0)
         engine.set_option("split_pch", 0)
+
+
+def test_randomised_differential_run_of_all_engines():
+    """tools/fuzz_engines.py for 15 s: random signals, item lists (with duplicates), grids (1-24 bins), blocks, epochs, workspace limits
+    and tuning switches; the default engine must equal itself under every switch / chunking byte for byte and agree with the
+    complex128 verification pipeline (same location, metric within 2e-6).  The long runs are in profiles/r02_fuzz_engines.log."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_engines.py"), "15", "77"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
+    assert '"failures": 0' in out.stdout
