@@ -345,7 +345,7 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_correlate_kernel(const flo
 #pragma unroll
       for (int k = 0; k < kR; k++) {
         const v2 r = v[rev16(k)];
-        q[k] += __builtin_amdgcn_sqrtf(r.x * r.x + r.y * r.y) * inv_n;
+        q[k] += __builtin_amdgcn_sqrtf(norm2(r)) * inv_n;
       }
     }
     float sum_f = q[0];
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_fused_kernel(const float2*
 #pragma unroll
     for (int k = 0; k < kR; k++) {
       const v2 r = v[rev16(k)];
-      q[k] += __builtin_amdgcn_sqrtf(r.x * r.x + r.y * r.y) * inv_n;
+      q[k] += __builtin_amdgcn_sqrtf(norm2(r)) * inv_n;
     }
     __syncthreads();                                  // the inverse transform's last LDS reads are complete
   }
@@ -675,13 +675,13 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float
 #pragma unroll
         for (int k = 0; k < kR; k++) {
           const v2 r = v[rev16(k)];
-          q[k] = __builtin_amdgcn_sqrtf(r.x * r.x + r.y * r.y);                  // np.absolute(ifft(...)) * N
+          q[k] = __builtin_amdgcn_sqrtf(norm2(r));                  // np.absolute(ifft(...)) * N
         }
       } else {
 #pragma unroll
         for (int k = 0; k < kR; k++) {
           const v2 r = v[rev16(k)];
-          q[k] += __builtin_amdgcn_sqrtf(r.x * r.x + r.y * r.y) * inv_n;
+          q[k] += __builtin_amdgcn_sqrtf(norm2(r)) * inv_n;
         }
       }
     }
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_fused4k_kernel(const float2*
 #pragma unroll
     for (int k = 0; k < kR; k++) {
       const v2 r = v[rev16(k)];
-      m[k] = __builtin_amdgcn_sqrtf(r.x * r.x + r.y * r.y);                      // np.absolute(ifft(...)) * N
+      m[k] = __builtin_amdgcn_sqrtf(norm2(r));                      // np.absolute(ifft(...)) * N
     }
     float sum_f = m[0];
 #pragma unroll

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_i
       float sum_f = 0.f;
       int expect = 0;
       OuterDft<R, true>::run(v, [&](int n1, v2 val) {
-        const float m = __builtin_amdgcn_sqrtf(val.x * val.x + val.y * val.y) * inv_n;      // np.absolute(ifft(..)), 1/N folded in
+        const float m = __builtin_amdgcn_sqrtf(norm2(val)) * inv_n;      // np.absolute(ifft(..)), 1/N folded in
         if (n1 == expect) {
           if (m > peak) { peak = m; idx = M * n1 + n2; }
           sum_f += m;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_i
         for (int k1 = 1; k1 < R; k1++) v[k1] = tp.apply(v[k1], k1);
       }
       OuterDft<R, true>::run(v, [&](int n1, v2 val) {
-        q[n1] += __builtin_amdgcn_sqrtf(val.x * val.x + val.y * val.y) * inv_n;      // np.absolute(ifft(..)), 1/N folded in
+        q[n1] += __builtin_amdgcn_sqrtf(norm2(val)) * inv_n;      // np.absolute(ifft(..)), 1/N folded in
       });
     }
 #pragma unroll
