@@ -23,7 +23,8 @@ namespace gacq {
 
 constexpr int kRingDepth = 3;
 constexpr size_t kChunkBytes = (size_t)32 << 20;      // samples per staging slot
-constexpr int kChunkEpochs = 64;                      // several chunks in flight matter more than the last percent of batching
+constexpr int kChunkEpochsMin = 64, kChunkEpochsMax = 1024;      // a call is cut into ~4 chunks (the ring holds 3) of 64..1024 epochs:
+                                                                 // enough in flight to hide the copies, launches big enough to batch well
 
 // Staging ring of one device.  pin_in is owned by the ring (single-device calls) or by the group (shared by all members).
 struct BatchRing {
@@ -67,7 +68,8 @@ int ring_get(gacq_ctx* ctx, BatchRing** out) {
 
 int epochs_per_chunk(size_t nsamp, int nepoch) {
   const size_t by_bytes = std::max<size_t>(1, kChunkBytes / std::max<size_t>(1, nsamp * sizeof(float2)));
-  return (int)std::min<size_t>((size_t)nepoch, std::min<size_t>(by_bytes, kChunkEpochs));
+  const size_t quarter = std::min<size_t>(kChunkEpochsMax, std::max<size_t>(kChunkEpochsMin, ((size_t)nepoch + 3) / 4));
+  return (int)std::min<size_t>((size_t)nepoch, std::min<size_t>(by_bytes, quarter));
 }
 
 // Queue one chunk on `sig`'s device: H2D of ne*nsamp samples from pinned `src` on the copy stream, then the search of this

@@ -71,8 +71,8 @@ def main():
         ts.append(time.perf_counter() - t0)
     print("empty synchronize: median %.1f us" % (np.median(ts) * 1e6))
     # batched host entry point: per-epoch cost
-    xs = np.stack([x] * 512)
-    for E in (1, 8, 64, 512):
+    xs = np.stack([x] * 4096)
+    for E in (1, 8, 64, 512, 2048, 4096):
         eng2 = eng
         eng2.set_stream(None)
         for _ in range(3):
