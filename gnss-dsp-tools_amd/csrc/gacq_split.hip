@@ -81,10 +81,14 @@ __global__ __launch_bounds__(kBlock) void split_outer_forward_kernel(const float
   });
 }
 
-// Ablation builds for profiling only (tools/ablate.sh sN): bit 0 = the outer inverse kernel keeps its loads and its reduction but
-// skips the twiddles and the DFT; bit 1 = it reads one contiguous R x 256 tile instead of R row segments, bit 2 = with 16-byte loads, bit 3 = groups in reverse order
-// (last written first), bit 4 = plain instead of non-temporal Z' loads, bit 5 = non-temporal Z' stores in the Stockham kernel bit 6 = unpadded Z' rows,
-// bit 7 = engine 4 keeps Z' in natural order (needs -DGACQ_ABL=64 in gacq_ldsfft.hip as well) (bits 3-7 compute correctly).  Results are wrong by construction; never set in the product build.
+// Ablation / A-B builds for profiling only (tools/ablate.sh sN), never set in the product build.
+//   wrong results by construction:
+//     bit 0  the outer inverse kernel keeps its loads and its reduction but skips the twiddles and the DFT
+//     bit 1  it reads one contiguous R x 256 tile instead of R row segments      bit 2  ... with 16-byte loads
+//   correct results, other schedule / layout:
+//     bit 3  groups visited last-written first          bit 4  plain instead of non-temporal Z' loads
+//     bit 5  non-temporal Z' stores in the Stockham kernel          bit 6  unpadded Z' rows
+//     bit 7  engine 4 keeps Z' in natural order (needs -DGACQ_ABL=64 in gacq_ldsfft.hip as well)
 #ifndef GACQ_ABL_SPLIT
 #define GACQ_ABL_SPLIT 0
 #endif
