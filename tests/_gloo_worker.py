@@ -33,6 +33,21 @@ def oracle_local(name, x, items, dopplers, blocks):
     return torch.from_numpy(out.view(np.float64).reshape(xs.shape[0], len(items), 2).copy())
 
 
+_HIP = {}
+
+
+def hip_local(name, x, items, dopplers, blocks):
+    """The real per-rank compute: this process's own HIP engine on cuda:0 (GLOO_HIP=1; several ranks then share the one GPU of the
+    test box, the exchange still runs over gloo on host tensors)."""
+    from gnss_dsp_tools_amd import acquire
+    if "eng" not in _HIP:
+        _HIP["eng"] = acquire.Engine(0)
+        _HIP["eng"].use_torch_stream()
+    out = _HIP["eng"].search_batch_dev(name, x.cuda(), items, dopplers, blocks)
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
 def main_mix(out_path, spec):
     """BASELINE config 5 in miniature: several different signals, every grid Doppler-sliced over the ranks, ONE all-gather
     (search_jobs_async with two steps in flight, as bench.py --config 5 runs it)."""
@@ -45,7 +60,7 @@ def main_mix(out_path, spec):
             B = sig.blocks(ms)
             xs = synth.make_epochs(sig, B, 6060, [(items[0], 0.4, 1537.0, 1201)], 1, nsamp=sig.samples_needed(B))
             jobs.append({"name": name, "x": torch.from_numpy(xs), "items": items, "dopplers": acquire.doppler_grid(ds), "blocks": B})
-        sh = sharded.ShardedSearch(engine=None, local_fn=oracle_local)
+        sh = sharded.ShardedSearch(engine=None, local_fn=hip_local if os.environ.get("GLOO_HIP") else oracle_local)
         p1 = sh.search_jobs_async(jobs)
         p2 = sh.search_jobs_async(jobs)                     # second step queued before the first merge
         g = p1.shards()
@@ -77,7 +92,7 @@ def main():
         blocks = sig.blocks(ms)
         dop = acquire.doppler_grid(ds)
         xs = synth.make_epochs(sig, blocks, 5150, [(items[0], 0.4, 1537.0, 1201)], 2)
-        sh = sharded.ShardedSearch(engine=None, local_fn=oracle_local)
+        sh = sharded.ShardedSearch(engine=None, local_fn=hip_local if os.environ.get("GLOO_HIP") else oracle_local)
         if os.environ.get("GLOO_JOBS"):
             # two jobs, one exchange: the same search plus a second Doppler grid
             dop2 = acquire.doppler_grid([ds[0] + 37.0, ds[1], ds[2] * 2])

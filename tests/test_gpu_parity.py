@@ -1068,3 +1068,49 @@ def test_randomised_differential_run_of_all_engines():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_engines.py"), "15", "77"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
     assert '"failures": 0' in out.stdout
+
+
+@pytest.mark.parametrize("world,name,items,ds,ms,mode", [
+    (2, "gps-l1", [3, 4, 11, 28], [-2000.0, 2500.0, 250.0], 2, ""),                  # 18 bins -> 9 + 9
+    (3, "glonass-l1", [-2, 5, 1], [1000.0, 2300.0, 100.0], 1, "GLOO_ASYNC"),         # 13 bins -> 5 + 4 + 4, FDMA biases, async exchange
+    (2, "gps-l5i", [7, 8, 9], [1000.0, 2000.0, 100.0], 1, ""),                       # split engine, Doppler tiles inside each slice
+    (2, "galileo-e1b", [5, 11, 24], [1000.0, 1375.0, 125.0], 8, ""),                 # 3 bins < 4 per rank -> item split, ragged slices
+])
+def test_ranks_sharing_the_gpu_with_real_kernels_equal_the_single_process_search(engine, tmp_path, world, name, items, ds, ms, mode):
+    """The sharded path with real per-rank compute: `world` processes, each with its own HIP engine on cuda:0, Doppler (or item)
+    slices, ONE all-gather of peak records (gloo on host tensors -- RCCL refuses two ranks on one device), tie-exact merge.  The
+    tuples must equal what one process returns for the whole grid."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from gnss_dsp_tools_amd import signals, synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = tmp_path / "res.json"
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_HIP="1")
+        if mode:
+            env[mode] = "1"
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "_gloo_worker.py"), str(out), name, ",".join(map(str, items)),
+                                       ",".join(map(str, ds)), str(ms)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        try:
+            log, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, log.decode()[-2000:]
+    res = json.load(open(out))
+    sig = signals.get(name)
+    xs = synth.make_epochs(sig, sig.blocks(ms), 5150, [(items[0], 0.4, 1537.0, 1201)], 2)        # the worker's seed and satellites
+    for e in range(xs.shape[0]):
+        want = engine.search_all(sig, xs[e], items, ds, ms)
+        for got, w in zip(res[e], want):
+            assert (got[0], got[1], got[2]) == (float(w[0]), float(w[1]), float(w[2])), (e, got, w)
