@@ -116,7 +116,9 @@ int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes);
                                 /*     one kernel (no forward-spectra buffer); 2 = also for small batches                    */
 #define GACQ_OPT_SPLIT_DT 7      /* [0 = auto] Doppler bins per workgroup of the Stockham inner kernel (1, 2 or 3): every      */
                                 /*     code-spectrum row fetched serves that many correlation rows                           */
-#define GACQ_NOPTS 8
+#define GACQ_OPT_FE_GENERIC 8    /* [0] front-end: 1 = run the any-length mix + FIR kernels even for the reference's 161-tap filter     */
+                                /*     (the specialised kernels produce the same bits; this is the A/B and test switch)              */
+#define GACQ_NOPTS 9
 int gacq_set_option(gacq_ctx* ctx, int option, long value);
 int gacq_get_option(gacq_ctx* ctx, int option, long* value);
 

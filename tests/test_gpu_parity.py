@@ -1114,3 +1114,31 @@ def test_ranks_sharing_the_gpu_with_real_kernels_equal_the_single_process_search
         want = engine.search_all(sig, xs[e], items, ds, ms)
         for got, w in zip(res[e], want):
             assert (got[0], got[1], got[2]) == (float(w[0]), float(w[1]), float(w[2])), (e, got, w)
+
+
+@pytest.mark.parametrize("name,fs,coffset,n_in", [("gps-l1", 8184000.0, 1250000.0, 57288), ("gps-l5i", 40.0e6, -1250000.0, 240000),
+                                                   ("galileo-e1b", 10.0e6, 250000.0, 1283)])
+def test_specialised_161_tap_front_end_kernels_equal_the_generic_ones_bit_for_bit(engine, name, fs, coffset, n_in):
+    """acquire-gps-l1.py:78-96 on the GPU: for the reference's 161-tap filter the carrier wipe-off is fused into the forward FIR pass
+    and both passes run the fully unrolled five-outputs-per-thread kernel; GACQ_OPT_FE_GENERIC selects the any-length kernels.
+    Same products in the same order: the conditioned samples must be identical (incl. a recording only a few tiles long and the
+    odd-extension edges, n_in = 1283 > 3 * 161 * ... barely above filtfilt's pad length)."""
+    import torch
+    from gnss_dsp_tools_amd import signals
+    sig = signals.get(name)
+    rng = np.random.Generator(np.random.PCG64(4242))
+    iq = np.clip(np.round(18.0 * rng.standard_normal((n_in, 2))), -127, 127).astype(np.int8)
+    ms_pad = max(1, int(n_in / fs * 1000.0) - 1)
+    try:
+        engine.set_option("fe_generic", 1)
+        want = engine.frontend_dev(sig, iq, fs, coffset, ms_pad)
+        torch.cuda.synchronize()
+        want = want.cpu().numpy().copy()
+        engine.set_option("fe_generic", 0)
+        got = engine.frontend_dev(sig, iq, fs, coffset, ms_pad)
+        torch.cuda.synchronize()
+        got = got.cpu().numpy()
+    finally:
+        engine.set_option("fe_generic", 0)
+    assert got.tobytes() == want.tobytes()
+    assert np.isfinite(got.view(np.float32)).all() and float(np.abs(got).max()) > 0.0
