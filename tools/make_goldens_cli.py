@@ -153,6 +153,14 @@ def main():
     fs, coff, ms = 40.0e6, 1250000.0, 1
     iq = recording_by_delay(fs, coff, ms, [("gps.l5i", 7, 10230000.0, 10230, 9.0, 1537.0, 0.000293, False)], SEED + 95)
     write_case("gps-l5i", "cli_gps_l5i_int8.iq", iq, fs, coff, ["--prn", "6-8", "--doppler-search", "1000,2000,200", "--time", str(ms)])
+    # GPS L1Cd: Weil code with BOC(1,1), 10 ms coherent blocks, N = 81920 (split engine R = 20), 8.192 MS/s from a 10 MS/s recording
+    fs, coff, ms = 10.0e6, 250000.0, 10
+    iq = recording_by_delay(fs, coff, ms, [("gps.l1cd", 9, 1023000.0, 10230, 8.0, 1537.0, 0.00412, True)], SEED + 94)
+    write_case("gps-l1cd", "cli_gps_l1cd_int8.iq", iq, fs, coff, ["--prn", "8-9", "--doppler-search", "1400,1700,50", "--time", str(ms)])
+    # GPS L2CM: 20 ms code, padded search (blocks = ms//20 - 1), N = 163840 (split engine R = 40), 4.096 MS/s from a 5 MS/s recording
+    fs, coff, ms = 5.0e6, -250000.0, 40
+    iq = recording_by_delay(fs, coff, ms, [("gps.l2cm", 17, 511500.0, 10230, 8.0, -409.0, 0.0137, False)], SEED + 93)
+    write_case("gps-l2cm", "cli_gps_l2cm_int8.iq", iq, fs, coff, ["--prn", "16-17", "--doppler-search", "-600,-200,100", "--time", str(ms)])
     # long-code scripts: FILE FS COFFSET ITEM DOPPLER CODE_PHASE
     fs, coff, ms = 4092000.0, -127126.0, 40
     iq = recording_by_start_chips(fs, coff, ms, "gps.l2cl", 30, 511500.0, 767250, 3.0, 1618.0, 10230.0 * 42 + 8317.2, SEED + 601)
