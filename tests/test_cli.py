@@ -117,11 +117,12 @@ _ANY = re.compile(r"(prn|chan)\s+(-?\d+) doppler\s+(-?[\d.]+) metric\s+(-?[\d.]+
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("gname", ["cli_glonass_l1.json", "cli_galileo_e1b.json", "cli_beidou_b1i.json", "cli_gps_l5i.json", "cli_gps_l1cd.json",
-                                   "cli_gps_l2cm.json"])
+                                   "cli_gps_l2cm.json", "cli_xona_x1.json", "cli_glonass_l2.json", "cli_galileo_e6b.json"])
 def test_cli_other_signals_match_reference_stdout(gname):
     """--channel list syntax + FDMA bias (acquire-glonass-l1.py:69,28), the BOC/padded 4 ms variant, the padded raw-metric B1I
     search (N = 16384 LDS kernels), the 10.23 Mcps family (N = 61380 radix-31 engine, 30.69 MS/s from a 40 MS/s file), the BOC Weil code of
-    L1Cd (N = 81920, ms//10 blocks) and the padded 20 ms L2CM search (N = 163840, ms//20 - 1 blocks) through the
+    L1Cd (N = 81920, ms//10 blocks), the padded 20 ms L2CM search (N = 163840, ms//20 - 1 blocks), Xona X1 (default item list '0', normalised
+    metric), GLONASS L2 (437.5 kHz channel spacing) and Galileo E6-B (N = 30690, M = 990 Stockham kernel) through the
     whole device-resident chain: GPU front-end at four different rates / cutoffs, then the engine auto picks."""
     from gnss_dsp_tools_amd import cli
     g = json.load(open(os.path.join(GOLD, gname)))

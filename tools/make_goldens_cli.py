@@ -161,6 +161,19 @@ def main():
     fs, coff, ms = 5.0e6, -250000.0, 40
     iq = recording_by_delay(fs, coff, ms, [("gps.l2cm", 17, 511500.0, 10230, 8.0, -409.0, 0.0137, False)], SEED + 93)
     write_case("gps-l2cm", "cli_gps_l2cm_int8.iq", iq, fs, coff, ["--prn", "16-17", "--doppler-search", "-600,-200,100", "--time", str(ms)])
+    # Xona X1: unpadded, normalised metric, the default item list is the single PRN 0, very wide default Doppler range
+    fs, coff, ms = 5.0e6, 100000.0, 2
+    iq = recording_by_delay(fs, coff, ms, [("xona.x1p", 0, 1023000.0, 1023, 9.0, 21537.0, 0.000293, False)], SEED + 92)
+    write_case("xona-x1", "cli_xona_x1_int8.iq", iq, fs, coff, ["--doppler-search", "20000,23000,250", "--time", str(ms)])
+    # GLONASS L2: the 437.5 kHz channel spacing (acquire-glonass-l2.py:28), channels given as a range and a single value
+    fs, coff, ms = 18.0e6, 0.0, 2
+    iq = recording_by_delay(fs, coff, ms, [("glonass.ca", 0, 511000.0, 511, 9.0, 437500.0 * 3 - 1262.0, 0.000412, False),
+                                           ("glonass.ca", 0, 511000.0, 511, 7.0, 437500.0 * (-6) + 2037.0, 0.00071, False)], SEED + 91)
+    write_case("glonass-l2", "cli_glonass_l2_int8.iq", iq, fs, coff, ["--channel", "-6,2:3", "--doppler-search", "-3000,3000,250", "--time", str(ms)])
+    # Galileo E6-B: 5.115 Mcps, N = 30690 (radix-31 engine with M = 990), padded, raw metric, 2 blocks
+    fs, coff, ms = 20.0e6, -500000.0, 2
+    iq = recording_by_delay(fs, coff, ms, [("galileo.e6b", 4, 5115000.0, 5115, 9.0, 1537.0, 0.000293, False)], SEED + 90)
+    write_case("galileo-e6b", "cli_galileo_e6b_int8.iq", iq, fs, coff, ["--prn", "3-4", "--doppler-search", "1000,2000,200", "--time", str(ms)])
     # long-code scripts: FILE FS COFFSET ITEM DOPPLER CODE_PHASE
     fs, coff, ms = 4092000.0, -127126.0, 40
     iq = recording_by_start_chips(fs, coff, ms, "gps.l2cl", 30, 511500.0, 767250, 3.0, 1618.0, 10230.0 * 42 + 8317.2, SEED + 601)
