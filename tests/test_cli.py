@@ -137,9 +137,9 @@ def test_cli_other_signals_match_reference_stdout(gname):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("gname", ["cli_gps_l2cl.json", "cli_glonass_l1_p.json"])
+@pytest.mark.parametrize("gname", ["cli_gps_l2cl.json", "cli_glonass_l1_p.json", "cli_glonass_l2_p.json"])
 def test_cli_longcode_scripts_match_reference_stdout(gname):
-    """acquire-gps-l2cl.py / acquire-glonass-l1-p.py surface: FILE FS COFFSET ITEM DOPPLER CODE_PHASE -> '%f %f'."""
+    """acquire-gps-l2cl.py / acquire-glonass-l1-p.py / -l2-p.py surface: FILE FS COFFSET ITEM DOPPLER CODE_PHASE -> '%f %f'."""
     from gnss_dsp_tools_amd import cli
     g = json.load(open(os.path.join(GOLD, gname)))
     path = os.path.join(GOLD, g["file"])

@@ -181,6 +181,10 @@ def main():
     fs, coff, ms = 10220000.0, 245125.0, 8
     iq = recording_by_start_chips(fs, coff, ms, "glonass.p", 0, 5110000.0, 5110000, 4.0, 562500.0 * (-4) + 2600.0, 5110.0 * 611 + 2786.0, SEED + 602)
     write_case("glonass-l1-p", "cli_glonass_l1_p_int8.iq", iq, fs, coff, ["--time", str(ms)], tail=["-4", "2600.0", "278.6"])
+    # the L2 twin: 437.5 kHz channel spacing (acquire-glonass-l2-p.py:18)
+    fs, coff, ms = 10220000.0, -145125.0, 8
+    iq = recording_by_start_chips(fs, coff, ms, "glonass.p", 0, 5110000.0, 5110000, 4.0, 437500.0 * 3 - 1800.0, 5110.0 * 127 + 1493.0, SEED + 603)
+    write_case("glonass-l2-p", "cli_glonass_l2_p_int8.iq", iq, fs, coff, ["--time", str(ms)], tail=["3", "-1800.0", "149.3"])
 
 
 if __name__ == "__main__":
