@@ -7,8 +7,16 @@ raises at import, and the engine entry points raise when no GPU is visible.
 import ctypes
 import os
 
+import sys
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgacq.so")
+# Tuning tools only (tools/variant.py): a script that defines GACQ_TUNING_LIB = "<path>" in its __main__ module before
+# importing the package loads that build (an A/B or diagnostic variant under build/variants/) instead of the product library.
+# lib/libgacq.so itself is never replaced, and nothing reads the environment.
+_tuning = getattr(sys.modules.get("__main__"), "GACQ_TUNING_LIB", None)
+if _tuning:
+    LIB_PATH = os.path.abspath(_tuning)
 
 # One HIP runtime per process: when torch is (or will be) in the process its bundled
 # libamdhip64/librocfft (same SONAMEs as /opt/rocm's) must be the ones that get bound, so it
@@ -51,7 +59,7 @@ ERRORS = {0: "GACQ_OK", -1: "GACQ_ERR_BAD_ARG", -2: "GACQ_ERR_UNKNOWN_CODE", -3:
           -8: "GACQ_ERR_INTERNAL", -9: "GACQ_ERR_UNSUPPORTED"}
 
 # GACQ_OPT_* of include/gacq.h
-OPTIONS = {"fused_inner": 0, "fused_16k": 1, "lds_variant": 2, "lds_pch": 3, "split_pch": 4, "split_teams": 5, "fused_4k": 6, "split_dt": 7, "fe_generic": 8}
+OPTIONS = {"fused_inner": 0, "fused_16k": 1, "lds_variant": 2, "lds_pch": 3, "split_pch": 4, "split_teams": 5, "fused_4k": 6, "split_dt": 7, "fe_generic": 8, "lds_ugroup": 9}
 
 # name -> (restype, argtypes): every symbol include/gacq.h declares
 SYMBOLS = {

@@ -51,7 +51,7 @@ struct gacq_ctx {
   size_t ws_limit = (size_t)4 << 30;
   std::map<std::pair<long, long>, gacq::FftPlan> plans;   // (N * 2 + inverse, batch)
   gacq::DevBuf tab, xstage, X, Y, rows, freq, fset, items, out_peaks, d0, partial, fe_a, fe_b, fe_taps, chunk_peaks;
-  long opt[GACQ_NOPTS] = {1, 1, -1, 0, 0, 0, 1, 0, 0};   // gacq_set_option values (defaults documented in include/gacq.h)
+  long opt[GACQ_NOPTS] = {1, 1, -1, 0, 0, 0, 1, 0, 0, 0};   // gacq_set_option values (defaults documented in include/gacq.h)
   gacq::DevBuf pin_x, pin_peaks;       // pinned host staging for the host-buffer entry point (gacq_search)
   gacq::BatchRing* ring = nullptr;     // staging ring of gacq_search_batch / gacq_group_search_batch, created on first use
   bool profiling = false;

@@ -184,61 +184,217 @@ __global__ __launch_bounds__(kBlock) void lds_forward_kernel(const float2* __res
 }
 
 // ======================================================================================================
-// N = 16384 = 4 x 4096 in ONE 1024-thread workgroup (B1I/B2I padded, GLONASS L1/L2): 16 points per lane,
-//   n = 4096 na + m, k = ka + 4 km:  X[ka + 4 km] = FFT4096_m( W_N^{m ka} * sum_na x[4096 na + m] W_4^{na ka} )[km]
-//   pass 0  lane t holds x[t + 1024 j], j = 4 na + jj (m = t + 1024 jj): four DFT-4 over na, twiddle W_N^{m ka}
-//   exchange 0 through LDS: (ka, m) -> region ka, lane t' = m mod 256 gets m = t' + 256 j
-//   then each 256-lane group runs the 4096-point transform of its region (same code as the N = 4096 engine).
-// LDS: 4 regions x 32.9 KB = 131.6 KB -> one workgroup (16 waves, 4 per SIMD) per CU.  Output: lane (ka, t'') holds
-// X[(ka + 4 t'') + 1024 k2] in register rev16(k2), i.e. exactly the input convention with lane index ka + 4 t''.
+// N = 16384 in ONE 1024-thread workgroup (B1I/B2I padded, GLONASS L1/L2), 16 points per lane, as
+//   16 wave-private 1024-point transforms + one radix-16 pass across the waves:
+//     n = t + 1024 j  (t = 64 w + l: wave w, lane l; j = register),   k = ka + 16 kk,  kk = k0 + 16 k1 + 256 k2
+//   forward (decimation in frequency, natural order in, digit-permuted order out):
+//     pass 0  DFT16 over j -> ka, twiddle W_N^{t ka};  exchange 0: lane t sends output ka to wave ka (the only step
+//             that crosses waves: one workgroup barrier)
+//     then wave ka transforms its 1024 values u[m], m = l + 64 j', WITHOUT any barrier -- a wave runs in lockstep and the
+//     LDS executes one wave's accesses in order, so the two transposes inside a wave need no synchronisation:
+//     pass 1  DFT16 over j' -> k0, twiddle W_1024^{l k0};   transpose 1: lane (k0, l_lo) collects l = l_lo + 4 l_hi
+//     pass 2  DFT16 over l_hi -> k1, twiddle W_64^{l_lo k1}; transpose 2: lane mu = k0 + 16 k1_lo collects (k1_hi, l_lo)
+//     pass 3  four DFT4 over l_lo -> k2
+//     out: register r = k1_hi + 4 k2 of lane (w, mu) holds X[w + 16 mu + 1024 r]
+//   inverse (decimation in time) is the transposed network with conjugated twiddles: it takes exactly that order in and
+//   leaves y[t + 1024 j] in register rev16(j) of lane t.  Spectra (X, C_p) therefore live in memory in the order the
+//   forward transform produces them ("physical lane-pair layout": element (t, r) at (r >> 1) * 2048 + 2 t + (r & 1)), the
+//   pointwise product needs no order at all, and no reordering pass exists anywhere.
+// A correlation row costs two workgroup barriers (around the one cross-wave exchange) instead of the seven of the
+// 4 x 4096 decomposition of rounds 1-2, and the 16 waves of the CU drift apart everywhere else.
+// LDS: 16 regions of 1056 complex (1024 + the padding of the pitch-66 / pitch-65 transposes) = 132 KB + 256 B of reduction
+// scratch -> one workgroup (16 waves, 4 per SIMD, <= 128 VGPRs) per CU.  Every LDS access below is (per-lane base) +
+// (compile-time offset) and bank-conflict free (checked per 16-lane store group / 32-lane load group).
 constexpr int kBig = 16384;
 constexpr int kBigThreads = 1024;
-constexpr int kBigLdsBytes = 4 * kLdsElems * (int)sizeof(v2);
+constexpr int kRegion = 1056;                               // complex elements per wave region
+constexpr int kBigScratch = 16 * kRegion * (int)sizeof(v2); // byte offset of the cross-wave reduction scratch
+constexpr int kBigLdsBytes = kBigScratch + 256;
 
-template <bool INV>
-__device__ __forceinline__ void fft16k(v2 (&v)[kR], v2* lds, const float2* __restrict__ twn /* W_16384^m, m < 1024 */, v2 base) {
+// workgroup barrier that does not drain the vector-memory counter: an LDS-DMA in flight survives it (__syncthreads() would
+// wait for vmcnt(0) first).  lgkmcnt(0): this wave's LDS stores have been performed before the others are released.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Phase timing of lds16k_correlate_kernel (diagnostic builds only, -DGACQ_PHASE_TIMING16; tools/phase_timing16.py): lane 0 of every
+// wave accumulates the shader-clock cycles between marks into gacq_phase16[wave][phase] (read back with gacq_debug_phase16).
+// Never defined in the product build.
+#ifdef GACQ_PHASE_TIMING16
+__device__ unsigned long long gacq_phase16[16 * 8];
+#define GACQ_MARK16(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); acc16_[i] += now_ - mark16_; mark16_ = now_; } while (0)
+#else
+#define GACQ_MARK16(i) do { } while (0)
+#endif
+
+// Progress-based wave priority.  The four waves that share a SIMD do the same work between two workgroup barriers: VALU
+// segments separated by LDS round trips.  Left to the default oldest-first arbitration, the two oldest waves ping-pong
+// through all their segments (an LDS round trip is longer than a segment, so the VALU idles in between) and then wait at the
+// barrier while the two youngest do the same.  A wave that lowers its own priority at the end of every segment -- right
+// after issuing the LDS accesses that end it -- hands the VALU to the waves that are behind: the four waves take turns
+// segment by segment and every round trip is covered by the three other waves' arithmetic.
+#define GACQ_SETPRIO_(n) asm volatile("s_setprio " #n ::: "memory")
+#define GACQ_SETPRIO(n) GACQ_SETPRIO_(n)
+// Levels of the four segments between two barrier pairs of the inverse transform (last radix-16 pass + magnitudes | C * x +
+// radix-4 | radix-16 | radix-16): measured on B1I, 63 items x 200 bins x 10 blocks (profiles/r03_16k_priority_sweep.log):
+// none 3.50 ms, 3-2-1-0 3.06-3.09, 0-1-2-3 3.21, 2-3-1-0 2.98-2.99.
+#ifndef GACQ_P1
+#define GACQ_P1 2
+#define GACQ_P2 3
+#define GACQ_P3 1
+#define GACQ_P4 0
+#endif
+
+// v[k] *= w^k, k = 1..15, registers in natural order (the DIT passes twiddle their inputs); same product tree as apply_powers
+__device__ __forceinline__ void apply_powers_nat(v2 (&v)[kR], v2 w1) {
+  const v2 w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
+  v[1] = cmul(v[1], w1);    v[2] = cmul(v[2], w2);    v[3] = cmul(v[3], w3);
+  const v2 w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3), w8 = cmul(w4, w4);
+  v[4] = cmul(v[4], w4);    v[5] = cmul(v[5], w5);    v[6] = cmul(v[6], w6);    v[7] = cmul(v[7], w7);
+  const v2 w9 = cmul(w8, w1), w10 = cmul(w5, w5), w11 = cmul(w8, w3), w12 = cmul(w6, w6);
+  v[8] = cmul(v[8], w8);    v[9] = cmul(v[9], w9);    v[10] = cmul(v[10], w10); v[11] = cmul(v[11], w11);
+  v[12] = cmul(v[12], w12);
+  const v2 w13 = cmul(w8, w5), w14 = cmul(w7, w7), w15 = cmul(w8, w7);
+  v[13] = cmul(v[13], w13); v[14] = cmul(v[14], w14); v[15] = cmul(v[15], w15);
+}
+
+// Per-lane twiddle bases of the three twiddled passes: W_N^t, W_1024^l = W_N^{16 l}, W_64^{l >> 4} = W_N^{256 (l >> 4)};
+// twn holds W_16384^m for m < 1024.  The powers are rebuilt per pass (14 complex products): tables of the two wave-private
+// passes in LDS (8.5 KB, one ds_read_b64 per product) were measured -- B1I 3.04 -> 3.51 ms: the LDS pipe, already carrying
+// three exchanges per row, is as loaded as the VALU (profiles/r03_16k_*).
+struct Tw16k { v2 w0, w1, w2; };
+__device__ __forceinline__ Tw16k tw16k_load(const float2* __restrict__ twn, bool conj) {
+  const int t = threadIdx.x, l = t & 63;
+  Tw16k k;
+  k.w0 = ld2(twn + t);
+  k.w1 = ld2(twn + 16 * l);
+  k.w2 = ld2(twn + 256 * (l >> 4));
+  if (conj) { k.w0.y = -k.w0.y; k.w1.y = -k.w1.y; k.w2.y = -k.w2.y; }
+  return k;
+}
+
+// Forward transform.  In: v[j] = x[t + 1024 j].  Out: v[r] = X[(t >> 6) + 16 (t & 63) + 1024 r].
+// The caller guarantees that no wave still uses its region when the exchange-0 stores start (they go to every region).
+__device__ __forceinline__ void fft16k_fwd(v2 (&v)[kR], v2* lds, const Tw16k& tw) {
+  const int t = threadIdx.x, l = t & 63;
+  v2* reg = lds + (t >> 6) * kRegion;
+  dft16<false>(v);
+  apply_powers(v, tw.w0);
+#pragma unroll
+  for (int ka = 0; ka < kR; ka++) lds[ka * kRegion + t] = v[rev16(ka)];            // exchange 0: output ka -> wave ka
+  lds_barrier();
+  GACQ_SETPRIO(3);
+#pragma unroll
+  for (int j = 0; j < kR; j++) v[j] = reg[l + 64 * j];
+  dft16<false>(v);
+  apply_powers(v, tw.w1);
+#pragma unroll
+  for (int k0 = 0; k0 < kR; k0++) reg[66 * k0 + l] = v[rev16(k0)];                 // transpose 1, element (k0, l) at 66 k0 + l
+#pragma unroll
+  for (int lh = 0; lh < kR; lh++) v[lh] = reg[66 * (l & 15) + (l >> 4) + 4 * lh];  // lane (k0 = l & 15, l_lo = l >> 4)
+  GACQ_SETPRIO(2);
+  dft16<false>(v);
+  apply_powers(v, tw.w2);
+#pragma unroll
+  for (int k1 = 0; k1 < kR; k1++) reg[256 * (l >> 4) + (l & 15) + 16 * k1] = v[rev16(k1)];   // transpose 2, (k0, l_lo, k1) at 256 l_lo + 16 k1 + k0
+#pragma unroll
+  for (int lo = 0; lo < 4; lo++) {
+#pragma unroll
+    for (int kh = 0; kh < 4; kh++) v[kh + 4 * lo] = reg[l + 256 * lo + 64 * kh];     // lane mu = k0 + 16 k1_lo, k1 = k1_lo + 4 kh
+  }
+#pragma unroll
+  for (int kh = 0; kh < 4; kh++) dft4<false, false>(v[kh], v[kh + 4], v[kh + 8], v[kh + 12]);   // over l_lo -> k2 at v[kh + 4 k2]
+}
+
+// Inverse transform, wave-private part.  In: v[r] = Y[(t >> 6) + 16 (t & 63) + 1024 r]; on return the wave's region holds
+// z[l + 64 j'] (its 1024-point inverse transform), ready for the cross-wave exchange.  tw: conjugated bases.
+__device__ __forceinline__ void ifft16k_private(v2 (&v)[kR], v2* reg, const Tw16k& tw) {
+  const int l = threadIdx.x & 63;
+#pragma unroll
+  for (int kh = 0; kh < 4; kh++) dft4<true, false>(v[kh], v[kh + 4], v[kh + 8], v[kh + 12]);    // over k2 -> l_lo at v[kh + 4 l_lo]
+#pragma unroll
+  for (int lo = 0; lo < 4; lo++) {
+#pragma unroll
+    for (int kh = 0; kh < 4; kh++) reg[64 * (l >> 4) + (l & 15) + 256 * kh + 16 * lo] = v[kh + 4 * lo];   // (k0, l_lo, k1) at 64 k1 + 16 l_lo + k0
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < kR; k1++) v[k1] = reg[l + 64 * k1];                         // lane (k0 = l & 15, l_lo = l >> 4)
+  GACQ_SETPRIO(GACQ_P3);
+  apply_powers_nat(v, tw.w2);
+  dft16<true>(v);                                                                   // over k1 -> l_hi
+#pragma unroll
+  for (int lh = 0; lh < kR; lh++) reg[65 * (l & 15) + (l >> 4) + 4 * lh] = v[rev16(lh)];   // element (k0, l = l_lo + 4 l_hi) at 65 k0 + l
+#pragma unroll
+  for (int k0 = 0; k0 < kR; k0++) v[k0] = reg[l + 65 * k0];
+  GACQ_SETPRIO(GACQ_P4);
+  apply_powers_nat(v, tw.w1);
+  dft16<true>(v);                                                                   // over k0 -> j'
+#pragma unroll
+  for (int j = 0; j < kR; j++) reg[l + 64 * j] = v[rev16(j)];
+}
+// cross-wave part: gather the 16 partial transforms of n = t (mod 1024) ...
+__device__ __forceinline__ void ifft16k_gather(v2 (&v)[kR], const v2* lds) {
   const int t = threadIdx.x;
-  const int g = t >> 8, tl = t & 255;
-  // issue the table loads of the inner transform before any asm
-  v2 wa = ld2(twn + 4 * tl), wb = ld2(twn + 64 * (tl & 15));
-  if (INV) base.y = -base.y;
-  const v2 p2 = cmul(base, base), p3 = cmul(p2, base);
 #pragma unroll
-  for (int jj = 0; jj < 4; jj++) {
-    dft4<INV, false>(v[jj], v[jj + 4], v[jj + 8], v[jj + 12]);                 // -> ka at v[jj + 4 ka]
-    v2 a = v[jj + 4], b = v[jj + 8], c = v[jj + 12];
-    if (jj) {                                                                  // W_16^{jj ka} part of W_N^{(t + 1024 jj) ka}
-      a = cmul_k(a, wconst<16, INV>(jj));
-      b = cmul_k(b, wconst<16, INV>(2 * jj));
-      c = cmul_k(c, wconst<16, INV>(3 * jj));
-    }
-    v[jj + 4] = cmul(a, base);
-    v[jj + 8] = cmul(b, p2);
-    v[jj + 12] = cmul(c, p3);
-  }
-#pragma unroll
-  for (int ka = 0; ka < 4; ka++) {
-#pragma unroll
-    for (int jj = 0; jj < 4; jj++) lds[ka * kLdsElems + t + 1024 * jj] = v[jj + 4 * ka];
-  }
-  if (!(GACQ_ABL & 32)) __syncthreads();
-  v2* region = lds + g * kLdsElems;
-#pragma unroll
-  for (int j = 0; j < kR; j++) v[j] = region[tl + 256 * j];
-  if (!(GACQ_ABL & 32)) __syncthreads();             // exchange-0 reads complete before the regions are reused
-  fft4096<INV>(v, region, wa, wb, nullptr, nullptr, tl);
+  for (int ka = 0; ka < kR; ka++) v[ka] = lds[ka * kRegion + t];
+}
+// ... and combine them: v[rev16(j)] = N y[t + 1024 j]
+__device__ __forceinline__ void ifft16k_final(v2 (&v)[kR], const Tw16k& tw) {
+  apply_powers_nat(v, tw.w0);
+  dft16<true>(v);
 }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t big_rsrc(const float2* row) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, kBig * (int)sizeof(float2), 0x00020000);
 }
+// elements (t, 2 jp) and (t, 2 jp + 1) of a row in the physical lane-pair layout
 __device__ __forceinline__ void ld_pair_big(__amdgpu_buffer_rsrc_t r, unsigned lane_off, int jp, v2& a, v2& b) {
   const f4 q = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, (unsigned)jp * 16384u, 0));
   a = q.xy;
   b = q.zw;
 }
 
-// forward: one workgroup per (e, f, d, b) row; output conj(FFT) in the 1024-lane pair layout (j>>1)*2048 + 2 lane + (j&1)
+// LDS-DMA of one spectrum row into the wave's own region: 8 x 1 KiB, lane l's 16 bytes of piece jp land at
+// region + 1024 jp + 16 l -- no VGPRs are tied up while the row is in flight.
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+__device__ __forceinline__ void dma_row(const float2* __restrict__ row, v2* reg) {
+  const char* src = reinterpret_cast<const char*>(row) + (size_t)threadIdx.x * 16;
+#pragma unroll
+  for (int jp = 0; jp < kR / 2; jp++)
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + jp * 16384), (lptr_t)(reinterpret_cast<char*>(reg) + jp * 1024), 16, 0, 0);
+}
+__device__ __forceinline__ void dma_wait_read(v2 (&x)[kR], const v2* reg) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const f4* p = reinterpret_cast<const f4*>(reg) + (threadIdx.x & 63);
+#pragma unroll
+  for (int jp = 0; jp < kR / 2; jp++) { const f4 q = p[jp * 64]; x[2 * jp] = q.xy; x[2 * jp + 1] = q.zw; }
+  GACQ_SETPRIO(GACQ_P2);
+}
+
+// cross-wave (max, first argmax, sum) of one item through the scratch words behind the regions; thread 0 writes the record
+__device__ __forceinline__ void big_reduce_store(char* smem, float peak, unsigned widx, float wsum, RowRec* dst) {
+  float* s_peak = reinterpret_cast<float*>(smem + kBigScratch);
+  int* s_idx = reinterpret_cast<int*>(smem + kBigScratch + 64);
+  double* s_sum = reinterpret_cast<double*>(smem + kBigScratch + 128);
+  const int t = threadIdx.x;
+  if ((t & 63) == 0) { s_peak[t >> 6] = peak; s_idx[t >> 6] = (int)widx; s_sum[t >> 6] = (double)wsum; }
+  lds_barrier();
+  if (t == 0) {
+    float bp = s_peak[0];
+    int bi = s_idx[0];
+    double bs = s_sum[0];
+    for (int w = 1; w < kBigThreads / 64; w++) {
+      if (s_peak[w] > bp || (s_peak[w] == bp && s_idx[w] < bi)) { bp = s_peak[w]; bi = s_idx[w]; }
+      bs += s_sum[w];
+    }
+    RowRec r;
+    r.peak = bp;
+    r.idx = bi;
+    r.sum = bs;
+    *dst = r;
+  }
+}
+
+// forward: one workgroup per (e, f, d, b) row; output conj(FFT) in the physical lane-pair layout, 1 KiB per wave and store
 template <bool DUMP>
 __global__ __launch_bounds__(kBigThreads) void lds16k_forward_kernel(const float2* __restrict__ x, size_t epoch_stride,
                                                                       float2* __restrict__ X, const double* __restrict__ freq,
@@ -264,120 +420,126 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_forward_kernel(const float
     w[j] = ld2(nco_tab + k);
   }
   if (DUMP) return;
-  const v2 base = ld2(twn + t);
+  const Tw16k tw = tw16k_load(twn, false);
 #pragma unroll
   for (int j = 0; j < kR; j++) v[j] = cmul(v[j], w[j]);
-  fft16k<false>(v, lds, twn, base);
-  // lane (ka, t'') holds X[(ka + 4 t'') + 1024 k2]: storing straight from here would write 16-byte pieces at a 64-byte stride
-  // (quarter cache lines).  One more pass through LDS puts lane t back on natural indices t + 1024 j, so every wave stores
-  // full 1 KiB runs of the lane-pair layout.
-  const int lane = (t >> 8) + 4 * (t & 255);
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < kR; k++) lds[lane + 1024 * k] = v[rev16(k)];
-  __syncthreads();
+  fft16k_fwd(v, lds, tw);
   float2* dst = X + row * (long)kBig;
 #pragma unroll
   for (int jp = 0; jp < kR / 2; jp++) {
-    const v2 a = lds[t + 1024 * (2 * jp)], c = lds[t + 1024 * (2 * jp + 1)];
+    const v2 a = v[2 * jp], c = v[2 * jp + 1];
+    // np.conj(fft.fft(b))  acquire-beidou-b1i.py:32
     *reinterpret_cast<float4*>(dst + jp * 2048 + 2 * t) = make_float4(a.x, -a.y, c.x, -c.y);
   }
 }
 
+// natural order -> physical lane-pair layout for the code spectra (once per signal)
 __global__ __launch_bounds__(kBigThreads) void lds16k_permute_kernel(const float2* __restrict__ nat, float2* __restrict__ perm) {
   const long row = blockIdx.x;
   const int t = threadIdx.x;
-  const float2* src = nat + row * kBig;
+  const float2* src = nat + row * kBig + (t >> 6) + 16 * (t & 63);
   float2* dst = perm + row * kBig;
 #pragma unroll
   for (int jp = 0; jp < kR / 2; jp++) {
-    const float2 a = src[t + 1024 * (2 * jp)], b = src[t + 1024 * (2 * jp + 1)];
+    const float2 a = src[1024 * (2 * jp)], b = src[1024 * (2 * jp + 1)];
     *reinterpret_cast<float4*>(dst + jp * 2048 + 2 * t) = make_float4(a.x, a.y, b.x, b.y);
   }
 }
 
-// correlate: workgroup = (epoch, Doppler, chunk of items); per item: sum_b |IFFT(C_p * X_b)|/N -> (max, argmax, sum)
+// correlate: workgroup = (epoch, Doppler bin, chunk of items); per item: sum_b |IFFT(C_p * X_b)|/N -> (max, argmax, sum).
+// The item's code spectrum stays in registers for all B blocks; the forward spectrum of the NEXT row is fetched by LDS-DMA
+// into the wave's own region as soon as the cross-wave exchange of the current row has been read out, i.e. under the last
+// radix-16 pass and the magnitudes -- the register file (16 + 16 complex + 16 accumulators of 128 VGPRs) has no room for a
+// prefetch, the LDS is idle exactly then.  Blocks -> (unit, chunk): see lds_correlate().
 __global__ __launch_bounds__(kBigThreads) void lds16k_correlate_kernel(const float2* __restrict__ X, const float2* __restrict__ C,
                                                                         const int* __restrict__ items, const int* __restrict__ fset,
                                                                         const float2* __restrict__ twn, RowRec* __restrict__ rows,
-                                                                        int E, int P, int F, int D, int B, int pch, int nchunk) {
+                                                                        int E, int P, int F, int D, int B, int pch, int nchunk, int ugroup) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v2* lds = reinterpret_cast<v2*>(smem);
-  __shared__ float s_peak[kBigThreads / 64];
-  __shared__ int s_idx[kBigThreads / 64];
-  __shared__ double s_sum[kBigThreads / 64];
   const int t = threadIdx.x;
+  // placement: workgroup b runs on XCD b % 8.  Within an XCD consecutive workgroups walk ugroup units side by side
+  // (chunk-major, unit-minor), so that the workgroups resident on the XCD's 32 CUs share ugroup forward-spectrum sets
+  // (B x 128 KB each) and read the same code spectra at about the same time.
   const int xcd = blockIdx.x & 7;
   const unsigned j = blockIdx.x >> 3;
-  const unsigned u = (j / (unsigned)nchunk) * 8 + xcd;             // (epoch, Doppler) unit -> XCD, as in lds_correlate_kernel
+  const unsigned per_group = (unsigned)(nchunk * ugroup);
+  const unsigned ug = j / per_group, within = j % per_group;
+  const unsigned u = (ug * (unsigned)ugroup + within % (unsigned)ugroup) * 8 + xcd;
   if (u >= (unsigned)E * (unsigned)D) return;
   const long e = u / (unsigned)D;
   const int d = (int)(u % (unsigned)D);
-  const int p0 = (int)(j % (unsigned)nchunk) * pch;
+  const int p0 = (int)(within / (unsigned)ugroup) * pch;
   const int p1 = min(P, p0 + pch);
-  const v2 base = ld2(twn + t);
+  v2* reg = lds + (t >> 6) * kRegion;
+  const Tw16k tw = tw16k_load(twn, true);
   const unsigned lane_off = (unsigned)t * 16u;
   const float inv_n = 1.0f / (float)kBig;
-  const int lag0 = (t >> 8) + 4 * (t & 255);        // lags of this lane: lag0 + 1024 k
+  const float2* xrow = X + (((e * F + fset[p0]) * D + d) * (long)B) * kBig;
+  dma_row(xrow, reg);
+#ifdef GACQ_PHASE_TIMING16
+  unsigned long long acc16_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long mark16_ = __builtin_readcyclecounter();
+#endif
   for (int p = p0; p < p1; p++) {
     const __amdgpu_buffer_rsrc_t cres = big_rsrc(C + (long)items[p] * kBig);
-    const float2* xs = X + (((e * F + fset[p]) * D + d) * (long)B) * kBig;
-    float q[kR];
-    // the code spectrum of the item stays in registers for all B blocks: half the loads (and half the L2 traffic: the 63 x 128 KB
-    // of B1I code spectra do not fit the 4 MB L2 next to the forward spectra) of re-reading it per block
     v2 c[kR];
 #pragma unroll
     for (int jp = 0; jp < kR / 2; jp++) ld_pair_big(cres, lane_off, jp, c[2 * jp], c[2 * jp + 1]);
+    const float2* xnext_item = (p + 1 < p1) ? X + (((e * F + fset[p + 1]) * D + d) * (long)B) * kBig : nullptr;
+    float q[kR];
 #pragma unroll
     for (int k = 0; k < kR; k++) q[k] = 0.f;
     for (int b = 0; b < B; b++) {
-      const __amdgpu_buffer_rsrc_t xres = big_rsrc(xs + (long)b * kBig);
       v2 v[kR];
-#pragma unroll
-      for (int jp = 0; jp < kR / 2; jp++) {
-        if (GACQ_ABL & 16) { v[2 * jp] = c[2 * jp + 1]; v[2 * jp + 1] = c[2 * jp]; continue; }      // ablation: no X loads
-        ld_pair_big(xres, lane_off, jp, v[2 * jp], v[2 * jp + 1]);      // loads first, asm afterwards
-      }
+      GACQ_MARK16(0);                                    // previous row's tail (reduction, code-spectrum loads)
+      dma_wait_read(v, reg);
 #pragma unroll
       for (int jj = 0; jj < kR; jj++) v[jj] = cmul(c[jj], v[jj]);
-      if (!(GACQ_ABL & 32) && (b > 0 || p > p0)) __syncthreads();          // previous transform's last LDS reads are complete
-      fft16k<true>(v, lds, twn, base);
+      GACQ_MARK16(1);
+      ifft16k_private(v, reg, tw);
+      GACQ_MARK16(2);
+      lds_barrier();
+      GACQ_MARK16(3);
+      ifft16k_gather(v, lds);
+      lds_barrier();                                     // every wave has read this region: it may be overwritten
+      GACQ_SETPRIO(GACQ_P1);
+      GACQ_MARK16(4);
+      const float2* nx = (b + 1 < B) ? xrow + (long)(b + 1) * kBig : xnext_item;
+      if (nx) dma_row(nx, reg);
+      GACQ_MARK16(5);
+      ifft16k_final(v, tw);
 #pragma unroll
       for (int k = 0; k < kR; k++) {
         const v2 r = v[rev16(k)];
         q[k] += __builtin_amdgcn_sqrtf(norm2(r)) * inv_n;
       }
+      GACQ_MARK16(6);
     }
+    xrow = xnext_item;
     float sum_f = q[0];
 #pragma unroll
     for (int k = 1; k < kR; k++) sum_f += q[k];
-    // lane l of a wave holds lags lag0 + 1024 k with lag0 = g + 4 (tl_base + l): first maximum as in lds_correlate_kernel
+    // lane l of wave w holds lags 64 w + l + 1024 k: first maximum as in lds_correlate_kernel
     float peak;
     unsigned widx;
-    wave_first_max(q, (unsigned)__builtin_amdgcn_readfirstlane(lag0), 4u, 1024u, peak, widx);
-    int idx = (int)widx;
-    double sum = (double)wave_add_f32(sum_f);
-    if ((t & 63) == 0) { s_peak[t >> 6] = peak; s_idx[t >> 6] = idx; s_sum[t >> 6] = sum; }
-    __syncthreads();
-    if (t == 0) {
-      for (int w = 1; w < kBigThreads / 64; w++) {
-        if (s_peak[w] > peak || (s_peak[w] == peak && s_idx[w] < idx)) { peak = s_peak[w]; idx = s_idx[w]; }
-        sum += s_sum[w];
-      }
-      RowRec r;
-      r.peak = peak;
-      r.idx = idx;
-      r.sum = sum;
-      rows[(e * P + p) * (long)D + d] = r;
-    }
+    wave_first_max(q, (unsigned)__builtin_amdgcn_readfirstlane(t & ~63), 1u, 1024u, peak, widx);
+    big_reduce_store(smem, peak, widx, wave_add_f32(sum_f), rows + (e * P + p) * (long)D + d);
   }
+#ifdef GACQ_PHASE_TIMING16
+  if ((t & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) if (acc16_[i]) atomicAdd(&gacq_phase16[(t >> 6) * 8 + i], acc16_[i]);
+  }
+#endif
 }
 
 // Fused search for item lists in which every item has its own carrier (F == P: the GLONASS FDMA channels, or a single
 // item): the forward spectrum of (e, f, d, b) is used by exactly one item, so writing it to HBM and reading it back
-// (8 N bytes each way per row) buys nothing.  Workgroup = (epoch, Doppler bin, item); per block b: mix + forward FFT,
-// one LDS pass back to natural lane order, conj * C_p, inverse FFT, |.| accumulated in registers.  Same arithmetic in the
-// same order as lds16k_forward_kernel + lds16k_correlate_kernel.
+// (8 N bytes each way per row) buys nothing.  Workgroup = (epoch, Doppler bin, item); per block b: mix + forward transform --
+// whose output order is the inverse transform's input order, so the spectrum stays in registers -- conj * C_p, inverse
+// transform, |.| accumulated in registers.  Three workgroup barriers per block.  Same arithmetic in the same order as
+// lds16k_forward_kernel + lds16k_correlate_kernel.
 template <bool DUMP>
 __global__ __launch_bounds__(kBigThreads) void lds16k_fused_kernel(const float2* __restrict__ x, size_t epoch_stride,
                                                                     const float2* __restrict__ C, const int* __restrict__ items,
@@ -387,9 +549,6 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_fused_kernel(const float2*
                                                                     int P, int D, int B) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v2* lds = reinterpret_cast<v2*>(smem);
-  __shared__ float s_peak[kBigThreads / 64];
-  __shared__ int s_idx[kBigThreads / 64];
-  __shared__ double s_sum[kBigThreads / 64];
   const int t = threadIdx.x;
   unsigned blk = blockIdx.x;                          // ((e*D + d)*P + p): the P items of one (e, d) run side by side
   const int p = (int)(blk % (unsigned)P);
@@ -398,10 +557,9 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_fused_kernel(const float2*
   const long e = blk / (unsigned)D;
   const double f = freq[(long)fset[p] * D + d];
   const __amdgpu_buffer_rsrc_t cres = big_rsrc(C + (long)items[p] * kBig);
-  const v2 base = ld2(twn + t);
+  v2* reg = lds + (t >> 6) * kRegion;
   const unsigned lane_off = (unsigned)t * 16u;
   const float inv_n = 1.0f / (float)kBig;
-  const int lane = (t >> 8) + 4 * (t & 255);          // natural index (mod 1024) this lane holds after a transform
   float q[kR];
 #pragma unroll
   for (int k = 0; k < kR; k++) q[k] = 0.f;
@@ -419,48 +577,36 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_fused_kernel(const float2*
     if (DUMP) return;
 #pragma unroll
     for (int j = 0; j < kR; j++) v[j] = cmul(v[j], w[j]);
-    fft16k<false>(v, lds, twn, base);
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < kR; k++) lds[lane + 1024 * k] = v[rev16(k)];
-    __syncthreads();
+    // the twiddle bases are re-read per block (three 8-byte loads, L1 hits): kept live across the block loop, the two sets cost
+    // 12 VGPRs the 128-register budget does not have
+    const float2* twp = twn;
+    asm volatile("" : "+s"(twp));
+    fft16k_fwd(v, lds, tw16k_load(twp, false));
     v2 c[kR];
 #pragma unroll
     for (int jp = 0; jp < kR / 2; jp++) ld_pair_big(cres, lane_off, jp, c[2 * jp], c[2 * jp + 1]);
+    const Tw16k twi = tw16k_load(twp, true);
 #pragma unroll
-    for (int j = 0; j < kR; j++) { const v2 a = lds[t + 1024 * j]; v[j] = v2{a.x, -a.y}; }      // np.conj(fft.fft(b))
-    __syncthreads();                                  // natural-order reads done before the inverse reuses the buffer
-#pragma unroll
-    for (int j = 0; j < kR; j++) v[j] = cmul(c[j], v[j]);
-    fft16k<true>(v, lds, twn, base);
+    for (int j = 0; j < kR; j++) v[j] = cmul(c[j], v2{v[j].x, -v[j].y});      // C_p * np.conj(fft.fft(b))
+    ifft16k_private(v, reg, twi);
+    lds_barrier();
+    ifft16k_gather(v, lds);
+    lds_barrier();                                    // every wave has read this region: the next block's exchange 0 may overwrite it
+    GACQ_SETPRIO(3);
+    ifft16k_final(v, twi);
 #pragma unroll
     for (int k = 0; k < kR; k++) {
       const v2 r = v[rev16(k)];
       q[k] += __builtin_amdgcn_sqrtf(norm2(r)) * inv_n;
     }
-    __syncthreads();                                  // the inverse transform's last LDS reads are complete
   }
   float sum_f = q[0];
 #pragma unroll
   for (int k = 1; k < kR; k++) sum_f += q[k];
   float peak;
   unsigned widx;
-  wave_first_max(q, (unsigned)__builtin_amdgcn_readfirstlane(lane), 4u, 1024u, peak, widx);      // lane l of the wave: lags lane + 4 l + 1024 k
-  int idx = (int)widx;
-  double sum = (double)wave_add_f32(sum_f);
-  if ((t & 63) == 0) { s_peak[t >> 6] = peak; s_idx[t >> 6] = idx; s_sum[t >> 6] = sum; }
-  __syncthreads();
-  if (t == 0) {
-    for (int w = 1; w < kBigThreads / 64; w++) {
-      if (s_peak[w] > peak || (s_peak[w] == peak && s_idx[w] < idx)) { peak = s_peak[w]; idx = s_idx[w]; }
-      sum += s_sum[w];
-    }
-    RowRec r;
-    r.peak = peak;
-    r.idx = idx;
-    r.sum = sum;
-    rows[(e * P + p) * (long)D + d] = r;
-  }
+  wave_first_max(q, (unsigned)__builtin_amdgcn_readfirstlane(t & ~63), 1u, 1024u, peak, widx);      // lane l of wave w: lags 64 w + l + 1024 k
+  big_reduce_store(smem, peak, widx, wave_add_f32(sum_f), rows + (e * P + p) * (long)D + d);
 }
 
 // ---- inner transforms of the split engine (N = R * 4096, gacq_split.hip) -----------------------------
@@ -840,6 +986,17 @@ namespace gacq {
 
 bool lds_supported(int N) { return N == kLdsN || N == kBig; }
 
+#ifdef GACQ_PHASE_TIMING16
+extern "C" int gacq_debug_phase16(unsigned long long* out128, int reset) {
+  if (hipMemcpyFromSymbol(out128, HIP_SYMBOL(gacq_phase16), sizeof(unsigned long long) * 128) != hipSuccess) return GACQ_ERR_HIP;
+  if (reset) {
+    unsigned long long z[128] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(gacq_phase16), z, sizeof z) != hipSuccess) return GACQ_ERR_HIP;
+  }
+  return GACQ_OK;
+}
+#endif
+
 int lds_prepare_spectra(gacq_ctx* ctx, const float2* natural, float2* perm, int nprn, int N) {
   if (!lds_supported(N)) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "LDS FFT engine: N=%d not supported", N);
   if (N == kBig) {
@@ -948,15 +1105,22 @@ int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const i
     const float2* twn;
     int rcb = twiddle_cache(ctx, "W16384_lo", kBig, 1024, &twn);
     if (rcb != GACQ_OK) return rcb;
-    // one 1024-thread workgroup per CU: keep >= ~1024 workgroups, at most 8 items per group
-    const long rows_total = (long)nepoch * nitems * D;
-    int pch = (int)std::max<long>(1, std::min<long>(8, rows_total / 1024));
+    // One 1024-thread workgroup per CU, 32 per XCD.  Items per workgroup: about P/16, so that the ~32 workgroups resident on
+    // an XCD are 16 item chunks x 2 (epoch, Doppler) units walked side by side: two forward-spectrum sets (B x 128 KB each)
+    // stay in that XCD's 4 MB L2 while every code-spectrum row fetched serves both units, and the grid is fine-grained
+    // enough that the last round of workgroups leaves few CUs idle (B1I, 63 items x 200 bins: 3200 workgroups).
+    const long units = (long)nepoch * D;
+    int pch = std::max(1, (nitems + 15) / 16);
+    if (ctx->opt[GACQ_OPT_LDS_PCH] >= 1) pch = (int)ctx->opt[GACQ_OPT_LDS_PCH];
     pch = std::min(pch, nitems);
     const int nchunk = (nitems + pch - 1) / pch;
-    const long units8 = ((long)nepoch * D + 7) / 8;
+    int ugroup = std::max(1, std::min(32 / nchunk, 24 / std::max(1, B)));
+    if (ctx->opt[GACQ_OPT_LDS_UGROUP] >= 1) ugroup = (int)ctx->opt[GACQ_OPT_LDS_UGROUP];
+    const long units8 = (units + 7) / 8;                                 // units per XCD
+    const long groups = (units8 + ugroup - 1) / ugroup;
     GACQ_HIP(ctx, hipFuncSetAttribute((const void*)lds16k_correlate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes));
-    hipLaunchKernelGGL(lds16k_correlate_kernel, dim3((unsigned)(8 * units8 * nchunk)), dim3(kBigThreads), kBigLdsBytes, ctx->stream, X,
-                       spectra, d_items, d_fset, twn, rows, nepoch, nitems, F, D, B, pch, nchunk);
+    hipLaunchKernelGGL(lds16k_correlate_kernel, dim3((unsigned)(8 * groups * ugroup * nchunk)), dim3(kBigThreads), kBigLdsBytes, ctx->stream, X,
+                       spectra, d_items, d_fset, twn, rows, nepoch, nitems, F, D, B, pch, nchunk, ugroup);
     GACQ_HIP(ctx, hipGetLastError());
     return GACQ_OK;
   }

@@ -118,7 +118,9 @@ int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes);
                                 /*     code-spectrum row fetched serves that many correlation rows                           */
 #define GACQ_OPT_FE_GENERIC 8    /* [0] front-end: 1 = run the any-length mix + FIR kernels even for the reference's 161-tap filter     */
                                 /*     (the specialised kernels produce the same bits; this is the A/B and test switch)              */
-#define GACQ_NOPTS 9
+#define GACQ_OPT_LDS_UGROUP 9    /* [0 = auto] N = 16384 correlate kernel: (epoch, Doppler) units the workgroups resident on one XCD    */
+                                /*     walk side by side (they share those units' forward spectra and the code spectra in its L2)     */
+#define GACQ_NOPTS 10
 int gacq_set_option(gacq_ctx* ctx, int option, long value);
 int gacq_get_option(gacq_ctx* ctx, int option, long* value);
 
