@@ -161,25 +161,31 @@ def _pool_worker(task):
     return acq_oracle.search_script_blocks(name, x, it, ds, B)
 
 
-def cpu_baseline_pool(job, reps=60):
+def cpu_baseline_pool(job, runs=5, reps=12):
     """Same oracle through multiprocessing.Pool(cpu_count()) with one task per PRN and x pickled per task -- the
-    reference's own parallel harness (acquire-gps-l1.py:98-108).  Config 2 only (one signal)."""
+    reference's own parallel harness (acquire-gps-l1.py:98-108).  Config 2 only (one signal).  BASELINE.md section 4: median of
+    >= 5 timed runs after a warm-up; every run is `reps` epochs."""
     import multiprocessing as mp
     sig, items, dop, B, ds = job["sig"], job["items"], job["dop"], job["B"], job["ds"]
     cores = os.cpu_count()
     n_cells_epoch = len(items) * len(dop) * sig.nfft
     ctx = mp.get_context("fork")
+    rates = []
     with ctx.Pool(min(cores, len(items))) as pool:
         x = job["host"][0].astype(np.complex128)
-        pool.map(_pool_worker, [(sig.name, x, it, ds, B) for it in items])          # warm-up: code caches, page faults
-        t0 = time.perf_counter()
-        for r in range(reps):
-            x = job["host"][r % job["host"].shape[0]].astype(np.complex128)
-            pool.map(_pool_worker, [(sig.name, x, it, ds, B) for it in items])
-        dt = time.perf_counter() - t0
-    return {"value": reps * n_cells_epoch / dt, "unit": "cells/s", "cores": min(cores, len(items)), "kind": "port",
-            "sample": "%d epoch(s) via multiprocessing.Pool(%d).map over %d PRNs (one task per PRN, x pickled per task, like "
-                      "acquire-gps-l1.py:105-108), %.2f s" % (reps, min(cores, len(items)), len(items), dt)}
+        for _ in range(2):
+            pool.map(_pool_worker, [(sig.name, x, it, ds, B) for it in items])      # warm-up: code caches, page faults
+        t_all = time.perf_counter()
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            for r in range(reps):
+                x = job["host"][r % job["host"].shape[0]].astype(np.complex128)
+                pool.map(_pool_worker, [(sig.name, x, it, ds, B) for it in items])
+            rates.append(reps * n_cells_epoch / (time.perf_counter() - t0))
+        dt = time.perf_counter() - t_all
+    return {"value": float(np.median(rates)), "unit": "cells/s", "cores": min(cores, len(items)), "kind": "port", "runs": rates,
+            "sample": "median of %d runs of %d epoch(s) each via multiprocessing.Pool(%d).map over %d PRNs (one task per PRN, x pickled per "
+                      "task, like acquire-gps-l1.py:105-108) after 2 warm-up epochs, %.2f s in all" % (runs, reps, min(cores, len(items)), len(items), dt)}
 
 
 def pmc_passes(argv, kernel, passes, timeout_s=240):
@@ -224,6 +230,160 @@ def pmc_passes(argv, kernel, passes, timeout_s=240):
     return out
 
 
+def condense(o, wall_s):
+    """The short form of a side run's JSON line that the headline line carries under other_configs."""
+    r, sus = o["roofline"], o.get("sustained")
+    d = {"baseline_config": o["config"]["baseline_config"], "workload": o["config"]["workload"], "signals": o["config"]["signals"],
+         "value": sus["value"] if sus else o["value"], "unit": "cells/s",
+         "ms_per_step": sus["ms_per_step"] if sus else o["ms_per_step"], "steps_timed": sus["steps"] if sus else o["steps"],
+         "seconds_timed": sus["seconds"] if sus else o["ms_per_step"] * o["steps"] * 1e-3,
+         "cells_per_step": o["config"]["cells_per_step"], "cell_blocks_per_step": o["config"]["cell_blocks_per_step"],
+         "dominant_kernel": r["kernel"], "dominant_signal": r["signal"], "bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"],
+         "roofline_unit": r["unit"], "frac": r["frac"], "avg_kernel_ms": r["avg_kernel_ms"],
+         "algorithmic_per_launch": r.get("alg_bytes_per_launch", r.get("useful_flop_per_launch")),
+         "compulsory_hbm_bytes_per_launch": r.get("compulsory_bytes_per_launch"),
+         "traffic_measured_bytes_per_launch": r.get("traffic"),
+         "traffic_measured_in_this_run": bool((r.get("traffic_source") or {}).get("measured_in_this_run")),
+         "ms_per_step_by_signal": {pj["signal"]: sum(st["ms_per_step"] for st in pj["stages"].values()) for pj in o["pipeline"]["per_signal"]},
+         "wall_s": wall_s}
+    if d["traffic_measured_bytes_per_launch"] and d["compulsory_hbm_bytes_per_launch"]:
+        d["traffic_over_compulsory"] = d["traffic_measured_bytes_per_launch"] / d["compulsory_hbm_bytes_per_launch"]
+    return d
+
+
+def reference_precision(args, env, f32_value, epochs=64, seconds=1.0):
+    """The headline workload (config 2) in the reference's own arithmetic type: engine 5 keeps every value complex128 / fp64 on
+    the device (mix, rocFFT double-precision transforms, conj-multiply, magnitudes, metric).  Timed for >= `seconds`, and its
+    peaks are compared with the fp32 engine's on the same epochs (locations must be identical, metrics within 1e-5)."""
+    from gnss_dsp_tools_amd import acquire
+    dev = env["dev"]
+    job = build_jobs(CONFIGS[2], epochs, dev)[0]
+    sig, items, dop, B = job["sig"], job["items"], job["dop"], job["B"]
+    res = {}
+    peaks = {}
+    for label, which in (("f64", 5), ("f32", 0)):
+        eng = acquire.Engine(env["local_rank"], engine=which)
+        eng.use_torch_stream(dev)
+        try:
+            for _ in range(2):
+                pk = eng.search_batch_dev(sig, job["x"], items, dop, B)
+            torch.cuda.synchronize(dev)
+            peaks[label] = pk.cpu().numpy().view(acquire.PEAK_DTYPE).reshape(epochs, len(items))
+            if which == 5:
+                n, t0 = 0, time.perf_counter()
+                while time.perf_counter() - t0 < seconds:
+                    for _ in range(2):
+                        eng.search_batch_dev(sig, job["x"], items, dop, B)
+                    torch.cuda.synchronize(dev)
+                    n += 2
+                dt = time.perf_counter() - t0
+                cells = epochs * len(items) * len(dop) * sig.nfft
+                res = {"engine": "5: complex128 verification pipeline (fp64 table-NCO mix, rocFFT double-precision transforms, fp64 conj-multiply, "
+                                 "magnitudes, metric and Doppler scan), the reference's arithmetic type", "dtype": "f64",
+                       "workload": "BASELINE config 2, %d epochs/step resident in HBM" % epochs, "value": n * cells / dt, "unit": "cells/s",
+                       "ms_per_step": dt / n * 1e3, "steps_timed": n, "seconds_timed": dt, "f32_over_f64": f32_value / (n * cells / dt)}
+        finally:
+            eng.close()
+    a, b = peaks["f32"], peaks["f64"]
+    res["f32_vs_f64_on_the_same_%d_epochs" % epochs] = {
+        "searches": int(a.size), "peak_location_mismatches": int(((a["idx"] != b["idx"]) | (a["d_index"] != b["d_index"])).sum()),
+        "max_rel_metric_error": float(np.max(np.abs(a["metric"] - b["metric"]) / np.abs(b["metric"])))}
+    return res
+
+
+def emulate_ranks(args, env):
+    """PROJECTION, not a measurement (no multi-GPU node was available): every rank's share of an N-rank job is run on this one
+    GPU, one rank after the other -- the same Doppler slices ShardedSearch cuts (sharded.doppler_bounds), the same epochs (weak
+    scaling: N x EPOCHS, strong: EPOCHS), the same kernels.  Reports each slice's step time and dominant-kernel roofline
+    fraction, the slowest slice (which would pace a real step), the exchange size, and what that projects to."""
+    from gnss_dsp_tools_amd import acquire, sharded
+    dev, N = env["dev"], args.emulate_ranks
+    cfg = CONFIGS[args.config]
+    epochs = args.epochs or cfg["epochs"]
+    E_total = epochs * N if args.scaling == "weak" else epochs
+    jobs = build_jobs(cfg, E_total, dev)
+    eng = acquire.Engine(env["local_rank"], engine=args.engine)
+    eng.use_torch_stream(dev)
+    for kv in args.option:
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
+
+    def step(r, nranks, e_count):
+        for job in jobs:
+            b = sharded.doppler_bounds(len(job["dop"]), nranks)
+            dsl = job["dop"][b[r]:b[r + 1]]
+            x = job["x"][:e_count]
+            if job["family"]:
+                eng.search_family_batch_dev(job["family"], x, job["items"], dsl, job["B"])
+            else:
+                eng.search_batch_dev(job["sig"], x, job["items"], dsl, job["B"])
+
+    def timed(r, nranks, e_count, seconds=0.5):
+        for _ in range(2):
+            step(r, nranks, e_count)
+        torch.cuda.synchronize(dev)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds or n < 3:
+            step(r, nranks, e_count)
+            torch.cuda.synchronize(dev)
+            n += 1
+        return (time.perf_counter() - t0) / n
+
+    def stage_fracs(r, nranks, e_count):
+        """dominant stage (most time per step) of this slice and its roofline fraction"""
+        eng.set_profiling(True)
+        best = None
+        for job in jobs:
+            b = sharded.doppler_bounds(len(job["dop"]), nranks)
+            D_local = b[r + 1] - b[r]
+            eng.reset_stage_times()
+            for _ in range(3):
+                x = job["x"][:e_count]
+                if job["family"]:
+                    eng.search_family_batch_dev(job["family"], x, job["items"], job["dop"][b[r]:b[r + 1]], job["B"])
+                else:
+                    eng.search_batch_dev(job["sig"], x, job["items"], job["dop"][b[r]:b[r + 1]], job["B"])
+            torch.cuda.synchronize(dev)
+            st = eng.stage_times()
+            N_, P, B, F = job["sig"].nfft, job["P"], job["B"], job["F"]
+            fused16k = job["kind"] == "lds" and N_ == 16384 and F == P
+            fused4k = job["kind"] == "lds" and N_ == 4096 and not st["mix_nco"][1] and st["lds_correlate"][1] > 0
+            for sname, (tot_ms, nl) in st.items():
+                if not nl:
+                    continue
+                bound, work = stage_model(job["kind"], sname, N_, P, D_local, B, F, e_count, fused16k, fused4k)
+                if bound is None:
+                    continue
+                ms_step = tot_ms / 3
+                rate = work / (ms_step * 1e-3)
+                frac = rate / 1e12 / VALU_PEAK_TFLOPS if bound == "valu" else rate / 1e9 / HBM_PEAK_GBPS
+                if best is None or ms_step > best["ms_per_step"]:
+                    best = {"signal": job["label"], "stage": sname, "bound": bound, "ms_per_step": ms_step, "frac": frac, "D_local": D_local}
+        eng.set_profiling(False)
+        return best
+
+    cells_rank0 = lambda nranks, e: sum(e * j["P"] * len(j["dop"]) * j["sig"].nfft for j in jobs)
+    t_one = timed(0, 1, epochs)                                   # the 1-GPU reference point: whole grid, EPOCHS epochs
+    one = {"ms_per_step": t_one * 1e3, "value": cells_rank0(1, epochs) / t_one, "dominant": stage_fracs(0, 1, epochs)}
+    per_rank = []
+    for r in range(N):
+        t = timed(r, N, E_total)
+        per_rank.append({"rank": r, "ms_per_step": t * 1e3, "doppler_bins": [sharded.doppler_bounds(len(j["dop"]), N)[r + 1] - sharded.doppler_bounds(len(j["dop"]), N)[r] for j in jobs],
+                         "dominant": stage_fracs(r, N, E_total)})
+    eng.close()
+    slowest = max(p["ms_per_step"] for p in per_rank)
+    total_cells = cells_rank0(N, E_total)
+    exch = N * sum(16 * E_total * j["P"] for j in jobs)            # every rank receives N shards of 16-byte records
+    proj = total_cells / (slowest * 1e-3)
+    return {"projection": True,
+            "note": "PROJECTION, NOT A MEASUREMENT: the %d ranks' slices were run one after the other on ONE MI355X; a real step is paced by "
+                    "the slowest rank plus one all-gather of %d bytes per rank (latency-bound, overlapped with the next step)" % (N, exch),
+            "baseline_config": args.config, "workload": cfg["label"], "ranks_emulated": N, "scaling": args.scaling,
+            "epochs_per_step": E_total, "one_gpu": one, "per_rank": per_rank, "slowest_slice_ms": slowest,
+            "projected_value": proj, "unit": "cells/s", "projected_speedup_over_one_gpu": proj / one["value"],
+            "projected_efficiency": proj / one["value"] / N, "exchange_bytes_received_per_rank_per_step": exch}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -247,6 +407,12 @@ def main():
     ap.add_argument("--force-gather", action="store_true", help="run the all-gather + merge even on 1 rank (test aid)")
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the live rocprofv3 --pmc child runs that measure the dominant kernel's HBM traffic (N = 1 only; ~15 s each)")
+    ap.add_argument("--no-others", action="store_true",
+                    help="headline run only: skip the short runs of configs 3, 4, 5 and the complex128 (engine 5) leg that the default "
+                         "single-GPU config-2 run appends as other_configs / reference_precision")
+    ap.add_argument("--emulate-ranks", type=int, default=0, metavar="N",
+                    help="PROJECTION, not a measurement: on this one GPU, time every rank's slice of an N-rank job (the Doppler slices "
+                         "ShardedSearch would cut) one after the other and report the slowest slice, per-slice roofline and exchange bytes")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -260,14 +426,48 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    env = {"world": world, "rank": rank, "local_rank": local_rank, "use_dist": use_dist, "dev": dev}
 
-    from gnss_dsp_tools_amd import acquire, sharded, signals, synth
+    if args.emulate_ranks:
+        out = emulate_ranks(args, env)
+        if rank == 0:
+            print(json.dumps(out))
+        return
 
-    cfg = CONFIGS[args.config]
-    epochs = args.epochs or cfg["epochs"]
-    E_total = epochs * world if args.scaling == "weak" else epochs
+    t_start = time.perf_counter()
+    out = run(args, env)
+    # The default single-GPU headline run also measures the other BASELINE configurations (short runs of the same code path:
+    # >= 1 s timed each, dominant kernel, roofline fraction, HBM traffic measured next to the algorithmic bytes) and the
+    # headline workload in the reference's own arithmetic type (complex128, engine 5), so that the driver-recorded line
+    # carries them.
+    headline = args.config == 2 and world == 1 and args.engine == 0 and not args.no_others and not os.environ.get("GACQ_BENCH_PMC_CHILD")
+    if headline and rank == 0:
+        others = []
+        for k in (3, 4, 5):
+            a = argparse.Namespace(**vars(args))
+            a.config, a.epochs, a.steps, a.warmup, a.sustained_s, a.preroll_s = k, 0, 5, 1, 1.0, 0.2
+            a.no_cpu_baseline = a.no_latency = True
+            a.lanes = 1
+            t1 = time.perf_counter()
+            try:
+                others.append(condense(run(a, env), time.perf_counter() - t1))
+            except Exception as exc:                     # the headline line must survive a failing side run
+                others.append({"baseline_config": k, "error": repr(exc)[:300]})
+        out["other_configs"] = others
+        try:
+            out["reference_precision"] = reference_precision(args, env, out["value"])
+        except Exception as exc:
+            out["reference_precision"] = {"error": repr(exc)[:300]}
+        out["bench_wall_s"] = time.perf_counter() - t_start
+    if rank == 0:
+        print(json.dumps(out))
+    if use_dist:
+        dist.destroy_process_group()
 
-    # ---- workload: one job per signal, samples resident in HBM ------------------------------------------------------
+
+def build_jobs(cfg, E_total, dev):
+    """One job per signal of a BASELINE configuration, samples resident in HBM."""
+    from gnss_dsp_tools_amd import acquire, signals, synth
     jobs = []
     for name, items, ds, ms in cfg["jobs"]:
         family = name if isinstance(name, tuple) else None           # signals that share everything but their code tables
@@ -285,6 +485,18 @@ def main():
                      "B": B, "dop": dop, "dopplers": dop, "blocks": B, "sats": sats, "host": base, "xs": xs,
                      "x": torch.from_numpy(np.ascontiguousarray(xs)).to(dev), "F": len(flat) if sig.bias_hz else 1, "kind": engine_kind(sig.nfft),
                      "label": "+".join(family) if family else sig.name})
+    return jobs
+
+
+def run(args, env):
+    """One benchmark of one BASELINE configuration: returns the JSON line's dict (rank 0; other ranks return None)."""
+    world, rank, local_rank, use_dist, dev = env["world"], env["rank"], env["local_rank"], env["use_dist"], env["dev"]
+    from gnss_dsp_tools_amd import acquire, sharded, signals, synth
+
+    cfg = CONFIGS[args.config]
+    epochs = args.epochs or cfg["epochs"]
+    E_total = epochs * world if args.scaling == "weak" else epochs
+    jobs = build_jobs(cfg, E_total, dev)
     cells_step = sum(E_total * j["P"] * len(j["dop"]) * j["sig"].nfft for j in jobs)
     cell_blocks_step = sum(E_total * j["P"] * len(j["dop"]) * j["sig"].nfft * j["B"] for j in jobs)
 
@@ -471,6 +683,19 @@ def main():
                     "frac": achieved / HBM_PEAK_GBPS, "avg_kernel_ms": dk["avg_ms"], "alg_bytes_per_launch": work_launch,
                     "model": "bytes this kernel must move through HBM: its side of the split engine's one round trip (8 N per correlation "
                              "row), or x in + X out for the forward stage, over the kernel's HIP-event duration"}
+    # what the dominant kernel must at least move through HBM per launch (inputs once, outputs once): the yardstick for `traffic`
+    dom_job = next(j for j in jobs if j["label"] == dj["signal"])
+    rec_bytes = 16.0 * E_total * dj["P"] * dj["D_local"]
+    spectra = float(S * dj["P"] * dj["N"])
+    x_rows = float(S) * E_total * dj["F"] * dj["D_local"] * dj["B"] * dj["N"]            # forward spectra [E][F][D][B][N]
+    x_samples = float(S) * E_total * dom_job["xs"].shape[1]
+    if dk["bound"] == "hbm":
+        extra = (x_rows + spectra) if dstage == "lds_correlate" else (rec_bytes if dstage == "mag_peak" else 0.0)
+        roofline["compulsory_bytes_per_launch"] = (work_launch + extra / dk["launches_per_step"])
+    elif dj["fused_forward"]:
+        roofline["compulsory_bytes_per_launch"] = (x_samples + spectra + rec_bytes) / dk["launches_per_step"]
+    else:
+        roofline["compulsory_bytes_per_launch"] = (x_rows + spectra + rec_bytes) / dk["launches_per_step"]
     # Measured HBM traffic of the dominant kernel: rocprofv3 --pmc wraps a command, so rank 0 of a single-GPU run re-runs this
     # very command line (3 steps, no baselines) under it, one counter group per child run, and reads the kernel's FETCH_SIZE /
     # WRITE_SIZE (KiB; FETCH_SIZE doubled: on gfx950 it counts half of a wide coalesced read -- MI355X_MICROARCH.md, HBM
@@ -480,7 +705,7 @@ def main():
     under_profiler = any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ)       # never nest profilers
     if world == 1 and rank == 0 and not args.no_pmc and not under_profiler and not os.environ.get("GACQ_BENCH_PMC_CHILD"):
         child = ["--gpus", "1", "--config", str(args.config), "--epochs", str(epochs), "--steps", "3", "--warmup", "1", "--engine", str(args.engine),
-                 "--no-cpu-baseline", "--no-latency", "--sustained-s", "0", "--preroll-s", "0", "--no-pmc", "--lanes", str(args.lanes)]
+                 "--no-cpu-baseline", "--no-latency", "--sustained-s", "0", "--preroll-s", "0", "--no-pmc", "--no-others", "--lanes", str(args.lanes)]
         for kv in args.option:
             child += ["--option", kv]
         if args.no_self_check:
@@ -614,12 +839,12 @@ def main():
                     out["cpu_baseline_pool"] = {"error": repr(exc)}
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+    else:
+        out = None
     for _, e2, _ in lanes:
         e2.close()
     eng.close()
-    if use_dist:
-        dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":
