@@ -50,9 +50,11 @@ struct gacq_ctx {
   int engine = 0;
   size_t ws_limit = (size_t)4 << 30;
   std::map<std::pair<long, long>, gacq::FftPlan> plans;   // (N * 2 + inverse, batch)
-  gacq::DevBuf tab, xstage, X, Y, rows, freq, fset, items, out_peaks, d0, partial, fe_a, fe_b, fe_taps, chunk_peaks;
-  long opt[GACQ_NOPTS] = {1, 1, -1, 0, 0, 0, 1, 0, 0, 0};   // gacq_set_option values (defaults documented in include/gacq.h)
+  gacq::DevBuf tab, xstage, X, Y, rows, freq, fset, items, out_peaks, d0, partial, fe_a, fe_b, fe_taps, chunk_peaks, arrivals;
+  long opt[GACQ_NOPTS] = {1, 1, -1, 0, 0, 0, 1, 0, 0, 0, 0, 1};   // gacq_set_option values (defaults documented in include/gacq.h)
   gacq::DevBuf pin_x, pin_peaks;       // pinned host staging for the host-buffer entry point (gacq_search)
+  gacq::DevBuf bar_x;                  // fine-grained device memory the host writes directly through the PCIe BAR (small gacq_search inputs)
+  bool large_bar = false;              // hipDeviceProp_t.isLargeBar: device memory is host-addressable
   gacq::BatchRing* ring = nullptr;     // staging ring of gacq_search_batch / gacq_group_search_batch, created on first use
   bool profiling = false;
   double stage_ms[GACQ_NSTAGES] = {0};
@@ -108,8 +110,13 @@ int lds_fused_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, i
                      const int* d_fset, const double* d_freq, const float2* tab, int nitems, int D, int B, RowRec* rows);
 // N = 4096, B == 1, one carrier: forward + correlate in one kernel, no X buffer
 bool lds_fused4k_supported(const gacq_ctx* ctx, int N, int B, int F, long units);
+// arrivals != nullptr: single-launch search -- the Doppler scan runs inside the kernel (last workgroup of every item) and the peak
+// records go to `peaks`; arrivals = nepoch * nitems zeroed counters, left zeroed
 int lds_fused4k_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, const float2* spectra, const int* d_items,
-                       const double* d_freq, const float2* tab, int nitems, int D, RowRec* rows);
+                       const double* d_freq, const float2* tab, int nitems, int D, RowRec* rows, unsigned* arrivals = nullptr,
+                       gacq_peak* peaks = nullptr, int normalised = 0);
+// the single-launch form pays for small batches only (every workgroup resident at once)
+bool lds_search1_supported(const gacq_ctx* ctx, int N, int B, int F, long units, int nitems);
 int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const int* d_items, const int* d_fset,
                   int nepoch, int nitems, int F, int D, int B, int N, RowRec* rows);
 

@@ -22,6 +22,7 @@ using namespace gacq;
 
 namespace {
 constexpr size_t kPinnedStageMax = 1u << 20;     // host inputs up to 1 MiB are staged through pinned memory
+constexpr size_t kBarWriteMax = 1u << 18;        // host inputs up to 256 KiB are written straight into device memory through the BAR
 thread_local std::string g_last_error;     // last error of calls made without a ctx, per calling thread
 std::once_flag g_rocfft_once;
 const char* kStageNames[GACQ_NSTAGES] = {"mix_nco", "rocfft_forward", "conj_mul", "rocfft_inverse",
@@ -366,6 +367,10 @@ int gacq_create(int device_id, gacq_ctx** out) {
     return set_error(nullptr, GACQ_ERR_HIP, "gacq_create: cannot create stream on device %d", device_id);
   }
   ctx->stream = ctx->own_stream;
+  {
+    hipDeviceProp_t prop;
+    ctx->large_bar = hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.isLargeBar != 0;
+  }
   // NCO phasor table: np.exp(2*pi*1j*k/1024) evaluated in fp64, rounded once to fp32 (gnsstools/nco.py:4)
   std::vector<float2> tab(kNcoTableSize);
   for (int k = 0; k < kNcoTableSize; k++) {
@@ -391,10 +396,11 @@ void gacq_destroy(gacq_ctx* ctx) {
     if (kv.second.work) (void)hipFree(kv.second.work);
   }
   for (auto& ev : ctx->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-  DevBuf* bufs[] = {&ctx->tab, &ctx->xstage, &ctx->X, &ctx->Y, &ctx->rows, &ctx->freq, &ctx->fset, &ctx->items, &ctx->out_peaks, &ctx->d0, &ctx->partial, &ctx->fe_a, &ctx->fe_b, &ctx->fe_taps, &ctx->chunk_peaks};
+  DevBuf* bufs[] = {&ctx->tab, &ctx->xstage, &ctx->X, &ctx->Y, &ctx->rows, &ctx->freq, &ctx->fset, &ctx->items, &ctx->out_peaks, &ctx->d0, &ctx->partial, &ctx->fe_a, &ctx->fe_b, &ctx->fe_taps, &ctx->chunk_peaks, &ctx->arrivals};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   if (ctx->pin_x.p) (void)hipHostFree(ctx->pin_x.p);
   if (ctx->pin_peaks.p) (void)hipHostFree(ctx->pin_peaks.p);
+  if (ctx->bar_x.p) (void)hipFree(ctx->bar_x.p);
   for (auto& kv : ctx->tables) if (kv.second.p) (void)hipFree(kv.second.p);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -674,8 +680,14 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
   const bool fused16k = use_lds && lds_fused_supported(ctx, N, P, F);      // one carrier per item: no forward-spectra buffer at all
   const size_t x_epoch_bytes = sizeof(float2) * (size_t)F * D * B * N;
   int Ec = (int)std::max<size_t>(1, std::min<size_t>((size_t)nepoch, ctx->ws_limit / std::max<size_t>(1, x_epoch_bytes)));
-  const bool fused4k = use_lds && !fused16k && lds_fused4k_supported(ctx, N, B, F, (long)nepoch * D);
+  const bool search1 = use_lds && !fused16k && lds_search1_supported(ctx, N, B, F, (long)nepoch * D, P);      // whole search in one launch
+  const bool fused4k = search1 || (use_lds && !fused16k && lds_fused4k_supported(ctx, N, B, F, (long)nepoch * D));
   if (fused16k || fused4k) Ec = nepoch;            // nothing but the 16-byte row records is buffered
+  if (search1) {
+    const void* before_arr = ctx->arrivals.p;
+    if ((rc = ensure(ctx, ctx->arrivals, sizeof(unsigned) * (size_t)nepoch * P)) != GACQ_OK) return rc;
+    if (before_arr != ctx->arrivals.p) GACQ_HIP(ctx, hipMemsetAsync(ctx->arrivals.p, 0, ctx->arrivals.cap, st));      // the kernel leaves them zeroed
+  }
   if (!fused16k && !fused4k && (rc = ensure(ctx, ctx->X, x_epoch_bytes * Ec)) != GACQ_OK) return rc;
   if ((rc = ensure(ctx, ctx->rows, sizeof(RowRec) * (size_t)Ec * P * D)) != GACQ_OK) return rc;
 
@@ -694,9 +706,11 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
       if (rc != GACQ_OK) return rc;
     } else if (fused4k) {
       stage_begin(ctx, 6);
-      rc = lds_fused4k_search(ctx, xe, nsamp, ne, sig->spectra_lds, (const int*)ctx->items.p, (const double*)ctx->freq.p, (const float2*)ctx->tab.p, P, D, rows);
+      rc = lds_fused4k_search(ctx, xe, nsamp, ne, sig->spectra_lds, (const int*)ctx->items.p, (const double*)ctx->freq.p, (const float2*)ctx->tab.p, P, D, rows,
+                              search1 ? (unsigned*)ctx->arrivals.p : nullptr, search1 ? d_out + (size_t)e0 * P : nullptr, ds.metric_mode);
       stage_end(ctx);
       if (rc != GACQ_OK) return rc;
+      if (search1) continue;                       // the Doppler scan ran inside the kernel
     } else if (use_lds) {
       stage_begin(ctx, 0);
       rc = lds_forward(ctx, xe, nsamp, ne, n, N, (const double*)ctx->freq.p, F * D, B, (const float2*)ctx->tab.p, X);
@@ -841,7 +855,8 @@ int gacq_search_batch_dev(gacq_sig* sig, const void* d_x, size_t nsamp, int nepo
     F = (int)seen.size();
   }
   const size_t bin_bytes = (ctx->engine == 5 ? sizeof(double2) : sizeof(float2)) * (size_t)F * blocks * sig->N;
-  const bool no_x = (ctx->engine == 0 || ctx->engine == 2) && (lds_fused_supported(ctx, sig->N, nitems, F) || lds_fused4k_supported(ctx, sig->N, blocks, F, (long)nepoch * nd));
+  const bool no_x = (ctx->engine == 0 || ctx->engine == 2) && (lds_fused_supported(ctx, sig->N, nitems, F) || lds_fused4k_supported(ctx, sig->N, blocks, F, (long)nepoch * nd) ||
+                                                                 lds_search1_supported(ctx, sig->N, blocks, F, (long)nepoch * nd, nitems));
   if (!no_x && nd > 1 && bin_bytes * nd > ctx->ws_limit) {
     const int Dc = (int)std::max<size_t>(1, ctx->ws_limit / bin_bytes);
     const int nch = (nd + Dc - 1) / Dc;
@@ -937,20 +952,40 @@ int gacq_search(gacq_sig* sig, const float* x_iq, size_t nsamp, const int* items
   GACQ_DEVICE(ctx);
   const size_t need = (size_t)(blocks + (sig->desc.pad ? 1 : 0)) * sig->desc.n;      // <= nsamp (check_search_args)
   const size_t take = need;
-  if ((rc = ensure(ctx, ctx->xstage, sizeof(float2) * take)) != GACQ_OK) return rc;
   if ((rc = ensure_pinned(ctx, ctx->pin_peaks, sizeof(gacq_peak) * nitems)) != GACQ_OK) return rc;
-  // Small inputs go through a pinned staging buffer (one host memcpy, then a true async DMA); a pageable hipMemcpyAsync
-  // stages internally and costs ~10 us more per call.  Large inputs are copied directly.
   const size_t xbytes = sizeof(float2) * need;
-  const void* src = x_iq;
-  if (xbytes <= kPinnedStageMax) {
-    if ((rc = ensure_pinned(ctx, ctx->pin_x, xbytes)) != GACQ_OK) return rc;
-    std::memcpy(ctx->pin_x.p, x_iq, xbytes);
-    src = ctx->pin_x.p;
+  const void* d_x = nullptr;
+  if (ctx->large_bar && xbytes <= kBarWriteMax && ctx->opt[GACQ_OPT_BAR_UPLOAD]) {
+    // Small inputs (a 1 ms GPS L1 block is 32 KB): the host writes them straight into fine-grained device memory through the PCIe
+    // BAR -- one write-combined memcpy (~1 us for 32 KB), no staging copy, no DMA engine (a 32 KB pinned H2D costs ~7 us of
+    // latency in front of the kernels).  The doorbell write of the kernel launch is ordered after these stores.  This call is
+    // synchronous, so the buffer is never rewritten while a kernel still reads it.
+    if (xbytes > ctx->bar_x.cap) {
+      if (ctx->bar_x.p) { GACQ_HIP(ctx, hipDeviceSynchronize()); GACQ_HIP(ctx, hipFree(ctx->bar_x.p)); ctx->bar_x.p = nullptr; ctx->bar_x.cap = 0; }
+      const size_t want = std::max<size_t>(xbytes + xbytes / 8, 65536);
+      if (hipExtMallocWithFlags(&ctx->bar_x.p, want, hipDeviceMallocFinegrained) == hipSuccess) ctx->bar_x.cap = want;
+      else { (void)hipGetLastError(); ctx->bar_x.p = nullptr; ctx->large_bar = false; }      // fall back to the staged copy for good
+    }
+    if (ctx->bar_x.p) {
+      std::memcpy(ctx->bar_x.p, x_iq, xbytes);
+      d_x = ctx->bar_x.p;
+    }
   }
-  GACQ_HIP(ctx, hipMemcpyAsync(ctx->xstage.p, src, xbytes, hipMemcpyHostToDevice, ctx->stream));
+  if (!d_x) {
+    // Staged path: small inputs go through a pinned staging buffer (one host memcpy, then a true async DMA); a pageable
+    // hipMemcpyAsync stages internally and costs ~10 us more per call.  Large inputs are copied directly.
+    if ((rc = ensure(ctx, ctx->xstage, sizeof(float2) * take)) != GACQ_OK) return rc;
+    const void* src = x_iq;
+    if (xbytes <= kPinnedStageMax) {
+      if ((rc = ensure_pinned(ctx, ctx->pin_x, xbytes)) != GACQ_OK) return rc;
+      std::memcpy(ctx->pin_x.p, x_iq, xbytes);
+      src = ctx->pin_x.p;
+    }
+    GACQ_HIP(ctx, hipMemcpyAsync(ctx->xstage.p, src, xbytes, hipMemcpyHostToDevice, ctx->stream));
+    d_x = ctx->xstage.p;
+  }
   // the Doppler scan writes its 16-byte records straight into device-visible pinned host memory: no D2H copy
-  rc = gacq_search_batch_dev(sig, ctx->xstage.p, take, 1, items, nitems, dopplers, nd, item_bias_hz, blocks, ctx->pin_peaks.p);
+  rc = gacq_search_batch_dev(sig, d_x, take, 1, items, nitems, dopplers, nd, item_bias_hz, blocks, ctx->pin_peaks.p);
   if (rc != GACQ_OK) return rc;
   GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return gacq_finalize(&sig->desc, (const gacq_peak*)ctx->pin_peaks.p, 1, nullptr, nitems, dopplers, nd, out);

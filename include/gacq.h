@@ -120,7 +120,13 @@ int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes);
                                 /*     (the specialised kernels produce the same bits; this is the A/B and test switch)              */
 #define GACQ_OPT_LDS_UGROUP 9    /* [0 = auto] N = 16384 correlate kernel: (epoch, Doppler) units the workgroups resident on one XCD    */
                                 /*     walk side by side (they share those units' forward spectra and the code spectra in its L2)     */
-#define GACQ_NOPTS 10
+#define GACQ_OPT_SEARCH1 10       /* [0] N = 4096, B = 1, one carrier, small batches (<= 4096 rows): the whole search -- mix, forward        */
+                                /*     transform, correlation, Doppler scan -- in ONE kernel launch.  Off by default: measured slower      */
+                                /*     than the three short launches for one epoch (21.8 us of kernel against 6.8 + 12.3 + 6.5 us that     */
+                                /*     overlap their launch latencies; profiles/r03_single_search_latency.log)                            */
+#define GACQ_OPT_BAR_UPLOAD 11    /* [1] gacq_search: inputs up to 256 KiB are written by the host straight into fine-grained device       */
+                                /*     memory through the PCIe BAR (large-BAR devices) instead of pinned staging + DMA                  */
+#define GACQ_NOPTS 12
 int gacq_set_option(gacq_ctx* ctx, int option, long value);
 int gacq_get_option(gacq_ctx* ctx, int option, long* value);
 

@@ -1039,6 +1039,106 @@ def test_fused_4096_kernel_equals_two_kernel_path(engine):
         engine.set_profiling(False)
 
 
+@pytest.mark.parametrize("cid", ["cfg1_gps_l1_prn1", "cfg2_gps_l1_all32", "edge_fractional_grid"])      # the B = 1 goldens of N = 4096
+@pytest.mark.parametrize("search1", [0, 1])
+def test_fused_4096_bench_kernel_matches_reference_golden(engine, golden_cases, cid, search1):
+    """The kernel the headline bench line times (lds_fused4k_kernel<4, true, false>; auto-selected only for batches of >= 1024
+    units) held to the reference's own outputs directly: option fused_4k = 2 forces it for these single-epoch golden cases
+    (search1 = 0), and the stage timers prove that it ran -- no separate forward launch, but a Doppler-scan launch.  search1 = 1 is
+    the single-launch instantiation of the same kernel (option search1, off by default): no Doppler-scan launch either."""
+    case = golden_cases[cid]
+    x = case_iq(case)
+    try:
+        engine.set_engine(2)
+        engine.set_option("fused_4k", 2)
+        engine.set_option("search1", search1)
+        engine.set_profiling(True)
+        engine.reset_stage_times()
+        got = engine.search_all(case["script"], x, case["items"], case["doppler_search"], case["ms"])
+        st = engine.stage_times()
+        assert st["mix_nco"][1] == 0 and st["lds_correlate"][1] >= 1, st
+        assert st["best_doppler"][1] == (0 if search1 else 1), st
+    finally:
+        engine.set_profiling(False)
+        engine.set_option("fused_4k", 1)
+        engine.set_option("search1", 0)
+        engine.set_engine(0)
+    _assert_results(got, case["results"], case)
+
+
+def test_single_launch_search_equals_the_three_kernel_path_bit_for_bit(engine):
+    """Option search1: small N = 4096 searches as ONE kernel (mix, forward transform, correlation and the Doppler scan by the last workgroup of
+    every item, records handed over with agent-scope stores/loads and an arrival counter).  The peak records must equal those of
+    forward + correlate + best_doppler byte for byte -- for one and several epochs, one and many items, repeated calls (the
+    counters are left zeroed) and noise-only inputs (near-tied Doppler bins)."""
+    import torch
+    from gnss_dsp_tools_amd import acquire, signals, synth
+    sig = signals.get("gps-l1")
+    dop = acquire.doppler_grid([-5000.0, 5000.0, 250.0])
+    for E, items, sats in ((1, list(range(1, 33)), None), (3, list(range(1, 33)), None), (1, [7], None), (2, [3, 3, 9], None), (1, list(range(1, 33)), [])):
+        xs = synth.make_epochs(sig, 1, 4242 + E, synth.default_sats(items) if sats is None else sats, E, nsamp=4096)
+        xd = torch.from_numpy(xs).cuda()
+        try:
+            engine.set_option("search1", 0)
+            want = engine.search_batch_dev(sig, xd, items, dop, 1)
+            torch.cuda.synchronize()
+            want = want.cpu().numpy().tobytes()
+            engine.set_option("search1", 1)
+            engine.set_profiling(True)
+            for rep in range(3):
+                engine.reset_stage_times()
+                got = engine.search_batch_dev(sig, xd, items, dop, 1)
+                torch.cuda.synchronize()
+                st = engine.stage_times()
+                assert st["best_doppler"][1] == 0 and st["mix_nco"][1] == 0 and st["lds_correlate"][1] == 1, st
+                assert got.cpu().numpy().tobytes() == want, (E, items, rep)
+        finally:
+            engine.set_profiling(False)
+            engine.set_option("search1", 0)
+
+
+FULL_SIZE_JOBS = [  # BASELINE.json configs 2-5 (SURVEY.md 8d): signal, items, Doppler search, blocks
+    ("cfg2", "gps-l1", list(range(1, 33)), [-5000.0, 5000.0, 250.0], 1),
+    ("cfg3", "galileo-e1b", list(range(1, 37)), [-4000.0, 4000.0, 125.0], 1),
+    ("cfg3", "galileo-e1c", list(range(1, 37)), [-4000.0, 4000.0, 125.0], 1),
+    ("cfg4", "gps-l5i", list(range(1, 33)), [-7000.0, 7000.0, 200.0], 1),
+    ("cfg4", "beidou-b2ad", list(range(1, 64)), [-7000.0, 7000.0, 200.0], 1),
+    ("cfg5", "gps-l1", list(range(1, 33)), [-10000.0, 10000.0, 100.0], 10),
+    ("cfg5", "galileo-e1b", list(range(1, 51)), [-10000.0, 10000.0, 100.0], 1),
+    ("cfg5", "beidou-b1i", list(range(1, 64)), [-10000.0, 10000.0, 100.0], 10),
+    ("cfg5", "glonass-l1", list(range(-7, 8)), [-10000.0, 10000.0, 100.0], 10),
+]
+
+
+@pytest.mark.parametrize("cfg,name,items,ds,B", FULL_SIZE_JOBS, ids=["%s-%s" % (j[0], j[1]) for j in FULL_SIZE_JOBS])
+def test_full_size_configs_agree_with_the_complex128_pipeline(engine, cfg, name, items, ds, B):
+    """Every BASELINE configuration at its FULL size (all items, the whole Doppler grid, every block), two seeded epochs, through
+    the default fp32 engines and through engine 5 (complex128 on the device, itself held to the reference's goldens at 1e-10):
+    identical peak locations -- a different location only passes as a near-tie when the two metrics agree to 1e-6 -- and metrics
+    within 2e-6 (north_star's bar is 1e-5).  The numpy oracle cannot do these sizes in test time."""
+    import torch
+    from gnss_dsp_tools_amd import acquire, signals, synth
+    sig = signals.get(name)
+    dop = acquire.doppler_grid(ds)
+    xs = synth.make_epochs(sig, B, 31337, synth.default_sats(items), 2, nsamp=sig.samples_needed(B))
+    xd = torch.from_numpy(xs).cuda()
+    engine.set_engine(0)
+    a = engine.search_batch_dev(sig, xd, items, dop, B)
+    torch.cuda.synchronize()
+    pa = a.cpu().numpy().view(acquire.PEAK_DTYPE).reshape(-1).copy()
+    try:
+        engine.set_engine(5)
+        c = engine.search_batch_dev(sig, xd, items, dop, B)
+        torch.cuda.synchronize()
+    finally:
+        engine.set_engine(0)
+    pc = c.cpu().numpy().view(acquire.PEAK_DTYPE).reshape(-1)
+    rel = np.abs(pa["metric"] - pc["metric"]) / np.abs(pc["metric"])
+    same = (pa["idx"] == pc["idx"]) & (pa["d_index"] == pc["d_index"])
+    assert int((~same & (rel >= 1e-6)).sum()) == 0, (cfg, name, np.flatnonzero(~same)[:8])
+    assert float(rel[same].max()) <= 2e-6, (cfg, name, float(rel[same].max()))
+
+
 @pytest.mark.parametrize("cid", ["cfg4_l5i_subset", "gal_e6b", "bds_b2bq"])
 @pytest.mark.parametrize("teams", [1, 2, 4])
 def test_stockham_inner_kernel_teams_match_reference_golden(engine, golden_cases, cid, teams):
