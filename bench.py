@@ -408,7 +408,7 @@ def main():
                     help="skip the single-epoch host-call latency probe (profiling runs: keeps every launch the bench workload)")
     ap.add_argument("--sustained-s", type=float, default=1.5, help="length of the second, sustained timed region (0 = skip)")
     ap.add_argument("--preroll-s", type=float, default=0.3, help="untimed load before the warm-up steps so the GPU has clocked up (0 = none)")
-    ap.add_argument("--no-self-check", action="store_true", help="ablation builds compute garbage on purpose (tools/ablate.sh)")
+    ap.add_argument("--no-self-check", action="store_true", help="variant builds that compute garbage on purpose (tools/build_variant.sh)")
     ap.add_argument("--force-gather", action="store_true", help="run the all-gather + merge even on 1 rank (test aid)")
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the live rocprofv3 --pmc child runs that measure the dominant kernel's HBM traffic (N = 1 only; ~15 s each)")
@@ -831,7 +831,7 @@ def run(args, env):
                          "us_per_search": dt / args.steps / E_total * 1e6, "cell_blocks_per_s": cell_blocks_step * args.steps / dt,
                          "per_signal": per_job},
         }
-        if args.config == 2:            # keep the flat stage table of the single-signal line (tools/ab_variants.sh, profiles/)
+        if args.config == 2:            # keep the flat stage table of the single-signal line (profiles/)
             out["pipeline"]["stages"] = per_job[0]["stages"]
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(jobs)

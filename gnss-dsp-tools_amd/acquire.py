@@ -225,7 +225,8 @@ class Engine:
         s, idx, bias = self._plan(sig, items)
         dopplers = np.ascontiguousarray(dopplers, dtype=np.float64)
         blocks = max(int(blocks), 0)                    # range(negative) is empty in the reference
-        need = sig.samples_needed(blocks)
+        # an empty Doppler grid: the reference's loop body never runs, x is never looked at (acquire-gps-l1.py:25-26,40)
+        need = sig.samples_needed(blocks) if len(dopplers) else 0
         x = np.asarray(x)
         if x.ndim != 1:
             raise ValueError("x must be a 1-D complex array")
@@ -356,7 +357,7 @@ class Engine:
         s, idx, bias = self._plan(sig, items)
         dopplers = np.ascontiguousarray(dopplers, dtype=np.float64)
         blocks = max(int(blocks), 0)
-        if xs.shape[1] < sig.samples_needed(blocks):
+        if len(dopplers) and xs.shape[1] < sig.samples_needed(blocks):      # an empty grid never touches the samples
             raise ValueError("operands could not be broadcast together: search needs %d samples per epoch, xs has %d" % (sig.samples_needed(blocks), xs.shape[1]))
         res = (nat.Result * (xs.shape[0] * len(idx)))()
         nat.check(nat.lib.gacq_search_batch(
@@ -456,7 +457,7 @@ class DeviceGroup:
         h = self._signal(sig, prns)
         dopplers = np.ascontiguousarray(dopplers, dtype=np.float64)
         blocks = max(int(blocks), 0)
-        if xs.shape[1] < sig.samples_needed(blocks):
+        if len(dopplers) and xs.shape[1] < sig.samples_needed(blocks):      # an empty grid never touches the samples
             raise ValueError("operands could not be broadcast together: search needs %d samples per epoch, xs has %d" % (sig.samples_needed(blocks), xs.shape[1]))
         res = (nat.Result * (xs.shape[0] * len(idx)))()
         self._check(nat.lib.gacq_group_search_batch(

@@ -11,13 +11,7 @@ typedef float v2 __attribute__((ext_vector_type(2)));
 
 // |z|^2 as one multiply and one FMA.  Written as x*x + y*y, hipcc's SLP vectoriser emits v_pk_mul_f32 + v_add_f32: 6 issue cycles
 // instead of 4 on a part where a packed-f32 instruction costs two plain ones.
-__device__ __forceinline__ float norm2(v2 r) {
-#ifdef GACQ_NORM2_PACKED
-  return r.x * r.x + r.y * r.y;
-#else
-  return __builtin_fmaf(r.y, r.y, r.x * r.x);
-#endif
-}
+__device__ __forceinline__ float norm2(v2 r) { return __builtin_fmaf(r.y, r.y, r.x * r.x); }
 
 // a + i*b = (a.re - b.im, a.im + b.re)
 __device__ __forceinline__ v2 add_i(v2 a, v2 b) {

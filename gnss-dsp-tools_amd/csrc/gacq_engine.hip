@@ -629,6 +629,25 @@ Grid make_grid(const gacq_sigdesc& d, int nitems, const double* dopplers, int nd
   return g;
 }
 
+// Which kernels of the LDS-resident engine serve a search -- decided in ONE place for the launch sequence (launch_search) and for
+// the Doppler-slicing decision of gacq_search_batch_dev, which must know whether a forward-spectra buffer exists at all.
+struct LdsPath {
+  bool use_lds = false;      // whole transform in one workgroup (engine 2, or auto where the length is supported)
+  bool fused16k = false;     // N = 16384, one carrier per item: forward + correlate in one kernel
+  bool search1 = false;      // N = 4096, small batch: the whole search, Doppler scan included, in one launch
+  bool fused4k = false;      // N = 4096, B = 1, one carrier: forward + correlate in one kernel (search1 implies it)
+  bool no_forward_buffer() const { return fused16k || fused4k; }
+};
+LdsPath lds_path(const gacq_ctx* ctx, int N, int nepoch, int P, int F, int D, int B, bool row_dump) {
+  LdsPath p;
+  p.use_lds = (ctx->engine == 2) || (ctx->engine == 0 && lds_supported(N) && !row_dump);
+  if (!p.use_lds || !lds_supported(N) || row_dump) return p;
+  p.fused16k = lds_fused_supported(ctx, N, P, F);
+  p.search1 = !p.fused16k && lds_search1_supported(ctx, N, B, F, (long)nepoch * D, P);
+  p.fused4k = p.search1 || (!p.fused16k && lds_fused4k_supported(ctx, N, B, F, (long)nepoch * D));
+  return p;
+}
+
 int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, const int* items, int nitems,
                   const double* dopplers, int nd, const double* bias, int blocks, gacq_peak* d_out, float* d_qrow) {
   gacq_ctx* ctx = sig->ctx;
@@ -664,7 +683,8 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
 
   if (ctx->engine == 5) return verify_search(sig, d_x, nsamp, nepoch, P, F, D, B, d_out, d_qrow);      // complex128 verification pipeline
 
-  const bool use_lds = (ctx->engine == 2) || (ctx->engine == 0 && lds_supported(N) && !d_qrow);      // whole transform in one workgroup
+  const LdsPath path = lds_path(ctx, N, nepoch, P, F, D, B, d_qrow != nullptr);
+  const bool use_lds = path.use_lds;
   if (ctx->engine == 2 && (!lds_supported(N) || d_qrow))
     return set_error(ctx, GACQ_ERR_UNSUPPORTED, "engine 2 (LDS FFT) does not support N=%d%s", N, d_qrow ? " with row dump" : "");
   const int R = split_radix(N);
@@ -677,11 +697,10 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
     return set_error(ctx, GACQ_ERR_UNSUPPORTED, "engine 3 (split with rocFFT inner transforms) does not support N=%d", N);
 
   // epochs per pass so that the forward-spectra buffer respects the workspace limit
-  const bool fused16k = use_lds && lds_fused_supported(ctx, N, P, F);      // one carrier per item: no forward-spectra buffer at all
+  const bool fused16k = path.fused16k;      // one carrier per item: no forward-spectra buffer at all
   const size_t x_epoch_bytes = sizeof(float2) * (size_t)F * D * B * N;
   int Ec = (int)std::max<size_t>(1, std::min<size_t>((size_t)nepoch, ctx->ws_limit / std::max<size_t>(1, x_epoch_bytes)));
-  const bool search1 = use_lds && !fused16k && lds_search1_supported(ctx, N, B, F, (long)nepoch * D, P);      // whole search in one launch
-  const bool fused4k = search1 || (use_lds && !fused16k && lds_fused4k_supported(ctx, N, B, F, (long)nepoch * D));
+  const bool search1 = path.search1, fused4k = path.fused4k;
   if (fused16k || fused4k) Ec = nepoch;            // nothing but the 16-byte row records is buffered
   if (search1) {
     const void* before_arr = ctx->arrivals.p;
@@ -816,7 +835,7 @@ int check_search_args(gacq_sig* sig, const void* x, size_t nsamp, int nepoch, co
   for (int k = 0; k < nd; k++)
     if (!std::isfinite(dopplers[k])) return set_error(ctx, GACQ_ERR_BAD_ARG, "search: Doppler value %d is not finite", k);
   const size_t need = (size_t)(blocks + (sig->desc.pad ? 1 : 0)) * sig->desc.n;
-  if (blocks > 0 && nsamp < need)
+  if (blocks > 0 && nd > 0 && nsamp < need)              // an empty Doppler grid never touches x (acquire-gps-l1.py:25-26,40)
     return set_error(ctx, GACQ_ERR_SHORT_INPUT, "search: %zu samples given, %zu needed for %d block(s) of n=%d%s", nsamp, need, blocks,
                      sig->desc.n, sig->desc.pad ? " (padded: windows span 2n)" : "");
   return GACQ_OK;
@@ -855,8 +874,7 @@ int gacq_search_batch_dev(gacq_sig* sig, const void* d_x, size_t nsamp, int nepo
     F = (int)seen.size();
   }
   const size_t bin_bytes = (ctx->engine == 5 ? sizeof(double2) : sizeof(float2)) * (size_t)F * blocks * sig->N;
-  const bool no_x = (ctx->engine == 0 || ctx->engine == 2) && (lds_fused_supported(ctx, sig->N, nitems, F) || lds_fused4k_supported(ctx, sig->N, blocks, F, (long)nepoch * nd) ||
-                                                                 lds_search1_supported(ctx, sig->N, blocks, F, (long)nepoch * nd, nitems));
+  const bool no_x = lds_path(ctx, sig->N, nepoch, nitems, F, nd, blocks, false).no_forward_buffer();
   if (!no_x && nd > 1 && bin_bytes * nd > ctx->ws_limit) {
     const int Dc = (int)std::max<size_t>(1, ctx->ws_limit / bin_bytes);
     const int nch = (nd + Dc - 1) / Dc;

@@ -93,6 +93,14 @@ int ring_submit(gacq_sig* sig, BatchRing* r, int slot, const void* src, size_t n
   return GACQ_OK;
 }
 
+// Error paths: a call that fails after its first submit leaves chunks in flight on the copy and compute streams, and the next
+// call would memcpy into pinned slots a pending DMA still reads.  Every failing exit drains both streams first.
+void ring_drain(gacq_ctx* ctx, BatchRing* r) {
+  gacq::DeviceGuard dg(ctx->device);
+  if (r && r->copy) (void)hipStreamSynchronize(r->copy);
+  (void)hipStreamSynchronize(ctx->stream);
+}
+
 int ring_collect(gacq_ctx* ctx, BatchRing* r, int slot) {
   GACQ_DEVICE(ctx);
   GACQ_HIP(ctx, hipEventSynchronize(r->done[slot]));
@@ -108,7 +116,7 @@ int check_batch_args(gacq_ctx* ctx, const void* sig, const float* x, size_t nsam
   if (!sig || !x || !items || !out || nitems <= 0 || nepoch <= 0 || nd < 0 || blocks < 0 || (nd > 0 && !dopplers))
     return set_error(ctx, GACQ_ERR_BAD_ARG, "batched search: bad argument");
   const size_t need = (size_t)(blocks + (desc->pad ? 1 : 0)) * desc->n;
-  if (blocks > 0 && nsamp < need)
+  if (blocks > 0 && nd > 0 && nsamp < need)               // an empty Doppler grid never touches x (acquire-gps-l1.py:25-26,40)
     return set_error(ctx, GACQ_ERR_SHORT_INPUT, "batched search: %zu samples per epoch given, %zu needed for %d block(s) of n=%d%s", nsamp, need,
                      blocks, desc->n, desc->pad ? " (padded: windows span 2n)" : "");
   return GACQ_OK;
@@ -136,16 +144,17 @@ extern "C" int gacq_search_batch(gacq_sig* sig, const float* x_iq, size_t nsamp,
                           out + (size_t)(e0 + e) * nitems);
     return rcf;
   };
+  auto fail = [&](int code) -> int { ring_drain(ctx, r); return code; };      // nothing of this call stays in flight
   for (int c = 0; c < nchunk; c++) {
     const int slot = c % kRingDepth, e0 = c * Ec, ne = std::min(Ec, nepoch - e0);
-    if (c >= kRingDepth && (rc = finish(c - kRingDepth)) != GACQ_OK) return rc;
+    if (c >= kRingDepth && (rc = finish(c - kRingDepth)) != GACQ_OK) return fail(rc);
     const size_t bytes = sizeof(float2) * nsamp * (size_t)ne;
-    if ((rc = ensure_pinned(ctx, r->pin_in[slot], bytes)) != GACQ_OK) return rc;
+    if ((rc = ensure_pinned(ctx, r->pin_in[slot], bytes)) != GACQ_OK) return fail(rc);
     std::memcpy(r->pin_in[slot].p, x + (size_t)e0 * nsamp, bytes);         // pageable caller memory -> pinned slot (one CPU copy)
-    if ((rc = ring_submit(sig, r, slot, r->pin_in[slot].p, nsamp, ne, items, nitems, dopplers, nd, item_bias_hz, blocks)) != GACQ_OK) return rc;
+    if ((rc = ring_submit(sig, r, slot, r->pin_in[slot].p, nsamp, ne, items, nitems, dopplers, nd, item_bias_hz, blocks)) != GACQ_OK) return fail(rc);
   }
   for (int c = std::max(0, nchunk - kRingDepth); c < nchunk; c++)
-    if ((rc = finish(c)) != GACQ_OK) return rc;
+    if ((rc = finish(c)) != GACQ_OK) return fail(rc);
   return GACQ_OK;
 }
 
@@ -283,14 +292,18 @@ int gacq_group_search_batch(gacq_gsig* s, const float* x_iq, size_t nsamp, int n
     }
     return GACQ_OK;
   };
+  auto fail = [&](int code) -> int {                    // every member drained: nothing of this call stays in flight anywhere
+    for (int k = 0; k < G; k++) ring_drain(g->ctx[k], ring[k]);
+    return code;
+  };
   for (int c = 0; c < nchunk; c++) {
     const int slot = c % kRingDepth, e0 = c * Ec, ne = std::min(Ec, nepoch - e0);
-    if (c >= kRingDepth && (rc = finish(c - kRingDepth)) != GACQ_OK) return rc;
+    if (c >= kRingDepth && (rc = finish(c - kRingDepth)) != GACQ_OK) return fail(rc);
     const size_t bytes = sizeof(float2) * nsamp * (size_t)ne;
     if (bytes > g->pin_in[slot].cap) {
-      if (g->pin_in[slot].p) { (void)hipDeviceSynchronize(); (void)hipHostFree(g->pin_in[slot].p); g->pin_in[slot] = DevBuf(); }
+      if (g->pin_in[slot].p) { fail(0); (void)hipHostFree(g->pin_in[slot].p); g->pin_in[slot] = DevBuf(); }
       if (hipHostMalloc(&g->pin_in[slot].p, bytes, hipHostMallocPortable) != hipSuccess)
-        return group_error(g, GACQ_ERR_HIP, "gacq_group_search_batch: portable pinned staging allocation failed");
+        return fail(group_error(g, GACQ_ERR_HIP, "gacq_group_search_batch: portable pinned staging allocation failed"));
       g->pin_in[slot].cap = bytes;
     }
     std::memcpy(g->pin_in[slot].p, x + (size_t)e0 * nsamp, bytes);
@@ -299,11 +312,11 @@ int gacq_group_search_batch(gacq_gsig* s, const float* x_iq, size_t nsamp, int n
       share(k, it, nit, dop, ndk, bias);
       if (nit == 0 || ndk == 0) continue;
       rc = ring_submit(s->sig[k], ring[k], slot, g->pin_in[slot].p, nsamp, ne, it, nit, dop, ndk, bias, blocks);
-      if (rc != GACQ_OK) return group_fail(g, k, rc);
+      if (rc != GACQ_OK) return fail(group_fail(g, k, rc));
     }
   }
   for (int c = std::max(0, nchunk - kRingDepth); c < nchunk; c++)
-    if ((rc = finish(c)) != GACQ_OK) return rc;
+    if ((rc = finish(c)) != GACQ_OK) return fail(rc);
   return GACQ_OK;
 }
 

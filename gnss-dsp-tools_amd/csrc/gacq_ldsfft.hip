@@ -29,14 +29,6 @@ constexpr int kLdsN = 4096;            // supported length (this round)
 constexpr int kPitch = 257;            // exchange-2 row pitch in complex elements
 constexpr int kLdsElems = 16 * kPitch; // 4112 complex = 32.9 KB -> 4 workgroups per CU
 
-// Ablation builds for profiling only (tools/ablate.sh): bit 0 drops the LDS traffic, bit 1 the barriers, bit 2 the
-// magnitude/reduce tail, bit 3 the twiddle multiplies, bit 4 the X loads of lds16k_correlate_kernel, bit 5 the workgroup-wide
-// barriers of fft16k; bit 6 keeps engine 4's Z' rows in natural order (A/B against the lane-pair stores, correct results with
-// -DGACQ_ABL_SPLIT=128 in gacq_split.hip).  Results are wrong by construction; never set in the product build.
-#ifndef GACQ_ABL
-#define GACQ_ABL 0
-#endif
-
 // v[rev16(k)] *= w^k for k = 1..15, powers built with multiplication depth <= 4 from the table value.
 __device__ __forceinline__ void apply_powers(v2 (&v)[kR], v2 w1) {
   const v2 w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
@@ -96,29 +88,25 @@ __device__ __forceinline__ void fft4096(v2 (&v)[kR], v2* lds, v2 wa, v2 wb, cons
   if (INV && !(PRE & 1)) wa.y = -wa.y;
   if (INV && !(PRE & 2)) wb.y = -wb.y;
   dft16<INV>(v);
-  if (!(GACQ_ABL & 8)) { if (PRE & 1) apply_table(v, *pa); else apply_powers(v, wa); }
+  if (PRE & 1) apply_table(v, *pa); else apply_powers(v, wa);
   {  // exchange 1: (n0,n1;k0) -> (n0,k0;n1)
     const int wbase = (t & 15) + 256 * (t >> 4);
-    if (!(GACQ_ABL & 1)) {
-_Pragma("unroll") for (int k = 0; k < kR; k++) lds[wbase + 16 * k] = v[rev16(k)];
-    }
-    if (!(GACQ_ABL & 2)) __syncthreads();
-    if (!(GACQ_ABL & 1)) {
-_Pragma("unroll") for (int j = 0; j < kR; j++) v[j] = lds[t + 256 * j];
-    }
+#pragma unroll
+    for (int k = 0; k < kR; k++) lds[wbase + 16 * k] = v[rev16(k)];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kR; j++) v[j] = lds[t + 256 * j];
   }
   dft16<INV>(v);
-  if (!(GACQ_ABL & 8)) { if (PRE & 2) apply_table(v, *pb); else apply_powers(v, wb); }
-  if (!(GACQ_ABL & 2)) __syncthreads();   // all exchange-1 reads done before the buffer is reused
+  if (PRE & 2) apply_table(v, *pb); else apply_powers(v, wb);
+  __syncthreads();   // all exchange-1 reads done before the buffer is reused
   {  // exchange 2: (n0,k0;k1) -> (k0,k1;n0)
     const int wbase = (t >> 4) + kPitch * (t & 15);
-    if (!(GACQ_ABL & 1)) {
-_Pragma("unroll") for (int k = 0; k < kR; k++) lds[wbase + 16 * k] = v[rev16(k)];
-    }
-    if (!(GACQ_ABL & 2)) __syncthreads();
-    if (!(GACQ_ABL & 1)) {
-_Pragma("unroll") for (int j = 0; j < kR; j++) v[j] = lds[t + kPitch * j];
-    }
+#pragma unroll
+    for (int k = 0; k < kR; k++) lds[wbase + 16 * k] = v[rev16(k)];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kR; j++) v[j] = lds[t + kPitch * j];
   }
   dft16<INV>(v);
 }
@@ -692,10 +680,7 @@ __global__ __launch_bounds__(kBlock, 4) void lds_inner_correlate_kernel(const fl
     // the row goes out in the lane-pair layout (n2 = t + 256 k at (k >> 1) * 512 + 2 t + (k & 1)): one 16-byte store per two
     // outputs, 1 KiB per wave and instruction; split_outer_inverse_kernel (paired) undoes the permutation in its index arithmetic
     float2* dst = Z + (((g - g0) * B + b) * R + k1) * (long)kLdsN;
-    if (GACQ_ABL & 64) {                        // A/B builds: natural order, 8-byte stores
-#pragma unroll
-      for (int k = 0; k < kR; k++) { const v2 o = k1 == 0 ? v[rev16(k)] : cmul(v[rev16(k)], tk[k]); dst[t + 256 * k] = make_float2(o.x, o.y); }
-    } else if (k1 == 0) {
+    if (k1 == 0) {
 #pragma unroll
       for (int kp = 0; kp < kR / 2; kp++) {
         const v2 a = v[rev16(2 * kp)], c = v[rev16(2 * kp + 1)];
@@ -930,17 +915,28 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_fused4k_kernel(const float2*
                                                                     const float2* __restrict__ C, const int* __restrict__ items,
                                                                     const double* __restrict__ freq, const float2* __restrict__ nco_tab,
                                                                     const float2* __restrict__ tw, RowRec* __restrict__ rows, int E, int P,
-                                                                    int D, int pch, int nchunk, unsigned* __restrict__ arrivals,
+                                                                    int D, int pch, int nchunk, int by_epoch, unsigned* __restrict__ arrivals,
                                                                     gacq_peak* __restrict__ peaks, int normalised) {
   __shared__ v2 lds[kLdsElems];
   __shared__ float s_peak[kBlock / 64];
   __shared__ int s_idx[kBlock / 64];
   __shared__ double s_sum[kBlock / 64];
   const int t = threadIdx.x;
-  const int xcd = blockIdx.x & 7;                     // (epoch, Doppler) unit -> XCD, as in lds_correlate_kernel
+  // Placement (workgroup b runs on XCD b % 8).  Batches: all D x nchunk workgroups of an epoch go to XCD e % 8, so the epoch's
+  // sample block is fetched into one L2 instead of eight (round 2: 8.3 x the compulsory fetch).  Few epochs: (epoch, Doppler)
+  // units are dealt round-robin as in lds_correlate_kernel, so that a single-epoch search still fills all eight XCDs.
+  const int xcd = blockIdx.x & 7;
   const unsigned j = blockIdx.x >> 3;
-  const unsigned u = (j / (unsigned)nchunk) * 8 + xcd;
-  if (u >= (unsigned)E * (unsigned)D) return;
+  unsigned u;
+  if (by_epoch) {
+    const unsigned per_epoch = (unsigned)D * (unsigned)nchunk;
+    const unsigned e8 = (j / per_epoch) * 8 + xcd;
+    if (e8 >= (unsigned)E) return;
+    u = e8 * (unsigned)D + (j % per_epoch) / (unsigned)nchunk;
+  } else {
+    u = (j / (unsigned)nchunk) * 8 + xcd;
+    if (u >= (unsigned)E * (unsigned)D) return;
+  }
   const long e = u / (unsigned)D;
   const int d = (int)(u % (unsigned)D);
   const int p0 = (int)(j % (unsigned)nchunk) * pch;
@@ -1049,26 +1045,6 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_fused4k_kernel(const float2*
   }
 }
 
-typedef void (*CorrKernel)(const float2*, const float2*, const int*, const int*, const float2*, RowRec*, int, int, int, int, int, int, int);
-
-struct CorrVariant { const char* name; CorrKernel b1; CorrKernel bn; };
-
-// variant table; index chosen by GACQ_LDS_VARIANT (tuning aid), default = kDefaultVariant
-const CorrVariant kVariants[] = {
-  {"w1-hoist", lds_correlate_kernel<1, true, false, false>, lds_correlate_kernel<1, false, false, false>},
-  {"w2-hoist-cachex", lds_correlate_kernel<2, true, true, false>, lds_correlate_kernel<2, false, false, false>},
-  {"w4-opaque-cachex", lds_correlate_kernel<4, true, true, true>, lds_correlate_kernel<4, false, false, true>},
-  {"w4-opaque", lds_correlate_kernel<4, true, false, true>, lds_correlate_kernel<4, false, false, true>},
-  {"w3-opaque-cachex", lds_correlate_kernel<3, true, true, true>, lds_correlate_kernel<3, false, false, true>},
-  {"w2-opaque-cachex", lds_correlate_kernel<2, true, true, true>, lds_correlate_kernel<2, false, false, true>},
-  {"w3-pretw-cachex", lds_correlate_kernel<3, true, true, false, true>, lds_correlate_kernel<3, false, false, false, true>},
-  {"w2-pretw-cachex", lds_correlate_kernel<2, true, true, false, true>, lds_correlate_kernel<2, false, false, false, true>},
-  {"w3-pretw", lds_correlate_kernel<3, true, false, false, true>, lds_correlate_kernel<3, false, false, false, true>},
-  {"w4-pretw", lds_correlate_kernel<4, true, false, false, true>, lds_correlate_kernel<4, false, false, false, true>},
-};
-constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
-constexpr int kDefaultVariant = 1;   // profiles/r01_ab_variants_*.log: all packed-math variants are within 5 %; this one led twice
-
 int twiddle_table(gacq_ctx* ctx, const float2** out) { return twiddle_cache(ctx, "W4096", kLdsN, kLdsN, out); }
 
 }  // namespace
@@ -1169,14 +1145,15 @@ int lds_fused4k_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch,
   if (ctx->opt[GACQ_OPT_LDS_PCH] >= 1) pch = (int)ctx->opt[GACQ_OPT_LDS_PCH];
   pch = std::min(pch, nitems);
   const int nchunk = (nitems + pch - 1) / pch;
-  const long units8 = (units + 7) / 8;
+  const int by_epoch = nepoch >= 64 ? 1 : 0;
+  const long units8 = by_epoch ? (long)((nepoch + 7) / 8) * D : (units + 7) / 8;      // units per XCD
   const dim3 grid((unsigned)(8 * units8 * nchunk));
   if (arrivals)
     hipLaunchKernelGGL((lds_fused4k_kernel<2, false, true>), grid, dim3(kBlock), 0, ctx->stream, x, nsamp, spectra, d_items, d_freq, tab, tw, rows,
-                       nepoch, nitems, D, pch, nchunk, arrivals, peaks, normalised);
+                       nepoch, nitems, D, pch, nchunk, by_epoch, arrivals, peaks, normalised);
   else
     hipLaunchKernelGGL((lds_fused4k_kernel<4, true, false>), grid, dim3(kBlock), 0, ctx->stream, x, nsamp, spectra, d_items, d_freq, tab, tw, rows,
-                       nepoch, nitems, D, pch, nchunk, (unsigned*)nullptr, (gacq_peak*)nullptr, 0);
+                       nepoch, nitems, D, pch, nchunk, by_epoch, (unsigned*)nullptr, (gacq_peak*)nullptr, 0);
   GACQ_HIP(ctx, hipGetLastError());
   return GACQ_OK;
 }
@@ -1241,11 +1218,11 @@ int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const i
   const int nchunk = (nitems + pch - 1) / pch;
   const long units8 = ((long)nepoch * D + 7) / 8;
   const long grid = 8 * units8 * nchunk;
-  int variant = kDefaultVariant;
-  if (ctx->opt[GACQ_OPT_LDS_VARIANT] >= 0 && ctx->opt[GACQ_OPT_LDS_VARIANT] < kNumVariants) variant = (int)ctx->opt[GACQ_OPT_LDS_VARIANT];
-  // register-cached X needs all items of a workgroup to share one forward set
+  // register-cached X needs all items of a workgroup to share one forward set.  <2 waves/SIMD declared, X cached, twiddle powers
+  // hoisted> led the round-1 A/B of ten register/occupancy variants (profiles/r01_ab_variants_*.log, all within 5 %); the others
+  // are gone from the build.
   const bool b1 = (B == 1) && (F == 1);
-  CorrKernel kern = b1 ? kVariants[variant].b1 : kVariants[variant].bn;
+  auto kern = b1 ? lds_correlate_kernel<2, true, true, false> : lds_correlate_kernel<2, false, false, false>;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, X, spectra, d_items, d_fset, tw, rows, nepoch,
                      nitems, F, D, B, pch, nchunk);
   GACQ_HIP(ctx, hipGetLastError());

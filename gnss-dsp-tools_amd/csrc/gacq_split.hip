@@ -81,23 +81,12 @@ __global__ __launch_bounds__(kBlock) void split_outer_forward_kernel(const float
   });
 }
 
-// Ablation / A-B builds for profiling only (tools/ablate.sh sN), never set in the product build.
-//   wrong results by construction:
-//     bit 0  the outer inverse kernel keeps its loads and its reduction but skips the twiddles and the DFT
-//     bit 1  it reads one contiguous R x 256 tile instead of R row segments      bit 2  ... with 16-byte loads
-//   correct results, other schedule / layout:
-//     bit 3  groups visited last-written first          bit 4  plain instead of non-temporal Z' loads
-//     bit 5  non-temporal Z' stores in the Stockham kernel          bit 6  unpadded Z' rows
-//     bit 7  engine 4 keeps Z' in natural order (needs -DGACQ_ABL=64 in gacq_ldsfft.hip as well)
-#ifndef GACQ_ABL_SPLIT
-#define GACQ_ABL_SPLIT 0
-#endif
 
 // Z' is read exactly once: non-temporal loads (`global_load_dwordx2 ... nt`) keep the 1-2 GB stream from displacing the code spectra
 // and twiddles in L2 and measured 3-17 % faster than plain loads on the reading side (profiles/r02_split_nontemporal_experiment.log).
 template <bool NT>
 __device__ __forceinline__ v2 ld_stream(const float2* p) {
-  if (!NT || (GACQ_ABL_SPLIT & 16)) { const float2 z = *p; return v2{z.x, z.y}; }
+  if (!NT) { const float2 z = *p; return v2{z.x, z.y}; }
   return __builtin_bit_cast(v2, __builtin_nontemporal_load(reinterpret_cast<const double*>(p)));
 }
 
@@ -116,7 +105,7 @@ __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_i
   constexpr bool kNT = B1 || R != 31;              // the multi-block R = 31 kernel (E6B, B3I, E5: 0.94 -> 0.99 ms) is the one case that loses
   const unsigned blk = blockIdx.x;
   const int chunk = (int)(blk % (unsigned)chunks);
-  const long g = (GACQ_ABL_SPLIT & 8) ? (long)(gridDim.x / (unsigned)chunks) - 1 - (long)(blk / (unsigned)chunks) : (long)(blk / (unsigned)chunks);
+  const long g = (long)(blk / (unsigned)chunks);
   // position of this thread's column inside a row of Z'.  paired (engine 4, M = 4096): the LDS inner kernel stores a row in its
   // lane-pair layout (n2 = t + 256 j at (j >> 1) * 512 + 2 t + (j & 1), 16 bytes per lane and store); columns are independent here,
   // so the thread simply serves whichever n2 lives at its position.  (The same layout for the Stockham kernel's last pass -- 7 x 16 + 8
@@ -131,26 +120,8 @@ __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_i
     v2 v[R];
     {
       const float2* src = Z + (g * B) * (long)(R * Mp) + pos;     // rows are Mp apart (128-byte aligned pitch)
-      if (GACQ_ABL_SPLIT & 4) {        // ablation: the same bytes as 16-byte loads from one contiguous tile (wrong elements)
-        const float4* s4 = reinterpret_cast<const float4*>(Z + ((g * B) * (long)(R * Mp) & ~1L));
-        long base4 = ((long)chunk * R * kBlock) / 2;
-        if ((base4 + (R + 1) / 2 * kBlock) * 2 >= (long)R * M) base4 -= (long)R * kBlock;
 #pragma unroll
-        for (int h = 0; h < (R + 1) / 2; h++) {
-          const float4 q4 = s4[base4 + h * kBlock + threadIdx.x];
-          v[2 * h] = v2{q4.x, q4.y};
-          if (2 * h + 1 < R) v[2 * h + 1] = v2{q4.z, q4.w};
-        }
-      } else
-#pragma unroll
-      for (int k1 = 0; k1 < R; k1++) {
-        long off = (long)k1 * Mp;
-        if (GACQ_ABL_SPLIT & 2) {      // ablation: the same bytes as one contiguous R x 256 tile per workgroup (wrong elements)
-          off = ((long)chunk * R + k1) * kBlock + threadIdx.x - pos;
-          if (off + pos >= (long)R * M) off -= (long)R * kBlock;
-        }
-        v[k1] = ld_stream<kNT>(src + off);
-      }
+      for (int k1 = 0; k1 < R; k1++) v[k1] = ld_stream<kNT>(src + (long)k1 * Mp);
     }
     TwPow tp;
     if (TW) {
@@ -158,16 +129,7 @@ __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_i
       const v2 wv = {wf.x, -wf.y};      // conj: W_N^{-n2}
       tp.init<R - 1>(wv);
     }
-    if (GACQ_ABL_SPLIT & 1) {        // ablation: the loads and the reduction only (no twiddles, no DFT)
-      float sum_f = 0.f;
-#pragma unroll
-      for (int n1 = 0; n1 < R; n1++) {
-        const float m = v[n1].x * v[n1].x + v[n1].y * v[n1].y;
-        if (m > peak) { peak = m; idx = M * n1 + n2; }
-        sum_f += m;
-      }
-      sum = (double)sum_f;
-    } else if (B1) {
+    if (B1) {
       if (TW) {
 #pragma unroll
         for (int k1 = 1; k1 < R; k1++) v[k1] = tp.apply(v[k1], k1);
@@ -316,8 +278,7 @@ __device__ __forceinline__ void stockham_pass(v2* __restrict__ buf, float2* __re
       const int j0 = (j / Ns) * Ns * R + k;
 #pragma unroll
       for (int t = 0; t < R; t++) {
-        if (LAST && (GACQ_ABL_SPLIT & 32)) __builtin_nontemporal_store(__builtin_bit_cast(double, x[it][t]), reinterpret_cast<double*>(gz + j0 + t * Ns));
-        else if (LAST) gz[j0 + t * Ns] = make_float2(x[it][t].x, x[it][t].y);
+        if (LAST) gz[j0 + t * Ns] = make_float2(x[it][t].x, x[it][t].y);
         else buf[j0 + t * Ns] = x[it][t];
       }
     }
@@ -524,7 +485,6 @@ extern "C" int gacq_debug_phase_cycles(unsigned long long* out32, int reset) {
 // K2 + inner inverse transforms in one kernel (no Y round trip); Z gets the unnormalised, untwiddled inner IFFTs
 int split_row_pitch(int N) {
   if (!split_inner_fused_supported(N)) return 0;
-  if (GACQ_ABL_SPLIT & 64) return N / 31;          // A/B builds: unpadded rows
   return (N / 31 + 15) & ~15;                      // 1980 -> 1984, 990 -> 992 complex: rows of Z' start on 128-byte lines
 }
 
@@ -551,6 +511,14 @@ int split_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* C, const
   const int DG = (D + dt - 1) / dt;
   const dim3 grid((unsigned)((long)R * nblk_ep * DG * B));
   const size_t smem = sizeof(float2) * ((size_t)teams * M + (size_t)M);
+  {
+    // teams = 4 with M = 1980 asks for 79 KB of dynamic LDS: fine on gfx950 (160 KB), not on a 64 KB part -- say so instead of
+    // failing inside hipFuncSetAttribute with a generic HIP error
+    int max_lds = 0;
+    if (hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device) == hipSuccess && max_lds > 0 && smem > (size_t)max_lds)
+      return set_error(ctx, GACQ_ERR_UNSUPPORTED, "split engine: %d team(s) of M=%d need %zu bytes of LDS per workgroup, the device allows %d",
+                       teams, M, smem, max_lds);
+  }
 #define GACQ_LAUNCH_INNER(KERN, NT)                                                                                                 \
   do {                                                                                                                              \
     GACQ_HIP(ctx, hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                   \
@@ -643,7 +611,7 @@ int split_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long n
   const int M = N / R;
   if (Mp <= 0) Mp = M;
   // Y written by lds_inner_correlate_kernel (inner == false, M == 4096): rows in the lane-pair layout
-  const int paired = (!inner && !twiddle_only && M == 4096 && !(GACQ_ABL_SPLIT & 128)) ? 1 : 0;
+  const int paired = (!inner && !twiddle_only && M == 4096) ? 1 : 0;
   if (Mp != M && !twiddle_only) return set_error(ctx, GACQ_ERR_BAD_ARG, "split engine: padded rows need the fused inner kernel");
   const float2* tw;
   int rc = base_twiddles(ctx, N, M, &tw);

@@ -108,7 +108,7 @@ int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes);
  * environment.  Defaults in brackets. */
 #define GACQ_OPT_FUSED_INNER 0  /* [1] engine 3: conj-multiply fused into the Stockham inner inverse transforms         */
 #define GACQ_OPT_FUSED_16K 1    /* [1] N = 16384 with one carrier per item: forward + correlate in one kernel           */
-#define GACQ_OPT_LDS_VARIANT 2  /* [-1 = built-in choice] register/occupancy variant of lds_correlate_kernel            */
+#define GACQ_OPT_LDS_VARIANT 2  /* retired (round 3): the build carries one instantiation of lds_correlate_kernel; accepted, ignored   */
 #define GACQ_OPT_LDS_PCH 3      /* [0 = auto] items per workgroup of the LDS correlate kernels                          */
 #define GACQ_OPT_SPLIT_PCH 4    /* [0 = auto] (epoch, item) rows per workgroup of the split engines' inner kernels      */
 #define GACQ_OPT_SPLIT_TEAMS 5  /* [0 = auto] rows (teams of waves) per workgroup of the Stockham inner kernel: 1, 2 or 4  */

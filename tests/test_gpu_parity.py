@@ -807,6 +807,32 @@ def test_zero_blocks_never_reads_x(engine, name, ms):
     assert rc == 0 and [(r.metric, r.idx, r.d_index) for r in res] == [(0.0, -1, -1)] * 2
 
 
+@pytest.mark.parametrize("name,ms", [("gps-l1", 1), ("beidou-b1i", 10), ("galileo-e1b", 8)])
+def test_empty_doppler_grid_never_reads_x(engine, name, ms):
+    """An empty Doppler grid with blocks > 0 (np.arange(1000, 1000, 100)): the reference's loop body never runs, it returns its
+    untouched (0, 0, 0) and never looks at x -- so x may be ONE sample long: Python mirror, batched host call, and the
+    three C entry points straight through ctypes."""
+    import ctypes
+    from gnss_dsp_tools_amd import _native as nat
+    from gnss_dsp_tools_amd import acquire, signals
+    sig = signals.get(name)
+    B = sig.blocks(ms)
+    assert B > 0
+    x = np.ones(1, dtype=np.complex64)
+    ds = [1000.0, 1000.0, 100.0]
+    assert len(acquire.doppler_grid(ds)) == 0
+    assert acquire.make_search(name, engine)(x, 1, ds, ms) == (0, 0, 0)
+    assert engine.search_all(sig, x, [1, 2], ds, ms) == [(0, 0, 0), (0, 0, 0)]
+    assert engine.search_batch_host(sig, x[None, :], [1, 2], acquire.doppler_grid(ds), B) == [[(0, 0, 0), (0, 0, 0)]]
+    s = engine.signal(sig, [1, 2])
+    items = np.array([0, 1], dtype=np.int32)
+    res = (nat.Result * 2)()
+    rc = nat.lib.gacq_search(s._h, x.ctypes.data_as(nat.c_float_p), 1, items.ctypes.data_as(nat.c_int_p), 2, None, 0, None, B, res)
+    assert rc == 0 and [(r.metric, r.idx, r.d_index) for r in res] == [(0.0, -1, -1)] * 2
+    rc = nat.lib.gacq_search_batch(s._h, x.ctypes.data_as(nat.c_float_p), 1, 1, items.ctypes.data_as(nat.c_int_p), 2, None, 0, None, B, res)
+    assert rc == 0 and [(r.metric, r.idx, r.d_index) for r in res] == [(0.0, -1, -1)] * 2
+
+
 def test_empty_item_list_and_out_buffer_validation(engine):
     """search_all over no items is [] like the reference's map over an empty list; a caller-supplied result buffer of the
     wrong shape / dtype / layout is refused instead of being overwritten by the last kernel."""
