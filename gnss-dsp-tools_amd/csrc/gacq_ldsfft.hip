@@ -81,9 +81,10 @@ __device__ __forceinline__ void wave_first_max(const float (&m)[kR], unsigned ba
 // wa = W_4096^t, wb = W_256^(t & 15) (forward values; conjugated here when INV).
 // PRE: bit 0 = the pass-1 powers (W_4096^t)^k, bit 1 = the pass-2 powers (W_256^(t&15))^k come precomputed in *pa / *pb (already
 // conjugated for an inverse transform) instead of being rebuilt from wa / wb by 14 complex products per pass.
+// bit 2 = the pass-2 powers are read from an LDS table (tb2[16 (k - 1)], tb2 already offset by the lane's class t & 15).
 template <bool INV, int PRE = 0>
 __device__ __forceinline__ void fft4096(v2 (&v)[kR], v2* lds, v2 wa, v2 wb, const v2 (*pa)[15] = nullptr, const v2 (*pb)[15] = nullptr,
-                                        int t = -1) {
+                                        int t = -1, const v2* tb2 = nullptr) {
   if (t < 0) t = threadIdx.x;                       // lane index within the 256-lane group that owns this transform
   if (INV && !(PRE & 1)) wa.y = -wa.y;
   if (INV && !(PRE & 2)) wb.y = -wb.y;
@@ -98,7 +99,11 @@ __device__ __forceinline__ void fft4096(v2 (&v)[kR], v2* lds, v2 wa, v2 wb, cons
     for (int j = 0; j < kR; j++) v[j] = lds[t + 256 * j];
   }
   dft16<INV>(v);
-  if (PRE & 2) apply_table(v, *pb); else apply_powers(v, wb);
+  if (PRE & 4) {
+#pragma unroll
+    for (int k = 1; k < kR; k++) v[rev16(k)] = cmul(v[rev16(k)], tb2[16 * (k - 1)]);
+  } else if (PRE & 2) apply_table(v, *pb);
+  else apply_powers(v, wb);
   __syncthreads();   // all exchange-1 reads done before the buffer is reused
   {  // exchange 2: (n0,k0;k1) -> (k0,k1;n0)
     const int wbase = (t >> 4) + kPitch * (t & 15);
@@ -224,6 +229,15 @@ __device__ unsigned long long gacq_phase16[16 * 8];
 // Levels of the four segments between two barrier pairs of the inverse transform (last radix-16 pass + magnitudes | C * x +
 // radix-4 | radix-16 | radix-16): measured on B1I, 63 items x 200 bins x 10 blocks (profiles/r03_16k_priority_sweep.log):
 // none 3.50 ms, 3-2-1-0 3.06-3.09, 0-1-2-3 3.21, 2-3-1-0 2.98-2.99.
+// forward + inverse in one kernel (lds16k_fused_kernel): after barrier A | after the sample loads are issued | after the forward
+// exchange | after transpose 1 | after transpose 2 (then GACQ_P3 / GACQ_P4 inside the inverse transform)
+#ifndef GACQ_QA
+#define GACQ_QA 3
+#define GACQ_QX 3
+#define GACQ_QF 3
+#define GACQ_QT1 2
+#define GACQ_QT2 2
+#endif
 #ifndef GACQ_P1
 #define GACQ_P1 2
 #define GACQ_P2 3
@@ -269,7 +283,7 @@ __device__ __forceinline__ void fft16k_fwd(v2 (&v)[kR], v2* lds, const Tw16k& tw
 #pragma unroll
   for (int ka = 0; ka < kR; ka++) lds[ka * kRegion + t] = v[rev16(ka)];            // exchange 0: output ka -> wave ka
   lds_barrier();
-  GACQ_SETPRIO(3);
+  GACQ_SETPRIO(GACQ_QF);
 #pragma unroll
   for (int j = 0; j < kR; j++) v[j] = reg[l + 64 * j];
   dft16<false>(v);
@@ -278,7 +292,7 @@ __device__ __forceinline__ void fft16k_fwd(v2 (&v)[kR], v2* lds, const Tw16k& tw
   for (int k0 = 0; k0 < kR; k0++) reg[66 * k0 + l] = v[rev16(k0)];                 // transpose 1, element (k0, l) at 66 k0 + l
 #pragma unroll
   for (int lh = 0; lh < kR; lh++) v[lh] = reg[66 * (l & 15) + (l >> 4) + 4 * lh];  // lane (k0 = l & 15, l_lo = l >> 4)
-  GACQ_SETPRIO(2);
+  GACQ_SETPRIO(GACQ_QT1);
   dft16<false>(v);
   apply_powers(v, tw.w2);
 #pragma unroll
@@ -288,6 +302,7 @@ __device__ __forceinline__ void fft16k_fwd(v2 (&v)[kR], v2* lds, const Tw16k& tw
 #pragma unroll
     for (int kh = 0; kh < 4; kh++) v[kh + 4 * lo] = reg[l + 256 * lo + 64 * kh];     // lane mu = k0 + 16 k1_lo, k1 = k1_lo + 4 kh
   }
+  GACQ_SETPRIO(GACQ_QT2);
 #pragma unroll
   for (int kh = 0; kh < 4; kh++) dft4<false, false>(v[kh], v[kh + 4], v[kh + 8], v[kh + 12]);   // over l_lo -> k2 at v[kh + 4 k2]
 }
@@ -563,6 +578,7 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_fused_kernel(const float2*
       w[j] = ld2(nco_tab + k);
     }
     if (DUMP) return;
+    GACQ_SETPRIO(GACQ_QX);
 #pragma unroll
     for (int j = 0; j < kR; j++) v[j] = cmul(v[j], w[j]);
     // the twiddle bases are re-read per block (three 8-byte loads, L1 hits): kept live across the block loop, the two sets cost
@@ -580,7 +596,7 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_fused_kernel(const float2*
     lds_barrier();
     ifft16k_gather(v, lds);
     lds_barrier();                                    // every wave has read this region: the next block's exchange 0 may overwrite it
-    GACQ_SETPRIO(3);
+    GACQ_SETPRIO(GACQ_QA);
     ifft16k_final(v, twi);
 #pragma unroll
     for (int k = 0; k < kR; k++) {
@@ -843,6 +859,10 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float
   }
 }
 
+#ifndef GACQ_PRE4K
+#define GACQ_PRE4K 5      // batch kernel: pass-1 powers in registers (1) + pass-2 powers from the LDS table (4); A/B partner: 1
+#endif
+
 // ---- pieces of the single-launch search (lds_fused4k_kernel<.., SCAN>) ------------------------------------------------------------
 // Row records cross workgroups inside one launch: per-XCD L2s are not coherent and a CU's L1 is never refreshed, so both sides use
 // agent-scope accesses (global_store / global_load ... sc1: write-through, L1-bypassing) and the arrival counter is an agent-scope
@@ -942,6 +962,17 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_fused4k_kernel(const float2*
   const int p0 = (int)(j % (unsigned)nchunk) * pch;
   const int p1 = min(P, p0 + pch);
   v2 wa = ld2(tw + t), wb = ld2(tw + 16 * (t & 15));
+  // PREA (the batch kernel): the pass-2 twiddle powers of the inverse transform, conj(W_256^c)^k for the 16 lane classes
+  // c = t & 15, are built once per workgroup with the product tree of apply_powers (same values, so the records stay
+  // bit-identical to the two-kernel path) and read back from a 1.9 KB LDS table: one ds_read_b64 per product instead of 14
+  // extra complex products per row.  (Pass 1's powers are per-lane and stay in registers, see PREA.)
+  __shared__ v2 s_tw2[PREA ? 15 * 16 : 1];
+  if (PREA && t < 16) {
+    v2 pw[15];
+    make_powers(pw, v2{wb.x, -wb.y});                  // lanes 0..15: wb = W_256^t
+#pragma unroll
+    for (int k = 0; k < 15; k++) s_tw2[16 * k + t] = pw[k];
+  }
   v2 xr[kR];
   const unsigned lane_off = (unsigned)t * 16u;
   // SCAN (latency path): a workgroup has only 1-4 rows, so every load it waits for is on the critical path of the whole search.
@@ -994,7 +1025,7 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_fused4k_kernel(const float2*
 #pragma unroll
       for (int jj = 0; jj < kR; jj++) v[jj] = cmul(v[jj], xr[jj]);
     }
-    if (PREA) fft4096<true, 1>(v, lds, wa, wb, reinterpret_cast<const v2(*)[15]>(pwa), nullptr);
+    if (PREA) fft4096<true, GACQ_PRE4K>(v, lds, wa, wb, reinterpret_cast<const v2(*)[15]>(pwa), nullptr, -1, s_tw2 + (t & 15));
     else fft4096<true>(v, lds, wa, wb);
     // lane t holds lags t + 256 k.  The 1/N of ifft is a power of two: applied once to the reduced values.
     float m[kR];
