@@ -1219,16 +1219,17 @@ int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const i
     const float2* twn;
     int rcb = twiddle_cache(ctx, "W16384_lo", kBig, 1024, &twn);
     if (rcb != GACQ_OK) return rcb;
-    // One 1024-thread workgroup per CU, 32 per XCD.  Items per workgroup: about P/16, so that the ~32 workgroups resident on
-    // an XCD are 16 item chunks x 2 (epoch, Doppler) units walked side by side: two forward-spectrum sets (B x 128 KB each)
-    // stay in that XCD's 4 MB L2 while every code-spectrum row fetched serves both units, and the grid is fine-grained
-    // enough that the last round of workgroups leaves few CUs idle (B1I, 63 items x 200 bins: 3200 workgroups).
+    // One 1024-thread workgroup per CU, 32 per XCD.  Items per workgroup: about P/32 -- the grid is then fine-grained enough that
+    // the last round of workgroups leaves few CUs idle (B1I, 63 items x 200 bins: 6400 workgroups = 25 rounds of 256) while a
+    // workgroup still amortises its start-up over >= 2 x B rows.  Measured (profiles/r03_16k_b1i_chunk_sweep.log): 2 items 3.04-3.06 ms,
+    // 1 item 3.07-3.15, 3 items 3.15-3.18, 4 items 3.15-3.21; walking two (epoch, Doppler) units side by side on an XCD (ugroup 2, so
+    // that both share the code spectra in L2) costs 3-4 % instead of paying: one unit at a time is the default.
     const long units = (long)nepoch * D;
-    int pch = std::max(1, (nitems + 15) / 16);
+    int pch = std::max(1, (nitems + 31) / 32);
     if (ctx->opt[GACQ_OPT_LDS_PCH] >= 1) pch = (int)ctx->opt[GACQ_OPT_LDS_PCH];
     pch = std::min(pch, nitems);
     const int nchunk = (nitems + pch - 1) / pch;
-    int ugroup = std::max(1, std::min(32 / nchunk, 24 / std::max(1, B)));
+    int ugroup = 1;
     if (ctx->opt[GACQ_OPT_LDS_UGROUP] >= 1) ugroup = (int)ctx->opt[GACQ_OPT_LDS_UGROUP];
     const long units8 = (units + 7) / 8;                                 // units per XCD
     const long groups = (units8 + ugroup - 1) / ugroup;

@@ -55,13 +55,12 @@ bool gen_gps_ca(int prn, Chips& out) {
 }
 
 // ---- GPS L5I / L5Q: XA (short-cycled) xor XB advanced (gnsstools/gps/l5i.py:73-107) --------
-bool gen_gps_l5(const PrnRow* tab, int ntab, bool is_q, int prn, Chips& out) {
+bool gen_gps_l5(const PrnRow* tab, int ntab, int prn, Chips& out) {
   const PrnRow* r = find_row(tab, ntab, prn);
   if (!r) return false;
   const int L = 10230;
   ShiftReg xa(13, 0x1fff, {12, 11, 9, 8});
-  ShiftReg xb = is_q ? ShiftReg(13, 0x1fff, {12, 11, 7, 6, 5, 3, 2, 0})
-                     : ShiftReg(13, 0x1fff, {12, 11, 7, 6, 5, 3, 2, 0});
+  ShiftReg xb(13, 0x1fff, {12, 11, 7, 6, 5, 3, 2, 0});       // L5I and L5Q share XA and XB; only the XB advance (table column a) differs
   std::vector<uint8_t> b(8191);
   for (int i = 0; i < 8191; i++) { b[i] = xb.stage(12); xb.shift(); }
   out.resize(L);
@@ -302,8 +301,8 @@ const Family* find_family(const char* name) {
 bool generate(const Family& f, int prn, Chips& out) {
   const std::string n = f.name;
   if (n == "gps.ca") return gen_gps_ca(prn, out);
-  if (n == "gps.l5i") return gen_gps_l5(T_gps_l5i, N_gps_l5i, false, prn, out);
-  if (n == "gps.l5q") return gen_gps_l5(T_gps_l5q, N_gps_l5q, true, prn, out);
+  if (n == "gps.l5i") return gen_gps_l5(T_gps_l5i, N_gps_l5i, prn, out);
+  if (n == "gps.l5q") return gen_gps_l5(T_gps_l5q, N_gps_l5q, prn, out);
   if (n == "gps.l2cm") return gen_gps_l2cm(prn, out);
   if (n == "gps.l2cl") return gen_gps_l2cl(prn, out);
   if (n == "glonass.p") return gen_glo_p(prn, out);
