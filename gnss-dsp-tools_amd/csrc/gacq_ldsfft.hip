@@ -478,18 +478,23 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_correlate_kernel(const flo
   const Tw16k tw = tw16k_load(twn, true);
   const unsigned lane_off = (unsigned)t * 16u;
   const float inv_n = 1.0f / (float)kBig;
-  const float2* xrow = X + (((e * F + fset[p0]) * D + d) * (long)B) * kBig;
+  // Every second unit an XCD works on walks its items backwards: a unit touches all P code spectra (B1I: 8 MB against 4 MB of L2), so
+  // the rows the next unit can still find in L2 are the ones touched LAST -- its workgroups start with those.
+  const bool backwards = (ug & 1) != 0;
+  const int pstep = backwards ? -1 : 1, pfirst = backwards ? p1 - 1 : p0;
+  const float2* xrow = X + (((e * F + fset[pfirst]) * D + d) * (long)B) * kBig;
   dma_row(xrow, reg);
 #ifdef GACQ_PHASE_TIMING16
   unsigned long long acc16_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long mark16_ = __builtin_readcyclecounter();
 #endif
-  for (int p = p0; p < p1; p++) {
+  for (int ip = 0; ip < p1 - p0; ip++) {
+    const int p = pfirst + pstep * ip;
     const __amdgpu_buffer_rsrc_t cres = big_rsrc(C + (long)items[p] * kBig);
     v2 c[kR];
 #pragma unroll
     for (int jp = 0; jp < kR / 2; jp++) ld_pair_big(cres, lane_off, jp, c[2 * jp], c[2 * jp + 1]);
-    const float2* xnext_item = (p + 1 < p1) ? X + (((e * F + fset[p + 1]) * D + d) * (long)B) * kBig : nullptr;
+    const float2* xnext_item = (ip + 1 < p1 - p0) ? X + (((e * F + fset[p + pstep]) * D + d) * (long)B) * kBig : nullptr;
     float q[kR];
 #pragma unroll
     for (int k = 0; k < kR; k++) q[k] = 0.f;

@@ -38,7 +38,7 @@ def draw(rng):
     E = int(rng.choice([1, 2, 3, 5] if not big else [1, 2]))
     opts = {"lds_pch": int(rng.choice([0, 1, 3, 8])), "split_pch": int(rng.choice([0, 1, 3, 5])), "fused_4k": int(rng.choice([0, 1, 2])),
             "fused_16k": int(rng.choice([0, 1])), "fused_inner": int(rng.choice([0, 1, 1, 1])), "split_teams": int(rng.choice([0, 0, 2, 4])),
-            "split_dt": int(rng.choice([0, 1, 2, 3]))}
+            "split_dt": int(rng.choice([0, 1, 2, 3])), "search1": int(rng.choice([0, 1, 1])), "lds_ugroup": int(rng.choice([0, 1, 2, 3]))}
     if opts["split_teams"] > 1:
         opts["split_dt"] = 1
     row = 8 * sig.nfft * B

@@ -54,7 +54,7 @@ def main():
     out = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     os.makedirs(out, exist_ok=True)
     py = sys.executable
-    bench = [py, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-latency", "--no-pmc"]
+    bench = [py, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-latency", "--no-pmc", "--no-others"]
     for cfg in (2, 3, 4, 5):
         trace(out, "config%d" % cfg, bench + ["--config", str(cfg)])
     txt = pmc(out, "config2", bench + ["--steps", "2", "--warmup", "1", "--preroll-s", "0", "--sustained-s", "0"], "fused4k|lds_correlate|lds_forward|best_doppler")
