@@ -239,7 +239,7 @@ def condense(o, wall_s):
          "seconds_timed": sus["seconds"] if sus else o["ms_per_step"] * o["steps"] * 1e-3,
          "cells_per_step": o["config"]["cells_per_step"], "cell_blocks_per_step": o["config"]["cell_blocks_per_step"],
          "dominant_kernel": r["kernel"], "dominant_signal": r["signal"], "bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"],
-         "roofline_unit": r["unit"], "frac": r["frac"], "avg_kernel_ms": r["avg_kernel_ms"],
+         "roofline_unit": r["unit"], "frac": r["frac"], "avg_kernel_ms": r["avg_kernel_ms"], "stream_ceiling": r.get("stream_ceiling"),
          "algorithmic_per_launch": r.get("alg_bytes_per_launch", r.get("useful_flop_per_launch")),
          "compulsory_hbm_bytes_per_launch": r.get("compulsory_bytes_per_launch"),
          "traffic_measured_bytes_per_launch": r.get("traffic"),
@@ -688,6 +688,12 @@ def run(args, env):
                     "frac": achieved / HBM_PEAK_GBPS, "avg_kernel_ms": dk["avg_ms"], "alg_bytes_per_launch": work_launch,
                     "model": "bytes this kernel must move through HBM: its side of the split engine's one round trip (8 N per correlation "
                              "row), or x in + X out for the forward stage, over the kernel's HIP-event duration"}
+    if dk["bound"] == "hbm":
+        # `peak` stays the 8 TB/s of MI355X_MICROARCH.md; what a plain streaming kernel reaches on this part is lower and differs by
+        # direction (tools/hbm_bandwidth.hip, profiles/r03_hbm_read_write_copy_bandwidth.log): 16-byte stores 4.2-4.7 TB/s, loads 6.5-7.1
+        side, ceil = ("read", 6800.0) if dstage == "mag_peak" else (("write", 4700.0) if dstage == "lds_correlate" else ("read+write", 4700.0))
+        roofline["stream_ceiling"] = {"side": side, "GBps": ceil, "frac": roofline["achieved"] / ceil,
+                                      "source": "tools/hbm_bandwidth.hip on MI355X, round 3: fill 4.2-4.7 TB/s, read 6.5-7.1 TB/s, copy 4.6-4.7 TB/s"}
     # what the dominant kernel must at least move through HBM per launch (inputs once, outputs once): the yardstick for `traffic`
     dom_job = next(j for j in jobs if j["label"] == dj["signal"])
     rec_bytes = 16.0 * E_total * dj["P"] * dj["D_local"]
