@@ -165,6 +165,7 @@ class Engine:
         return out
 
     def close(self):
+        self._plan_key = None
         for s in list(self._live):
             s.close()
         self._signals.clear()
@@ -186,6 +187,7 @@ class Engine:
         sig = _signals.get(name) if isinstance(name, str) else name
         key = (sig.name, tuple(prns))
         if chips is not None:
+            self._plan_key = None                      # a cached plan may point at the signal replaced here
             if key in self._signals:
                 self._signals.pop(key).close()
             self._signals[key] = AcqSignal(self, sig, prns, chips)
@@ -194,8 +196,23 @@ class Engine:
         return self._signals[key]
 
     def _plan(self, name, items):
-        """Map reference 'items' (PRNs, or GLONASS channels) to (AcqSignal, item indices, per-item bias)."""
+        """Map reference 'items' (PRNs, or GLONASS channels) to (AcqSignal, item indices, per-item bias).  The last plan is kept: a
+        scan calls search_all with the same item list for every block of samples."""
         sig = _signals.get(name) if isinstance(name, str) else name
+        key = (sig.name, tuple(items))
+        if getattr(self, "_plan_key", None) == key:
+            return self._plan_val
+        val = self._plan_uncached(sig, items)
+        self._plan_key, self._plan_val = key, val
+        # ctypes views of the index / bias arrays and a reusable result buffer: numpy's .ctypes accessor costs ~1 us per use, which shows
+        # on the single-search latency path
+        _, idx, bias = val
+        res = (nat.Result * len(idx))()
+        self._plan_c = (idx.ctypes.data_as(nat.c_int_p), bias.ctypes.data_as(nat.c_double_p) if bias is not None else None,
+                        res, np.frombuffer(res, dtype=RESULT_DTYPE))
+        return val
+
+    def _plan_uncached(self, sig, items):
         items = [int(i) for i in items]
         if sig.bias_hz:
             s = self.signal(sig, [0])                                  # one shared code (glonass/ca.py:27)
@@ -235,12 +252,12 @@ class Engine:
             raise ValueError("operands could not be broadcast together: search needs %d samples "
                              "(%d block(s) of n=%d%s), x has %d" % (need, blocks, sig.n, ", padded" if sig.pad else "", len(x)))
         xc = np.ascontiguousarray(x[:need], dtype=np.complex64) if need else np.zeros(1, dtype=np.complex64)
-        res = (nat.Result * len(idx))()
+        idx_p, bias_p, res, view = self._plan_c
         nat.check(nat.lib.gacq_search(
-            s._h, xc.ctypes.data_as(nat.c_float_p), len(xc), idx.ctypes.data_as(nat.c_int_p), len(idx),
-            dopplers.ctypes.data_as(nat.c_double_p), len(dopplers),
-            bias.ctypes.data_as(nat.c_double_p) if bias is not None else None, blocks, res), self._ctx)
-        return [_as_tuple(r) for r in res]
+            s._h, ctypes.cast(xc.__array_interface__["data"][0], nat.c_float_p), len(xc), idx_p, len(idx),
+            ctypes.cast(dopplers.__array_interface__["data"][0], nat.c_double_p) if len(dopplers) else None, len(dopplers),
+            bias_p, blocks, res), self._ctx)
+        return _as_tuples(view)
 
     def _family(self, names, items, ms=None):
         """(base descriptor, stacked AcqSignal or None, per-signal item lists) for signals that differ only in their code
@@ -283,7 +300,7 @@ class Engine:
         res = (nat.Result * total)()
         nat.check(nat.lib.gacq_search(fam._h, xc.ctypes.data_as(nat.c_float_p), len(xc), idx.ctypes.data_as(nat.c_int_p), total,
                                       dopplers.ctypes.data_as(nat.c_double_p), len(dopplers), None, blocks, res), self._ctx)
-        flat = [_as_tuple(r) for r in res]
+        flat = _as_tuples(res)
         out, at = [], 0
         for it in lists:
             out.append(flat[at:at + len(it)])
@@ -508,13 +525,25 @@ def finalize(name, items, peaks, dopplers, shard_d0=None):
     nat.check(nat.lib.gacq_finalize(ctypes.byref(desc), peaks.ctypes.data_as(ctypes.POINTER(nat.Peak)), nshard,
                                     d0.ctypes.data_as(nat.c_int_p), nitems,
                                     dopplers.ctypes.data_as(nat.c_double_p), len(dopplers), res))
-    return [_as_tuple(r) for r in res]
+    return _as_tuples(res)
 
 
 def _as_tuple(r):
     if r.d_index < 0:
         return 0, 0, 0                  # the reference's untouched initial values (acquire-gps-l1.py:25)
     return np.float64(r.metric), float(r.code_chips), np.float64(r.doppler_hz)
+
+
+def _as_tuples(res):
+    """[_as_tuple(r) for r in res] for a ctypes array of gacq_result, through one structured-array view: iterating a float64 column
+    yields np.float64 scalars (the reference's metric / doppler types), .tolist() plain floats (its code phase) -- a third of the time of
+    32 per-record attribute reads on the single-search latency path."""
+    a = res if isinstance(res, np.ndarray) else np.frombuffer(res, dtype=RESULT_DTYPE)
+    out = list(zip(a["metric"], a["code_chips"].tolist(), a["doppler_hz"]))
+    if a["d_index"].min() < 0:
+        for k in np.flatnonzero(a["d_index"] < 0):
+            out[k] = (0, 0, 0)          # the reference's untouched initial values (acquire-gps-l1.py:25)
+    return out
 
 
 def format_result(name, item, result):

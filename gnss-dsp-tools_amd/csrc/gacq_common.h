@@ -51,7 +51,7 @@ struct gacq_ctx {
   size_t ws_limit = (size_t)4 << 30;
   std::map<std::pair<long, long>, gacq::FftPlan> plans;   // (N * 2 + inverse, batch)
   gacq::DevBuf tab, xstage, X, Y, rows, freq, fset, items, out_peaks, d0, partial, fe_a, fe_b, fe_taps, chunk_peaks, arrivals;
-  long opt[GACQ_NOPTS] = {1, 1, -1, 0, 0, 0, 1, 0, 0, 0, 0, 1};   // gacq_set_option values (defaults documented in include/gacq.h)
+  long opt[GACQ_NOPTS] = {1, 1, -1, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1};   // gacq_set_option values (defaults documented in include/gacq.h)
   gacq::DevBuf pin_x, pin_peaks;       // pinned host staging for the host-buffer entry point (gacq_search)
   gacq::DevBuf bar_x;                  // fine-grained device memory the host writes directly through the PCIe BAR (small gacq_search inputs)
   bool large_bar = false;              // hipDeviceProp_t.isLargeBar: device memory is host-addressable

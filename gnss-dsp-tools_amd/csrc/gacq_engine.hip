@@ -12,6 +12,8 @@
 #include "gacq_common.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdlib>
@@ -1003,9 +1005,31 @@ int gacq_search(gacq_sig* sig, const float* x_iq, size_t nsamp, const int* items
     d_x = ctx->xstage.p;
   }
   // the Doppler scan writes its 16-byte records straight into device-visible pinned host memory: no D2H copy
+  // Completion (latency path, small inputs only): the host watches the pinned result records themselves instead of asking the
+  // runtime (an empty hipStreamSynchronize costs ~3 us here).  Every record is pre-set to a sentinel in both of its 8-byte halves;
+  // the last kernel of the search overwrites all of them, so "no sentinel left" means the search is complete.  Bounded: after
+  // 200 us (or on any doubt) the call falls back to hipStreamSynchronize, which is also what reports a failed launch.
+  gacq_peak* pk = (gacq_peak*)ctx->pin_peaks.p;
+  const bool watch = d_x == ctx->bar_x.p && ctx->opt[GACQ_OPT_WATCH_RESULTS] != 0;
+  constexpr unsigned long long kSentinelBits = 0x7ff8dead0badbeefULL;      // a NaN payload no search produces
+  if (watch)
+    for (int p = 0; p < nitems; p++) { std::memcpy(&pk[p].metric, &kSentinelBits, 8); pk[p].idx = -2; pk[p].d_index = -2; }
   rc = gacq_search_batch_dev(sig, d_x, take, 1, items, nitems, dopplers, nd, item_bias_hz, blocks, ctx->pin_peaks.p);
   if (rc != GACQ_OK) return rc;
-  GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  bool complete = false;
+  if (watch) {
+    const volatile unsigned long long* words = reinterpret_cast<const volatile unsigned long long*>(pk);
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
+    int first_pending = 0;
+    for (unsigned spin = 0;; spin++) {
+      while (first_pending < nitems && words[2 * first_pending] != kSentinelBits && pk[first_pending].d_index != -2) first_pending++;
+      if (first_pending == nitems) { complete = true; break; }
+      __builtin_ia32_pause();
+      if ((spin & 63) == 63 && std::chrono::steady_clock::now() > t_end) break;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
+  if (!complete) GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return gacq_finalize(&sig->desc, (const gacq_peak*)ctx->pin_peaks.p, 1, nullptr, nitems, dopplers, nd, out);
 }
 

@@ -126,7 +126,9 @@ int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes);
                                 /*     overlap their launch latencies; profiles/r03_single_search_latency.log)                            */
 #define GACQ_OPT_BAR_UPLOAD 11    /* [1] gacq_search: inputs up to 256 KiB are written by the host straight into fine-grained device       */
                                 /*     memory through the PCIe BAR (large-BAR devices) instead of pinned staging + DMA                  */
-#define GACQ_NOPTS 12
+#define GACQ_OPT_WATCH_RESULTS 12 /* [1] gacq_search (BAR upload path only): wait for completion by watching the pinned result records for  */
+                                /*     the last kernel's stores (bounded spin, then hipStreamSynchronize) instead of a runtime sync          */
+#define GACQ_NOPTS 13
 int gacq_set_option(gacq_ctx* ctx, int option, long value);
 int gacq_get_option(gacq_ctx* ctx, int option, long* value);
 
