@@ -87,8 +87,10 @@ SYMBOLS = {
     "gacq_signal_destroy": (None, [ctypes.c_void_p]),
     "gacq_signal_fft_length": (ctypes.c_int, [ctypes.c_void_p]),
     "gacq_signal_spectrum": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_float_p]),
-    "gacq_search": (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_size_t, c_int_p, ctypes.c_int,
-                                   c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.POINTER(Result)]),
+    # the sample and Doppler pointers are declared void*: the latency path passes plain addresses (no ctypes.cast per call); typed
+    # pointer objects are accepted for a void* parameter as well
+    "gacq_search": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, c_int_p, ctypes.c_int,
+                                   ctypes.c_void_p, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.POINTER(Result)]),
     "gacq_search_batch_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
                                              c_int_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p,
                                              ctypes.c_int, ctypes.c_void_p]),

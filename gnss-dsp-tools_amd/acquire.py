@@ -253,10 +253,10 @@ class Engine:
                              "(%d block(s) of n=%d%s), x has %d" % (need, blocks, sig.n, ", padded" if sig.pad else "", len(x)))
         xc = np.ascontiguousarray(x[:need], dtype=np.complex64) if need else np.zeros(1, dtype=np.complex64)
         idx_p, bias_p, res, view = self._plan_c
-        nat.check(nat.lib.gacq_search(
-            s._h, ctypes.cast(xc.__array_interface__["data"][0], nat.c_float_p), len(xc), idx_p, len(idx),
-            ctypes.cast(dopplers.__array_interface__["data"][0], nat.c_double_p) if len(dopplers) else None, len(dopplers),
-            bias_p, blocks, res), self._ctx)
+        rc = nat.lib.gacq_search(s._h, xc.__array_interface__["data"][0], len(xc), idx_p, len(idx),
+                                 dopplers.__array_interface__["data"][0] if len(dopplers) else None, len(dopplers), bias_p, blocks, res)
+        if rc < 0:
+            nat.check(rc, self._ctx)
         return _as_tuples(view)
 
     def _family(self, names, items, ms=None):
