@@ -1022,7 +1022,8 @@ int gacq_search(gacq_sig* sig, const float* x_iq, size_t nsamp, const int* items
     const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
     int first_pending = 0;
     for (unsigned spin = 0;; spin++) {
-      while (first_pending < nitems && words[2 * first_pending] != kSentinelBits && pk[first_pending].d_index != -2) first_pending++;
+      // both 8-byte halves of a record through volatile reads (little endian: d_index is the upper half of the second word)
+      while (first_pending < nitems && words[2 * first_pending] != kSentinelBits && (int)(words[2 * first_pending + 1] >> 32) != -2) first_pending++;
       if (first_pending == nitems) { complete = true; break; }
       __builtin_ia32_pause();
       if ((spin & 63) == 63 && std::chrono::steady_clock::now() > t_end) break;
