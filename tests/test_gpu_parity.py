@@ -524,6 +524,32 @@ def test_bench_measures_hbm_traffic_live_with_pmc_child_runs():
     assert x_bytes <= j["roofline"]["traffic"] <= 40 * x_bytes, (j["roofline"]["traffic"], x_bytes)
     assert 0.3 < src["valu_pipe_busy_pmc"] <= 1.0
     assert src["launches_averaged"] >= 3
+    # the default single-GPU headline run also carries the other BASELINE configurations and the complex128 leg (round 3)
+    others = j["other_configs"]
+    assert [c["baseline_config"] for c in others] == [3, 4, 5] and not any("error" in c for c in others), others
+    for c in others:
+        assert c["value"] > 1e10 and c["seconds_timed"] >= 1.0 and c["bound"] in ("valu", "hbm") and 0.0 < c["frac"] < 1.0, c
+        assert c["traffic_measured_in_this_run"] and c["traffic_measured_bytes_per_launch"] >= 0.9 * c["compulsory_hbm_bytes_per_launch"], c
+    ref = j["reference_precision"]
+    assert ref["dtype"] == "f64" and ref["value"] > 1e9 and ref["seconds_timed"] >= 1.0, ref
+    agree = ref["f32_vs_f64_on_the_same_64_epochs"]
+    assert agree["searches"] == 64 * 32 and agree["peak_location_mismatches"] == 0 and agree["max_rel_metric_error"] < 1e-5, agree
+
+
+def test_bench_rank_slice_projection_mode():
+    """bench.py --emulate-ranks N: every rank's Doppler slice of an N-rank job timed on this one GPU, labelled as a projection."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--config", "2", "--epochs", "16", "--emulate-ranks", "4"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["projection"] is True and "NOT A MEASUREMENT" in j["note"] and j["ranks_emulated"] == 4
+    assert [p["doppler_bins"] for p in j["per_rank"]] == [[10]] * 4 and j["epochs_per_step"] == 64
+    assert j["slowest_slice_ms"] == max(p["ms_per_step"] for p in j["per_rank"]) and 0.2 < j["projected_efficiency"] < 1.3
 
 
 R31_CASES = ["cfg4_l5i_subset", "l5q_subset", "cfg4_b2ad_b80", "gal_e6b", "gal_e5bq", "bds_b3i", "bds_b2bi", "glo_l3ocd",
