@@ -29,9 +29,17 @@ PLAN = [
 ]
 
 
+PLAN_16K = [   # round 3: the rebuilt N = 16384 engine on its own (usage: tools/parity_sweep.py 16k)
+    ("beidou-b1i", list(range(1, 64)), [-2000.0, 2000.0, 250.0], 3, 30),
+    ("beidou-b2i", list(range(1, 11)), [-1000.0, 1000.0, 125.0], 2, 30),
+    ("glonass-l1", list(range(-7, 8)), [-2000.0, 2000.0, 250.0], 2, 40),
+    ("glonass-l2", list(range(-7, 8)), [-1500.0, 1500.0, 250.0], 1, 20),
+]
+
+
 def main():
     eng = acquire.Engine(0)
-    for name, items, ds, ms, epochs in PLAN:
+    for name, items, ds, ms, epochs in (PLAN_16K if sys.argv[1:2] == ["16k"] else PLAN):
         sig = signals.get(name)
         B = sig.blocks(ms)
         rows = mism = 0
