@@ -59,7 +59,8 @@ ERRORS = {0: "GACQ_OK", -1: "GACQ_ERR_BAD_ARG", -2: "GACQ_ERR_UNKNOWN_CODE", -3:
           -8: "GACQ_ERR_INTERNAL", -9: "GACQ_ERR_UNSUPPORTED"}
 
 # GACQ_OPT_* of include/gacq.h
-OPTIONS = {"fused_inner": 0, "fused_16k": 1, "lds_variant": 2, "lds_pch": 3, "split_pch": 4, "split_teams": 5, "fused_4k": 6, "split_dt": 7, "fe_generic": 8, "lds_ugroup": 9, "search1": 10, "bar_upload": 11, "watch_results": 12}
+OPTIONS = {"fused_inner": 0, "fused_16k": 1, "lds_variant": 2, "lds_pch": 3, "split_pch": 4, "split_teams": 5, "fused_4k": 6, "split_dt": 7, "fe_generic": 8, "lds_ugroup": 9, "search1": 10, "bar_upload": 11, "watch_results": 12,
+           "tie_safe": 13, "tie_eps_ppb": 14, "tie_cap": 15}
 
 # name -> (restype, argtypes): every symbol include/gacq.h declares
 SYMBOLS = {
@@ -106,8 +107,12 @@ SYMBOLS = {
     "gacq_group_signal_destroy": (None, [ctypes.c_void_p]),
     "gacq_group_search_batch": (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_size_t, ctypes.c_int, c_int_p, ctypes.c_int,
                                                c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.POINTER(Result)]),
+    "gacq_get_tie_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong)]),
     "gacq_merge_peaks_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c_int_p, ctypes.c_long,
                                             ctypes.c_void_p]),
+    "gacq_merge_peaks_tiesafe_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, c_int_p, ctypes.c_int,
+                                                    c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, c_int_p,
+                                                    ctypes.c_void_p]),
     "gacq_finalize": (ctypes.c_int, [ctypes.POINTER(SigDesc), ctypes.POINTER(Peak), ctypes.c_int, c_int_p, ctypes.c_int,
                                      c_double_p, ctypes.c_int, ctypes.POINTER(Result)]),
     "gacq_firwin_hann": (ctypes.c_int, [ctypes.c_int, ctypes.c_double, c_double_p]),

@@ -149,6 +149,13 @@ class Engine:
         nat.check(nat.lib.gacq_get_option(self._ctx, int(option), ctypes.byref(v)), self._ctx)
         return v.value
 
+    def tie_stats(self):
+        """gacq_get_tie_stats: {ambiguous (epoch, item) pairs found, rows re-evaluated in complex128, pairs that kept their fp32 answer
+        (list full / unsupported length), pairs whose location the re-evaluation changed} since the context was created."""
+        v = (ctypes.c_longlong * 4)()
+        nat.check(nat.lib.gacq_get_tie_stats(self._ctx, v), self._ctx)
+        return {"ambiguous_pairs": v[0], "rows_reevaluated": v[1], "kept_fp32": v[2], "locations_changed": v[3]}
+
     def set_profiling(self, on):
         nat.check(nat.lib.gacq_set_profiling(self._ctx, int(bool(on))), self._ctx)
 
@@ -418,6 +425,32 @@ class Engine:
         d0 = np.ascontiguousarray(shard_d0, dtype=np.int32)
         nat.check(nat.lib.gacq_merge_peaks_dev(self._ctx, ctypes.c_void_p(gathered.data_ptr()), nshard,
                                                d0.ctypes.data_as(nat.c_int_p), n, ctypes.c_void_p(out.data_ptr())), self._ctx)
+        return out
+
+
+    def merge_peaks_tiesafe_dev(self, name, x_dev, items, dopplers, blocks, gathered, shard_d0, out=None, _signal=None):
+        """gacq_merge_peaks_tiesafe_dev: merge_peaks_dev for searches that run with tie-safe locations (the default) -- shard
+        winners within eps of the best one are re-evaluated in complex128 on this GPU before the scan decides.  name / x_dev /
+        items / blocks are those of the sharded search, `dopplers` its FULL grid."""
+        import torch
+        sig = _signals.get(name) if isinstance(name, str) else name
+        if _signal is not None:
+            s, idx, bias = _signal, np.array([_signal._index[i] for i in items], dtype=np.int32), None
+        else:
+            s, idx, bias = self._plan(sig, items)
+        dopplers = np.ascontiguousarray(dopplers, dtype=np.float64)
+        nepoch, nsamp = x_dev.shape
+        nshard = gathered.shape[0]
+        if tuple(gathered.shape[1:]) != (nepoch, len(idx), 2):
+            raise ValueError("gathered must have shape (nshard, %d, %d, 2)" % (nepoch, len(idx)))
+        if out is None:
+            out = torch.empty(gathered.shape[1:], dtype=torch.float64, device=gathered.device)
+        d0 = np.ascontiguousarray(shard_d0, dtype=np.int32)
+        nat.check(nat.lib.gacq_merge_peaks_tiesafe_dev(
+            s._h, ctypes.c_void_p(x_dev.data_ptr()), nsamp, nepoch, idx.ctypes.data_as(nat.c_int_p), len(idx),
+            dopplers.ctypes.data_as(nat.c_double_p), len(dopplers), bias.ctypes.data_as(nat.c_double_p) if bias is not None else None,
+            int(blocks), ctypes.c_void_p(gathered.data_ptr()), nshard, d0.ctypes.data_as(nat.c_int_p), ctypes.c_void_p(out.data_ptr())),
+            self._ctx)
         return out
 
 

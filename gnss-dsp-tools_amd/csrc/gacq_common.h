@@ -24,6 +24,29 @@ struct RowRec {
   double sum;    // sum_k q[k]  (for the max/mean metric)
 };
 
+// Tie-safe peak locations (gacq_tiesafe.hip).  The reference takes argmax and the strict-'>' Doppler scan in fp64
+// (acquire-gps-l1.py:34-39); the fp32 engines can land on another lag / bin when two candidates are closer than their rounding
+// error.  Every row reduction therefore also reports whether a second lag comes within `tie_scale` = 1 - eps of the row maximum
+// (bit kTieBit of RowRec::idx -- lags are < 2^28), the Doppler scan does the same across bins, and the (epoch, item) pairs that
+// are ambiguous get their candidate rows re-evaluated in complex128 on the device before the answer is written.
+constexpr int kTieBit = 0x40000000;
+constexpr int kIdxMask = kTieBit - 1;
+struct TieRow { int ep, d; };                       // row to re-evaluate: ep = epoch * P + item position, d = index into the Doppler grid
+struct TieEp { int ep, slot0, cnt, pad; };          // an ambiguous (epoch, item): its candidate rows are slots [slot0, slot0 + cnt), ascending d
+struct TieRec { double peak, sum; int idx, pad; };  // complex128 result of a re-evaluated row
+struct TieCounters {
+  unsigned nrows, neps, pad0, pad1;                 // fill levels of the two lists of the launch in flight (reset by tie_resolve_kernel)
+  unsigned long long flagged, rows, overflow, moved;      // cumulative since gacq_create: ambiguous pairs, rows re-evaluated, pairs dropped for lack
+                                                          // of list space (they keep their fp32 answer), pairs whose location changed
+};
+struct TieLists {                                   // kernel argument (by value)
+  TieCounters* c;
+  TieEp* eps;
+  TieRow* rows;
+  TieRec* recs;
+  int cap;
+};
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
@@ -51,7 +74,9 @@ struct gacq_ctx {
   size_t ws_limit = (size_t)4 << 30;
   std::map<std::pair<long, long>, gacq::FftPlan> plans;   // (N * 2 + inverse, batch)
   gacq::DevBuf tab, xstage, X, Y, rows, freq, fset, items, out_peaks, d0, partial, fe_a, fe_b, fe_taps, chunk_peaks, arrivals;
-  long opt[GACQ_NOPTS] = {1, 1, -1, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1};   // gacq_set_option values (defaults documented in include/gacq.h)
+  gacq::DevBuf tie, tie_scratch;       // tie-safe re-evaluation: counters + lists, and the complex128 row scratch (gacq_tiesafe.hip)
+  int tie_cap = 0;                     // list capacity the `tie` buffer was laid out for
+  long opt[GACQ_NOPTS] = {1, 1, -1, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 1, 8000, 0};   // gacq_set_option values (defaults documented in include/gacq.h)
   gacq::DevBuf pin_x, pin_peaks;       // pinned host staging for the host-buffer entry point (gacq_search)
   gacq::DevBuf bar_x;                  // fine-grained device memory the host writes directly through the PCIe BAR (small gacq_search inputs)
   bool large_bar = false;              // hipDeviceProp_t.isLargeBar: device memory is host-addressable
@@ -107,18 +132,18 @@ int lds_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n,
 // N = 16384 with one carrier per item (F == P): forward + correlate in one kernel, no X buffer
 bool lds_fused_supported(const gacq_ctx* ctx, int N, int P, int F);
 int lds_fused_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n, int N, const float2* spectra, const int* d_items,
-                     const int* d_fset, const double* d_freq, const float2* tab, int nitems, int D, int B, RowRec* rows);
+                     const int* d_fset, const double* d_freq, const float2* tab, int nitems, int D, int B, RowRec* rows, float tie_scale);
 // N = 4096, B == 1, one carrier: forward + correlate in one kernel, no X buffer
 bool lds_fused4k_supported(const gacq_ctx* ctx, int N, int B, int F, long units);
 // arrivals != nullptr: single-launch search -- the Doppler scan runs inside the kernel (last workgroup of every item) and the peak
 // records go to `peaks`; arrivals = nepoch * nitems zeroed counters, left zeroed
 int lds_fused4k_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, const float2* spectra, const int* d_items,
-                       const double* d_freq, const float2* tab, int nitems, int D, RowRec* rows, unsigned* arrivals = nullptr,
+                       const double* d_freq, const float2* tab, int nitems, int D, RowRec* rows, float tie_scale, unsigned* arrivals = nullptr,
                        gacq_peak* peaks = nullptr, int normalised = 0);
 // the single-launch form pays for small batches only (every workgroup resident at once)
 bool lds_search1_supported(const gacq_ctx* ctx, int N, int B, int F, long units, int nitems);
 int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const int* d_items, const int* d_fset,
-                  int nepoch, int nitems, int F, int D, int B, int N, RowRec* rows);
+                  int nepoch, int nitems, int F, int D, int B, int N, RowRec* rows, float tie_scale);
 
 // test hook (gacq_debug_nco_indices): the forward kernel's own NCO index expression for one row, d_idx[N]; fused: the
 // one-kernel N = 16384 search
@@ -146,8 +171,52 @@ int lds_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, c
                         long ng, int P, int F, int D, int B, int R, int N, float2* Z);
 // inner inverse transforms on Y (in place), then twiddle + inverse DFT-31 + |.|/N + sum over B + reduce -> rows[g0..g0+ng)
 // inner == false: Y already holds the twiddled inner inverse transforms (LDS inner path)
-int split_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng, int B, int N, float* q_out, bool inner = true,
-                       bool twiddle_only = false, int Mp = 0);
+int split_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng, int B, int N, float* q_out, float tie_scale,
+                       bool inner = true, bool twiddle_only = false, int Mp = 0);
+
+// tie-safe re-evaluation (gacq_tiesafe.hip)
+bool tie_supported(int N);                       // prime factors of N in {2, 3, 5, 7, 11, 13, 31}: every FFT length of the reference's scripts
+float tie_scale_of(const gacq_ctx* ctx);            // 1 - eps from GACQ_OPT_TIE_EPS_PPB
+int tie_prepare(gacq_sig* sig);                  // complex128 code spectra on first use
+int tie_lists(gacq_ctx* ctx, long nep, TieLists* out, gacq_peak** guesses);
+int tie_resolve(gacq_sig* sig, const TieLists& tl, const gacq_peak* guesses, const float2* d_x, size_t nsamp, int P, int D, int B, gacq_peak* d_out);
+
+// Running (maximum, first argmax, runner-up) of magnitudes visited in ascending lag order, and the merge of two such partial results.
+// An exact duplicate of the maximum counts as its runner-up.
+struct Top2 {
+  float peak = -1.0f;
+  int idx = 0x7fffffff;
+  float second = -1.0f;
+  __device__ __forceinline__ void add(float v, int i) {
+    if (v > peak) { second = peak; peak = v; idx = i; } else second = fmaxf(second, v);
+  }
+  __device__ __forceinline__ void merge(float op, int oi, float os) {
+    second = fmaxf(fmaxf(second, os), fminf(peak, op));
+    if (op > peak || (op == peak && oi < idx)) { peak = op; idx = oi; }
+  }
+  // idx with kTieBit set when the runner-up comes within tie_scale of the maximum
+  __device__ __forceinline__ int tagged(float tie_scale) const { return idx | ((second >= peak * tie_scale) ? kTieBit : 0); }
+};
+
+// Combine nparts partial (maximum, idx | tie bit) results of one row -- waves, workgroups or column chunks.  Conservative: a part
+// whose maximum reaches the threshold of the combined maximum counts once, twice if it is ambiguous in itself; two or more make
+// the row ambiguous.  On equal maxima the lower lag wins (np.argmax returns the first maximum).
+template <class GetPeak, class GetIdx>
+__device__ __forceinline__ void combine_tagged(int nparts, GetPeak pk, GetIdx ix, float tie_scale, float& peak, int& tagged_idx) {
+  float bp = pk(0);
+  int bi = ix(0) & kIdxMask;
+  for (int w = 1; w < nparts; w++) {
+    const float p = pk(w);
+    const int i = ix(w) & kIdxMask;
+    if (p > bp || (p == bp && i < bi)) { bp = p; bi = i; }
+  }
+  const float thr = bp * tie_scale;
+  int near = 0;
+  for (int w = 0; w < nparts; w++)
+    if (pk(w) >= thr) near += 1 + ((ix(w) & kTieBit) != 0);
+  peak = bp;
+  tagged_idx = bi | (near > 1 ? kTieBit : 0);
+}
 
 // Makes ctx's device current for the duration of an entry point and restores the caller's device afterwards
 // (a library must not leave a different current device behind in a multi-GPU process).

@@ -244,24 +244,25 @@ __global__ __launch_bounds__(kBlock) void conj_mul_kernel(const float2* __restri
 }
 
 // Block-wide (peak, first index, sum) reduction shared by K3 and the LDS engine.
-__device__ __forceinline__ void block_reduce_peak(float& peak, int& idx, double& sum) {
-  __shared__ float s_peak[kBlock / 64];
+__device__ __forceinline__ void block_reduce_peak(Top2& top, double& sum) {
+  __shared__ float s_peak[kBlock / 64], s_second[kBlock / 64];
   __shared__ int s_idx[kBlock / 64];
   __shared__ double s_sum[kBlock / 64];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
-    const float op = __shfl_down(peak, off);
-    const int oi = __shfl_down(idx, off);
+    const float op = __shfl_down(top.peak, off);
+    const int oi = __shfl_down(top.idx, off);
+    const float o2 = __shfl_down(top.second, off);
     const double os = __shfl_down(sum, off);
-    if (op > peak || (op == peak && oi < idx)) { peak = op; idx = oi; }
+    top.merge(op, oi, o2);
     sum += os;
   }
   const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { s_peak[wave] = peak; s_idx[wave] = idx; s_sum[wave] = sum; }
+  if ((threadIdx.x & 63) == 0) { s_peak[wave] = top.peak; s_idx[wave] = top.idx; s_second[wave] = top.second; s_sum[wave] = sum; }
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < kBlock / 64; w++) {
-      if (s_peak[w] > peak || (s_peak[w] == peak && s_idx[w] < idx)) { peak = s_peak[w]; idx = s_idx[w]; }
+      top.merge(s_peak[w], s_idx[w], s_second[w]);
       sum += s_sum[w];
     }
   }
@@ -269,11 +270,10 @@ __device__ __forceinline__ void block_reduce_peak(float& peak, int& idx, double&
 
 // K3: one workgroup per (e,p,d) group: q[k] = sum_b |Y[b][k]| / N, reduced to (max, argmax, sum).
 __global__ __launch_bounds__(kBlock) void mag_peak_kernel(const float2* __restrict__ Y, RowRec* __restrict__ rows,
-                                                           long g0, int B, int N, float inv_n, float* __restrict__ q_out) {
+                                                           long g0, int B, int N, float inv_n, float* __restrict__ q_out, float tie_scale) {
   const long gl = blockIdx.x;
   const float2* ys = Y + gl * (long)B * N;
-  float peak = -1.0f;
-  int idx = 0x7fffffff;
+  Top2 top;
   double sum = 0.0;
   for (int k0 = threadIdx.x * 2; k0 < N; k0 += kBlock * 2) {
     float q0 = 0.f, q1 = 0.f;
@@ -284,8 +284,8 @@ __global__ __launch_bounds__(kBlock) void mag_peak_kernel(const float2* __restri
         q1 += sqrtf(v.z * v.z + v.w * v.w) * inv_n;
       }
       if (q_out) { q_out[k0] = q0; q_out[k0 + 1] = q1; }
-      if (q0 > peak) { peak = q0; idx = k0; }
-      if (q1 > peak) { peak = q1; idx = k0 + 1; }
+      top.add(q0, k0);
+      top.add(q1, k0 + 1);
       sum += (double)q0 + (double)q1;
     } else {
       for (int b = 0; b < B; b++) {
@@ -293,15 +293,15 @@ __global__ __launch_bounds__(kBlock) void mag_peak_kernel(const float2* __restri
         q0 += sqrtf(v.x * v.x + v.y * v.y) * inv_n;
       }
       if (q_out) q_out[k0] = q0;
-      if (q0 > peak) { peak = q0; idx = k0; }
+      top.add(q0, k0);
       sum += (double)q0;
     }
   }
-  block_reduce_peak(peak, idx, sum);
+  block_reduce_peak(top, sum);
   if (threadIdx.x == 0) {
     RowRec r;
-    r.peak = peak;
-    r.idx = idx;
+    r.peak = top.peak;
+    r.idx = top.tagged(tie_scale);
     r.sum = sum;
     rows[g0 + gl] = r;
   }
@@ -311,31 +311,82 @@ __global__ __launch_bounds__(kBlock) void mag_peak_kernel(const float2* __restri
 // One wave per (epoch, item): lane l scans bins l, l+64, ... in ascending order with strict '>', then the 64 lane results
 // are combined keeping the larger metric and, on equal metrics, the lower bin -- the same winner as the serial scan of
 // acquire-gps-l1.py:36-39 (initial (0,0,0): a row that never exceeds 0 reports idx = d_index = -1, mapped to 0 by finalize).
+// TIE (tie-safe locations, gacq_tiesafe.hip): the scan also keeps the runner-up metric.  When it comes within eps of the winner, or
+// the winning row's own runner-up lag does (kTieBit of its idx), fp32 cannot tell which candidate the reference's fp64 scan picks:
+// the pair's record is NOT written here; instead every bin whose metric reaches (1 - eps) x the winner is appended, in ascending
+// Doppler order, to the re-evaluation list, and tie_resolve_kernel writes the record from the complex128 values.
+__device__ __forceinline__ double row_metric(const RowRec& r, int N, int normalised) {
+  return normalised ? (double)r.peak / (r.sum / (double)N) : (double)r.peak;
+}
+template <bool TIE>
 __global__ __launch_bounds__(256) void best_doppler_kernel(const RowRec* __restrict__ rows, gacq_peak* __restrict__ out, long nep,
-                                                           int D, int N, int normalised) {
+                                                           int D, int N, int normalised, TieLists tl, gacq_peak* __restrict__ guesses,
+                                                           float tie_scale) {
   const long ep = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (ep >= nep) return;
   const int lane = threadIdx.x & 63;
-  double best = 0.0;
+  double best = 0.0, second = 0.0;
   int bidx = -1, bd = 0x7fffffff;
   for (int d = lane; d < D; d += 64) {
     const RowRec r = rows[ep * D + d];
-    const double m = normalised ? (double)r.peak / (r.sum / (double)N) : (double)r.peak;
-    if (m > best) { best = m; bidx = r.idx; bd = d; }
+    const double m = row_metric(r, N, normalised);
+    if (m > best) { second = best; best = m; bidx = r.idx; bd = d; }
+    else if (TIE && m > second) second = m;
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     const double om = __shfl_down(best, off);
     const int oi = __shfl_down(bidx, off);
     const int od = __shfl_down(bd, off);
+    if (TIE) second = fmax(fmax(second, __shfl_down(second, off)), fmin(best, om));
     if (om > best || (om == best && od < bd)) { best = om; bidx = oi; bd = od; }
   }
+  gacq_peak o;
+  o.metric = best;
+  o.idx = bidx < 0 ? -1 : (bidx & kIdxMask);
+  o.d_index = bidx < 0 ? -1 : bd;
+  if (!TIE) {
+    if (lane == 0) out[ep] = o;
+    return;
+  }
+  best = __shfl(best, 0);
+  second = __shfl(second, 0);
+  bidx = __shfl(bidx, 0);
+  const double thr = best * (double)tie_scale;
+  if (bidx < 0 || !((bidx & kTieBit) || second >= thr)) {
+    if (lane == 0) out[ep] = o;
+    return;
+  }
+  // ambiguous: list every candidate bin (wave-uniform control flow from here on)
+  int cnt = 0;
+  for (int d0 = 0; d0 < D; d0 += 64) {
+    const int d = d0 + lane;
+    const bool c = d < D && row_metric(rows[ep * D + d], N, normalised) >= thr;
+    cnt += __popcll(__builtin_amdgcn_ballot_w64(c));
+  }
+  int slot0 = 0, epslot = 0;
+  if (lane == 0) slot0 = (int)atomicAdd(&tl.c->nrows, (unsigned)cnt);
+  slot0 = __shfl(slot0, 0);
+  if (slot0 + cnt > tl.cap || slot0 < 0) {
+    // no room: the pair keeps its fp32 answer; the slots reserved below the capacity are voided
+    for (int s = slot0 + lane; s < slot0 + cnt && s < tl.cap && s >= 0; s += 64) { TieRow v; v.ep = -1; v.d = 0; tl.rows[s] = v; }
+    if (lane == 0) { out[ep] = o; atomicAdd(&tl.c->overflow, 1ull); }
+    return;
+  }
   if (lane == 0) {
-    gacq_peak o;
-    o.metric = best;
-    o.idx = bidx;
-    o.d_index = bidx < 0 ? -1 : bd;
-    out[ep] = o;
+    epslot = (int)atomicAdd(&tl.c->neps, 1u);      // <= the number of listed rows <= cap
+    TieEp te;
+    te.ep = (int)ep; te.slot0 = slot0; te.cnt = cnt; te.pad = 0;
+    tl.eps[epslot] = te;
+    guesses[epslot] = o;
+  }
+  int off = 0;
+  for (int d0 = 0; d0 < D; d0 += 64) {
+    const int d = d0 + lane;
+    const bool c = d < D && row_metric(rows[ep * D + d], N, normalised) >= thr;
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(c);
+    if (c) { TieRow v; v.ep = (int)ep; v.d = d; tl.rows[slot0 + off + __popcll(mask & ((1ull << lane) - 1ull))] = v; }
+    off += __popcll(mask);
   }
 }
 
@@ -398,7 +449,7 @@ void gacq_destroy(gacq_ctx* ctx) {
     if (kv.second.work) (void)hipFree(kv.second.work);
   }
   for (auto& ev : ctx->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-  DevBuf* bufs[] = {&ctx->tab, &ctx->xstage, &ctx->X, &ctx->Y, &ctx->rows, &ctx->freq, &ctx->fset, &ctx->items, &ctx->out_peaks, &ctx->d0, &ctx->partial, &ctx->fe_a, &ctx->fe_b, &ctx->fe_taps, &ctx->chunk_peaks, &ctx->arrivals};
+  DevBuf* bufs[] = {&ctx->tab, &ctx->xstage, &ctx->X, &ctx->Y, &ctx->rows, &ctx->freq, &ctx->fset, &ctx->items, &ctx->out_peaks, &ctx->d0, &ctx->partial, &ctx->fe_a, &ctx->fe_b, &ctx->fe_taps, &ctx->chunk_peaks, &ctx->arrivals, &ctx->tie, &ctx->tie_scratch};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   if (ctx->pin_x.p) (void)hipHostFree(ctx->pin_x.p);
   if (ctx->pin_peaks.p) (void)hipHostFree(ctx->pin_peaks.p);
@@ -434,6 +485,12 @@ int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes) {
 
 int gacq_set_option(gacq_ctx* ctx, int option, long value) {
   if (!ctx || option < 0 || option >= GACQ_NOPTS) return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_set_option: unknown option %d", option);
+  // accepted range per option (GACQ_OPT_* order): switches 0/1(/2), counts bounded by what the kernels' index arithmetic carries
+  static const long kMax[GACQ_NOPTS] = {1, 1, 1000, 4096, 4096, 4, 2, 3, 1, 64, 1, 1, 1, 1, 1000000000L, 1L << 24};
+  const long lo = (option == GACQ_OPT_LDS_VARIANT) ? -1 : 0;
+  if (value < lo || value > kMax[option])
+    return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_set_option: value %ld out of range [%ld, %ld] for option %d", value, lo, kMax[option], option);
+  if (option == GACQ_OPT_SPLIT_TEAMS && value == 3) return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_set_option: split_teams must be 0, 1, 2 or 4");
   ctx->opt[option] = value;
   return GACQ_OK;
 }
@@ -645,20 +702,21 @@ LdsPath lds_path(const gacq_ctx* ctx, int N, int nepoch, int P, int F, int D, in
   p.use_lds = (ctx->engine == 2) || (ctx->engine == 0 && lds_supported(N) && !row_dump);
   if (!p.use_lds || !lds_supported(N) || row_dump) return p;
   p.fused16k = lds_fused_supported(ctx, N, P, F);
-  p.search1 = !p.fused16k && lds_search1_supported(ctx, N, B, F, (long)nepoch * D, P);
+  p.search1 = !p.fused16k && lds_search1_supported(ctx, N, B, F, (long)nepoch * D, P);      // only with GACQ_OPT_TIE_SAFE off
   p.fused4k = p.search1 || (!p.fused16k && lds_fused4k_supported(ctx, N, B, F, (long)nepoch * D));
   return p;
 }
 
-int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, const int* items, int nitems,
-                  const double* dopplers, int nd, const double* bias, int blocks, gacq_peak* d_out, float* d_qrow) {
+// NCO frequencies [F][D], forward-set index and item index per position -> ctx->freq / fset / items on the device (skipped when the
+// call repeats the grid uploaded last, as batched loops do)
+int upload_grid(gacq_sig* sig, int nepoch, const int* items, int nitems, const double* dopplers, int nd, const double* bias, int* F_out) {
   gacq_ctx* ctx = sig->ctx;
   const gacq_sigdesc& ds = sig->desc;
-  const int n = ds.n, N = sig->N, B = blocks, D = nd, P = nitems;
+  const int N = sig->N, D = nd, P = nitems;
   hipStream_t st = ctx->stream;
-
   Grid g = make_grid(ds, nitems, dopplers, nd, bias);
   const int F = g.F;
+  *F_out = F;
   int rc;
   double max_f = 0.0;
   for (double v : g.freq) max_f = std::max(max_f, std::fabs(v));
@@ -682,6 +740,18 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
     ctx->up_fset = g.fset;
     ctx->up_items = items_v;
   }
+  return GACQ_OK;
+}
+
+int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, const int* items, int nitems,
+                  const double* dopplers, int nd, const double* bias, int blocks, gacq_peak* d_out, float* d_qrow) {
+  gacq_ctx* ctx = sig->ctx;
+  const gacq_sigdesc& ds = sig->desc;
+  const int n = ds.n, N = sig->N, B = blocks, D = nd, P = nitems;
+  hipStream_t st = ctx->stream;
+  int F = 1;
+  int rc = upload_grid(sig, nepoch, items, nitems, dopplers, nd, bias, &F);
+  if (rc != GACQ_OK) return rc;
 
   if (ctx->engine == 5) return verify_search(sig, d_x, nsamp, nepoch, P, F, D, B, d_out, d_qrow);      // complex128 verification pipeline
 
@@ -698,6 +768,17 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
   if (ctx->engine == 3 && !split_supported(N))
     return set_error(ctx, GACQ_ERR_UNSUPPORTED, "engine 3 (split with rocFFT inner transforms) does not support N=%d", N);
 
+  // tie-safe locations: the reducers tag rows whose runner-up lag is within eps of the maximum, best_doppler_kernel lists the
+  // (epoch, item) pairs it cannot decide and gacq_tiesafe.hip re-evaluates their candidate rows in complex128
+  const bool tie = ctx->opt[GACQ_OPT_TIE_SAFE] != 0 && !d_qrow && !path.search1 && tie_supported(N);
+  const float tscale = tie ? tie_scale_of(ctx) : 1.0f;      // 1: only exact fp32 duplicates get tagged, and nobody looks
+  TieLists tl{};
+  gacq_peak* guesses = nullptr;
+  if (tie) {
+    if ((rc = tie_prepare(sig)) != GACQ_OK) return rc;
+    if ((rc = tie_lists(ctx, (long)nepoch * P, &tl, &guesses)) != GACQ_OK) return rc;
+  }
+
   // epochs per pass so that the forward-spectra buffer respects the workspace limit
   const bool fused16k = path.fused16k;      // one carrier per item: no forward-spectra buffer at all
   const size_t x_epoch_bytes = sizeof(float2) * (size_t)F * D * B * N;
@@ -705,9 +786,10 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
   const bool search1 = path.search1, fused4k = path.fused4k;
   if (fused16k || fused4k) Ec = nepoch;            // nothing but the 16-byte row records is buffered
   if (search1) {
-    const void* before_arr = ctx->arrivals.p;
+    // the kernel leaves its arrival counters zeroed -- unless a launch faulted or was aborted, and a grown buffer may come back at the
+    // old address with an unwritten tail: zeroed per launch (a 4-byte-per-item memset), never trusted
     if ((rc = ensure(ctx, ctx->arrivals, sizeof(unsigned) * (size_t)nepoch * P)) != GACQ_OK) return rc;
-    if (before_arr != ctx->arrivals.p) GACQ_HIP(ctx, hipMemsetAsync(ctx->arrivals.p, 0, ctx->arrivals.cap, st));      // the kernel leaves them zeroed
+    GACQ_HIP(ctx, hipMemsetAsync(ctx->arrivals.p, 0, sizeof(unsigned) * (size_t)nepoch * P, st));
   }
   if (!fused16k && !fused4k && (rc = ensure(ctx, ctx->X, x_epoch_bytes * Ec)) != GACQ_OK) return rc;
   if ((rc = ensure(ctx, ctx->rows, sizeof(RowRec) * (size_t)Ec * P * D)) != GACQ_OK) return rc;
@@ -722,13 +804,13 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
     if (fused16k) {
       stage_begin(ctx, 6);
       rc = lds_fused_search(ctx, xe, nsamp, ne, n, N, sig->spectra_lds, (const int*)ctx->items.p, (const int*)ctx->fset.p,
-                            (const double*)ctx->freq.p, (const float2*)ctx->tab.p, P, D, B, rows);
+                            (const double*)ctx->freq.p, (const float2*)ctx->tab.p, P, D, B, rows, tscale);
       stage_end(ctx);
       if (rc != GACQ_OK) return rc;
     } else if (fused4k) {
       stage_begin(ctx, 6);
       rc = lds_fused4k_search(ctx, xe, nsamp, ne, sig->spectra_lds, (const int*)ctx->items.p, (const double*)ctx->freq.p, (const float2*)ctx->tab.p, P, D, rows,
-                              search1 ? (unsigned*)ctx->arrivals.p : nullptr, search1 ? d_out + (size_t)e0 * P : nullptr, ds.metric_mode);
+                              tscale, search1 ? (unsigned*)ctx->arrivals.p : nullptr, search1 ? d_out + (size_t)e0 * P : nullptr, ds.metric_mode);
       stage_end(ctx);
       if (rc != GACQ_OK) return rc;
       if (search1) continue;                       // the Doppler scan ran inside the kernel
@@ -738,7 +820,7 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
       stage_end(ctx);
       if (rc != GACQ_OK) return rc;
       stage_begin(ctx, 6);
-      rc = lds_correlate(ctx, X, sig->spectra_lds, (const int*)ctx->items.p, (const int*)ctx->fset.p, ne, P, F, D, B, N, rows);
+      rc = lds_correlate(ctx, X, sig->spectra_lds, (const int*)ctx->items.p, (const int*)ctx->fset.p, ne, P, F, D, B, N, rows, tscale);
       stage_end(ctx);
       if (rc != GACQ_OK) return rc;
     } else {
@@ -777,7 +859,7 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
           stage_end(ctx);
           if (rc != GACQ_OK) return rc;
           stage_begin(ctx, 4);
-          rc = split_inverse_reduce(ctx, Y, rows, g0, ng, B, N, d_qrow, false);   // outer inverse DFT + |.| + reduce
+          rc = split_inverse_reduce(ctx, Y, rows, g0, ng, B, N, d_qrow, tscale, false);   // outer inverse DFT + |.| + reduce
           stage_end(ctx);
           if (rc != GACQ_OK) return rc;
           continue;
@@ -789,7 +871,7 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
           stage_end(ctx);
           if (rc != GACQ_OK) return rc;
           stage_begin(ctx, 4);
-          rc = split_inverse_reduce(ctx, Y, rows, g0, ng, B, N, d_qrow, false, true, zpitch);   // twiddle + outer DFT-31 + |.| + reduce
+          rc = split_inverse_reduce(ctx, Y, rows, g0, ng, B, N, d_qrow, tscale, false, true, zpitch);   // twiddle + outer DFT-31 + |.| + reduce
           stage_end(ctx);
           if (rc != GACQ_OK) return rc;
           continue;
@@ -802,7 +884,7 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
         GACQ_HIP(ctx, hipGetLastError());
         if (use_split) {
           stage_begin(ctx, 3);
-          rc = split_inverse_reduce(ctx, Y, rows, g0, ng, B, N, d_qrow);      // inner inverse FFTs + outer DFT-31 + |.| + reduce
+          rc = split_inverse_reduce(ctx, Y, rows, g0, ng, B, N, d_qrow, tscale);      // inner inverse FFTs + outer DFT-31 + |.| + reduce
           stage_end(ctx);
           if (rc != GACQ_OK) return rc;
         } else {
@@ -811,7 +893,7 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
           stage_end(ctx);
           if (rc != GACQ_OK) return rc;
           stage_begin(ctx, 4);
-          hipLaunchKernelGGL(mag_peak_kernel, dim3((unsigned)ng), dim3(kBlock), 0, st, Y, rows, g0, B, N, 1.0f / (float)N, d_qrow);
+          hipLaunchKernelGGL(mag_peak_kernel, dim3((unsigned)ng), dim3(kBlock), 0, st, Y, rows, g0, B, N, 1.0f / (float)N, d_qrow, tscale);
           stage_end(ctx);
           GACQ_HIP(ctx, hipGetLastError());
         }
@@ -819,10 +901,15 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
     }
     const long nep = (long)ne * P;
     stage_begin(ctx, 5);
-    hipLaunchKernelGGL(best_doppler_kernel, dim3((unsigned)((nep + 3) / 4)), dim3(256), 0, st, rows,
-                       d_out + (size_t)e0 * P, nep, D, N, ds.metric_mode);
+    if (tie)
+      hipLaunchKernelGGL(best_doppler_kernel<true>, dim3((unsigned)((nep + 3) / 4)), dim3(256), 0, st, rows, d_out + (size_t)e0 * P, nep, D, N,
+                         ds.metric_mode, tl, guesses, tscale);
+    else
+      hipLaunchKernelGGL(best_doppler_kernel<false>, dim3((unsigned)((nep + 3) / 4)), dim3(256), 0, st, rows, d_out + (size_t)e0 * P, nep, D, N,
+                         ds.metric_mode, tl, guesses, tscale);
     stage_end(ctx);
     GACQ_HIP(ctx, hipGetLastError());
+    if (tie && (rc = tie_resolve(sig, tl, guesses, xe, nsamp, P, D, B, d_out + (size_t)e0 * P)) != GACQ_OK) return rc;
   }
   return GACQ_OK;
 }
@@ -846,6 +933,65 @@ int check_search_args(gacq_sig* sig, const void* x, size_t nsamp, int nepoch, co
 __global__ void zero_peaks_kernel(gacq_peak* out, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { out[i].metric = 0.0; out[i].idx = -1; out[i].d_index = -1; }
+}
+
+// TIE: shard winners whose metrics come within eps of the best one cannot be ordered in fp32 (each is an fp32 value unless its own
+// shard re-evaluated it): their rows are listed for re-evaluation in complex128, with GLOBAL Doppler indices, and tie_resolve_kernel
+// writes the record -- the same machinery as best_doppler_kernel<true>, one level up.
+template <bool TIE>
+__global__ void merge_peaks_kernel(const gacq_peak* __restrict__ peaks, gacq_peak* __restrict__ out, long n, int nshard,
+                                   const int* __restrict__ d0, TieLists tl, gacq_peak* __restrict__ guesses, float tie_scale) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  gacq_peak best;
+  best.metric = 0.0;
+  best.idx = -1;
+  best.d_index = -1;
+  double second = 0.0;
+  for (int s = 0; s < nshard; s++) {
+    const gacq_peak k = peaks[(long)s * n + i];
+    if (k.d_index < 0) continue;
+    if (k.metric > best.metric) { second = best.metric; best.metric = k.metric; best.idx = k.idx; best.d_index = k.d_index + d0[s]; }
+    else if (k.metric > second) second = k.metric;
+  }
+  const double thr = best.metric * (double)tie_scale;
+  if (!TIE || best.d_index < 0 || second < thr) { out[i] = best; return; }
+  int cnt = 0;
+  for (int s = 0; s < nshard; s++) {
+    const gacq_peak k = peaks[(long)s * n + i];
+    cnt += (k.d_index >= 0 && k.metric >= thr) ? 1 : 0;
+  }
+  const int slot0 = (int)atomicAdd(&tl.c->nrows, (unsigned)cnt);
+  if (slot0 < 0 || slot0 + cnt > tl.cap) {
+    for (int sl = slot0; sl < slot0 + cnt && sl < tl.cap && sl >= 0; sl++) { TieRow v; v.ep = -1; v.d = 0; tl.rows[sl] = v; }
+    out[i] = best;
+    atomicAdd(&tl.c->overflow, 1ull);
+    return;
+  }
+  const int epslot = (int)atomicAdd(&tl.c->neps, 1u);
+  TieEp te;
+  te.ep = (int)i; te.slot0 = slot0; te.cnt = cnt; te.pad = 0;
+  tl.eps[epslot] = te;
+  guesses[epslot] = best;
+  int off = 0;
+  for (int s = 0; s < nshard; s++) {                   // shards are in global Doppler order: ascending d
+    const gacq_peak k = peaks[(long)s * n + i];
+    if (k.d_index >= 0 && k.metric >= thr) { TieRow v; v.ep = (int)i; v.d = k.d_index + d0[s]; tl.rows[slot0 + off++] = v; }
+  }
+}
+
+int upload_d0(gacq_ctx* ctx, const int* shard_d0, int nshard) {
+  const void* d0_before = ctx->d0.p;
+  int rc = ensure(ctx, ctx->d0, sizeof(int) * 4096);
+  if (rc != GACQ_OK) return rc;
+  if (d0_before != ctx->d0.p) ctx->up_d0.clear();
+  const std::vector<int> d0_v(shard_d0, shard_d0 + nshard);
+  if (d0_v != ctx->up_d0) {
+    GACQ_HIP(ctx, hipMemcpyAsync(ctx->d0.p, shard_d0, sizeof(int) * nshard, hipMemcpyHostToDevice, ctx->stream));
+    GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->up_d0 = d0_v;
+  }
+  return GACQ_OK;
 }
 
 }  // namespace
@@ -889,45 +1035,48 @@ int gacq_search_batch_dev(gacq_sig* sig, const void* d_x, size_t nsamp, int nepo
                          blocks, (gacq_peak*)ctx->chunk_peaks.p + (size_t)c * n, nullptr);
       if (rc != GACQ_OK) return rc;
     }
-    return gacq_merge_peaks_dev(ctx, ctx->chunk_peaks.p, nch, d0.data(), n, d_out);
+    // slice winners within eps of each other are re-evaluated in complex128 like near-tied bins of one scan (tie-safe locations)
+    return gacq_merge_peaks_tiesafe_dev(sig, d_x, nsamp, nepoch, items, nitems, dopplers, nd, item_bias_hz, blocks, ctx->chunk_peaks.p, nch,
+                                        d0.data(), d_out);
   }
   return launch_search(sig, (const float2*)d_x, nsamp, nepoch, items, nitems, dopplers, nd, item_bias_hz, blocks,
                        (gacq_peak*)d_out, nullptr);
-}
-
-__global__ void merge_peaks_kernel(const gacq_peak* __restrict__ peaks, gacq_peak* __restrict__ out, long n, int nshard,
-                                   const int* __restrict__ d0) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  gacq_peak best;
-  best.metric = 0.0;
-  best.idx = -1;
-  best.d_index = -1;
-  for (int s = 0; s < nshard; s++) {
-    const gacq_peak k = peaks[(long)s * n + i];
-    if (k.d_index >= 0 && k.metric > best.metric) { best.metric = k.metric; best.idx = k.idx; best.d_index = k.d_index + d0[s]; }
-  }
-  out[i] = best;
 }
 
 int gacq_merge_peaks_dev(gacq_ctx* ctx, const void* d_peaks, int nshard, const int* shard_d0, long n, void* d_out) {
   if (!ctx || !d_peaks || !d_out || !shard_d0 || nshard <= 0 || nshard > 4096 || n <= 0)
     return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_merge_peaks_dev: bad argument");
   GACQ_DEVICE(ctx);
-  const void* d0_before = ctx->d0.p;
-  int rc = ensure(ctx, ctx->d0, sizeof(int) * 4096);
+  int rc = upload_d0(ctx, shard_d0, nshard);
   if (rc != GACQ_OK) return rc;
-  if (d0_before != ctx->d0.p) ctx->up_d0.clear();
-  const std::vector<int> d0_v(shard_d0, shard_d0 + nshard);
-  if (d0_v != ctx->up_d0) {
-    GACQ_HIP(ctx, hipMemcpyAsync(ctx->d0.p, shard_d0, sizeof(int) * nshard, hipMemcpyHostToDevice, ctx->stream));
-    GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->up_d0 = d0_v;
-  }
-  hipLaunchKernelGGL(merge_peaks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const gacq_peak*)d_peaks,
-                     (gacq_peak*)d_out, n, nshard, (const int*)ctx->d0.p);
+  hipLaunchKernelGGL(merge_peaks_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const gacq_peak*)d_peaks,
+                     (gacq_peak*)d_out, n, nshard, (const int*)ctx->d0.p, TieLists{}, (gacq_peak*)nullptr, 1.0f);
   GACQ_HIP(ctx, hipGetLastError());
   return GACQ_OK;
+}
+
+int gacq_merge_peaks_tiesafe_dev(gacq_sig* sig, const void* d_x, size_t nsamp, int nepoch, const int* items, int nitems, const double* dopplers,
+                                 int nd, const double* item_bias_hz, int blocks, const void* d_peaks, int nshard, const int* shard_d0,
+                                 void* d_out) {
+  int rc = check_search_args(sig, d_x, nsamp, nepoch, items, nitems, dopplers, nd, blocks, d_out);
+  if (rc != GACQ_OK) return rc;
+  gacq_ctx* ctx = sig->ctx;
+  if (!d_peaks || !shard_d0 || nshard <= 0 || nshard > 4096) return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_merge_peaks_tiesafe_dev: bad argument");
+  GACQ_DEVICE(ctx);
+  const long n = (long)nepoch * nitems;
+  const bool tie = ctx->opt[GACQ_OPT_TIE_SAFE] != 0 && ctx->engine != 5 && nd > 0 && blocks > 0 && tie_supported(sig->N);
+  if (!tie) return gacq_merge_peaks_dev(ctx, d_peaks, nshard, shard_d0, n, d_out);
+  if ((rc = upload_d0(ctx, shard_d0, nshard)) != GACQ_OK) return rc;
+  int F = 1;
+  if ((rc = upload_grid(sig, nepoch, items, nitems, dopplers, nd, item_bias_hz, &F)) != GACQ_OK) return rc;      // the FULL grid: global bins
+  TieLists tl{};
+  gacq_peak* guesses = nullptr;
+  if ((rc = tie_prepare(sig)) != GACQ_OK) return rc;
+  if ((rc = tie_lists(ctx, n, &tl, &guesses)) != GACQ_OK) return rc;
+  hipLaunchKernelGGL(merge_peaks_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const gacq_peak*)d_peaks,
+                     (gacq_peak*)d_out, n, nshard, (const int*)ctx->d0.p, tl, guesses, tie_scale_of(ctx));
+  GACQ_HIP(ctx, hipGetLastError());
+  return tie_resolve(sig, tl, guesses, (const float2*)d_x, nsamp, nitems, nd, blocks, (gacq_peak*)d_out);
 }
 
 int gacq_finalize(const gacq_sigdesc* desc, const gacq_peak* peaks, int nshard, const int* shard_d0, int nitems,

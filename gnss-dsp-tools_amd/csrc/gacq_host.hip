@@ -271,6 +271,54 @@ int gacq_group_search_batch(gacq_gsig* s, const float* x_iq, size_t nsamp, int n
       const int rck = ring_collect(g->ctx[k], ring[k], slot);
       if (rck != GACQ_OK) return group_fail(g, k, rck);
     }
+    if (by_doppler && G > 1) {
+      // Tie-safe locations across devices: device winners whose metrics come within eps of the best one cannot be ordered in fp32.
+      // The host looks for such pairs (two compares per record); only when the chunk has one does a member re-evaluate them in
+      // complex128 (gacq_merge_peaks_tiesafe_dev on the samples it still holds in its staging slot) and the merged records
+      // replace the host merge below.
+      int k0 = 0;
+      while (k0 < G && lo[k0 + 1] == lo[k0]) k0++;
+      gacq_ctx* c0 = g->ctx[k0];
+      bool ambiguous = false;
+      if (c0->opt[GACQ_OPT_TIE_SAFE] != 0 && c0->engine != 5 && tie_supported(s->sig[k0]->N)) {
+        const double scale = (double)tie_scale_of(c0);
+        for (long i = 0; i < (long)ne * nitems && !ambiguous; i++) {
+          double best = 0.0, second = 0.0;
+          for (int k = 0; k < G; k++) {
+            if (lo[k + 1] == lo[k]) continue;
+            const gacq_peak& pk = ((const gacq_peak*)ring[k]->pin_out[slot].p)[i];
+            if (pk.d_index < 0) continue;
+            if (pk.metric > best) { second = best; best = pk.metric; } else if (pk.metric > second) second = pk.metric;
+          }
+          ambiguous = best > 0.0 && second >= best * scale;
+        }
+      }
+      if (ambiguous) {
+        DeviceGuard dg(c0->device);
+        const size_t n = (size_t)ne * nitems;
+        std::vector<gacq_peak> all((size_t)G * n, gacq_peak{0.0, -1, -1});
+        for (int k = 0; k < G; k++)
+          if (lo[k + 1] > lo[k]) std::memcpy(&all[(size_t)k * n], ring[k]->pin_out[slot].p, sizeof(gacq_peak) * n);
+        int rcm = ensure(c0, c0->chunk_peaks, sizeof(gacq_peak) * all.size());
+        if (rcm == GACQ_OK) rcm = ensure(c0, c0->out_peaks, sizeof(gacq_peak) * n);
+        if (rcm != GACQ_OK) return group_fail(g, k0, rcm);
+        if (hipMemcpyAsync(c0->chunk_peaks.p, all.data(), sizeof(gacq_peak) * all.size(), hipMemcpyHostToDevice, c0->stream) != hipSuccess ||
+            hipStreamSynchronize(c0->stream) != hipSuccess)
+          return group_error(g, GACQ_ERR_HIP, "gacq_group_search_batch: upload of the device records failed");
+        rcm = gacq_merge_peaks_tiesafe_dev(s->sig[k0], ring[k0]->dev_in[slot].p, nsamp, ne, items, nitems, dopplers, nd, item_bias_hz, blocks,
+                                           c0->chunk_peaks.p, G, lo.data(), c0->out_peaks.p);
+        if (rcm != GACQ_OK) return group_fail(g, k0, rcm);
+        std::vector<gacq_peak> merged(n);
+        if (hipMemcpyAsync(merged.data(), c0->out_peaks.p, sizeof(gacq_peak) * n, hipMemcpyDeviceToHost, c0->stream) != hipSuccess ||
+            hipStreamSynchronize(c0->stream) != hipSuccess)
+          return group_error(g, GACQ_ERR_HIP, "gacq_group_search_batch: download of the merged records failed");
+        for (int e = 0; e < ne; e++) {
+          const int rcf = gacq_finalize(&s->desc, merged.data() + (size_t)e * nitems, 1, nullptr, nitems, dopplers, nd, out + (size_t)(e0 + e) * nitems);
+          if (rcf != GACQ_OK) return group_error(g, rcf, gacq_last_error(nullptr));
+        }
+        return GACQ_OK;
+      }
+    }
     for (int e = 0; e < ne; e++) {
       gacq_result* dst = out + (size_t)(e0 + e) * nitems;
       if (by_doppler) {

@@ -62,18 +62,36 @@ __device__ __forceinline__ void apply_table(v2 (&v)[kR], const v2 (&pw)[15]) {
 // smallest k with a non-empty mask and its lowest lane are the smallest lag attaining the maximum (np.argmax returns the first
 // maximum, acquire-gps-l1.py:34).  24 VALU instructions instead of the 47 of a running (value, index) pair per lane; the
 // bookkeeping runs on the scalar unit.  Magnitudes are >= 0, so their bit patterns order like the values.
-__device__ __forceinline__ void wave_first_max(const float (&m)[kR], unsigned base, unsigned mult, unsigned kstride, float& wmaxf,
-                                               unsigned& widx) {
+__device__ __forceinline__ void wave_first_max(const float (&m)[kR], unsigned base, unsigned mult, unsigned kstride, float tie_scale,
+                                               float& wmaxf, unsigned& widx) {
   float lmax = __builtin_fmaxf(__builtin_fmaxf(m[0], m[1]), m[2]);
 #pragma unroll
   for (int k = 3; k + 1 < kR; k += 2) lmax = __builtin_fmaxf(__builtin_fmaxf(lmax, m[k]), m[k + 1]);
   lmax = __builtin_fmaxf(lmax, m[kR - 1]);
   wmaxf = __builtin_bit_cast(float, wave_max_u32(__builtin_bit_cast(unsigned, lmax)));
+  // Tie-safe locations: the compare runs against thr = (1 - eps) * maximum instead of the maximum itself.  When exactly one entry
+  // passes -- all but about one row in 10^4 -- it is the maximum and its mask is its location; the masks of all k are folded on the
+  // scalar unit (seen: lanes with an entry, dup: lanes with two) to tell.  Otherwise the row is tagged ambiguous (kTieBit; the
+  // Doppler scan decides whether it matters and has it re-evaluated in complex128) and the exact first maximum is located the
+  // plain way in a wave-uniform branch.  tie_scale == 1 degenerates to the equality compare.
+  const float thr = wmaxf * tie_scale;
+  unsigned long long seen = 0, dup = 0;
   widx = 0xffffffffu;
 #pragma unroll
   for (int k = kR - 1; k >= 0; k--) {                                            // descending: the last assignment is the smallest k
-    const unsigned long long mk = __builtin_amdgcn_ballot_w64(m[k] == wmaxf);
+    const unsigned long long mk = __builtin_amdgcn_ballot_w64(m[k] >= thr);
+    dup |= seen & mk;
+    seen |= mk;
     if (mk) widx = kstride * k + base + mult * (unsigned)__builtin_ctzll(mk);
+  }
+  if ((dup | (seen & (seen - 1))) != 0) {
+    widx = 0xffffffffu;
+#pragma unroll
+    for (int k = kR - 1; k >= 0; k--) {
+      const unsigned long long mk = __builtin_amdgcn_ballot_w64(m[k] == wmaxf);
+      if (mk) widx = kstride * k + base + mult * (unsigned)__builtin_ctzll(mk);
+    }
+    widx |= (unsigned)kTieBit;
   }
 }
 
@@ -374,7 +392,7 @@ __device__ __forceinline__ void dma_wait_read(v2 (&x)[kR], const v2* reg) {
 }
 
 // cross-wave (max, first argmax, sum) of one item through the scratch words behind the regions; thread 0 writes the record
-__device__ __forceinline__ void big_reduce_store(char* smem, float peak, unsigned widx, float wsum, RowRec* dst) {
+__device__ __forceinline__ void big_reduce_store(char* smem, float peak, unsigned widx, float wsum, float tie_scale, RowRec* dst) {
   float* s_peak = reinterpret_cast<float*>(smem + kBigScratch);
   int* s_idx = reinterpret_cast<int*>(smem + kBigScratch + 64);
   double* s_sum = reinterpret_cast<double*>(smem + kBigScratch + 128);
@@ -382,16 +400,10 @@ __device__ __forceinline__ void big_reduce_store(char* smem, float peak, unsigne
   if ((t & 63) == 0) { s_peak[t >> 6] = peak; s_idx[t >> 6] = (int)widx; s_sum[t >> 6] = (double)wsum; }
   lds_barrier();
   if (t == 0) {
-    float bp = s_peak[0];
-    int bi = s_idx[0];
-    double bs = s_sum[0];
-    for (int w = 1; w < kBigThreads / 64; w++) {
-      if (s_peak[w] > bp || (s_peak[w] == bp && s_idx[w] < bi)) { bp = s_peak[w]; bi = s_idx[w]; }
-      bs += s_sum[w];
-    }
     RowRec r;
-    r.peak = bp;
-    r.idx = bi;
+    combine_tagged(kBigThreads / 64, [&](int w) { return s_peak[w]; }, [&](int w) { return s_idx[w]; }, tie_scale, r.peak, r.idx);
+    double bs = s_sum[0];
+    for (int w = 1; w < kBigThreads / 64; w++) bs += s_sum[w];
     r.sum = bs;
     *dst = r;
   }
@@ -457,7 +469,8 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_permute_kernel(const float
 __global__ __launch_bounds__(kBigThreads) void lds16k_correlate_kernel(const float2* __restrict__ X, const float2* __restrict__ C,
                                                                         const int* __restrict__ items, const int* __restrict__ fset,
                                                                         const float2* __restrict__ twn, RowRec* __restrict__ rows,
-                                                                        int E, int P, int F, int D, int B, int pch, int nchunk, int ugroup) {
+                                                                        int E, int P, int F, int D, int B, int pch, int nchunk, int ugroup,
+                                                                        float tie_scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v2* lds = reinterpret_cast<v2*>(smem);
   const int t = threadIdx.x;
@@ -531,8 +544,8 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_correlate_kernel(const flo
     // lane l of wave w holds lags 64 w + l + 1024 k: first maximum as in lds_correlate_kernel
     float peak;
     unsigned widx;
-    wave_first_max(q, (unsigned)__builtin_amdgcn_readfirstlane(t & ~63), 1u, 1024u, peak, widx);
-    big_reduce_store(smem, peak, widx, wave_add_f32(sum_f), rows + (e * P + p) * (long)D + d);
+    wave_first_max(q, (unsigned)__builtin_amdgcn_readfirstlane(t & ~63), 1u, 1024u, tie_scale, peak, widx);
+    big_reduce_store(smem, peak, widx, wave_add_f32(sum_f), tie_scale, rows + (e * P + p) * (long)D + d);
   }
 #ifdef GACQ_PHASE_TIMING16
   if ((t & 63) == 0) {
@@ -554,7 +567,7 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_fused_kernel(const float2*
                                                                     const int* __restrict__ fset, const double* __restrict__ freq,
                                                                     const float2* __restrict__ nco_tab,
                                                                     const float2* __restrict__ twn, RowRec* __restrict__ rows, int n,
-                                                                    int P, int D, int B) {
+                                                                    int P, int D, int B, float tie_scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v2* lds = reinterpret_cast<v2*>(smem);
   const int t = threadIdx.x;
@@ -614,8 +627,8 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_fused_kernel(const float2*
   for (int k = 1; k < kR; k++) sum_f += q[k];
   float peak;
   unsigned widx;
-  wave_first_max(q, (unsigned)__builtin_amdgcn_readfirstlane(t & ~63), 1u, 1024u, peak, widx);      // lane l of wave w: lags 64 w + l + 1024 k
-  big_reduce_store(smem, peak, widx, wave_add_f32(sum_f), rows + (e * P + p) * (long)D + d);
+  wave_first_max(q, (unsigned)__builtin_amdgcn_readfirstlane(t & ~63), 1u, 1024u, tie_scale, peak, widx);      // lane l of wave w: lags 64 w + l + 1024 k
+  big_reduce_store(smem, peak, widx, wave_add_f32(sum_f), tie_scale, rows + (e * P + p) * (long)D + d);
 }
 
 // ---- inner transforms of the split engine (N = R * 4096, gacq_split.hip) -----------------------------
@@ -743,7 +756,7 @@ template <int MINW, bool B1, bool CACHEX, bool OPAQUE, bool PRETW = false>
 __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float2* __restrict__ X, const float2* __restrict__ C,
                                                                       const int* __restrict__ items, const int* __restrict__ fset,
                                                                       const float2* __restrict__ tw, RowRec* __restrict__ rows,
-                                                                      int E, int P, int F, int D, int B, int pch, int nchunk) {
+                                                                      int E, int P, int F, int D, int B, int pch, int nchunk, float tie_scale) {
   __shared__ v2 lds[kLdsElems];
   __shared__ float s_peak[kBlock / 64];
   __shared__ int s_idx[kBlock / 64];
@@ -842,23 +855,15 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float
     for (int k = 1; k < kR; k++) sum_f += q[k];
     float wmaxf;
     unsigned widx;
-    wave_first_max(q, (unsigned)__builtin_amdgcn_readfirstlane(t & ~63), 1u, 256u, wmaxf, widx);      // first maximum, like np.argmax
+    wave_first_max(q, (unsigned)__builtin_amdgcn_readfirstlane(t & ~63), 1u, 256u, tie_scale, wmaxf, widx);      // first maximum, like np.argmax
     const unsigned wmax = __builtin_bit_cast(unsigned, B1 ? wmaxf * inv_n : wmaxf);
     const float wsum = wave_add_f32(B1 ? sum_f * inv_n : sum_f);
     if ((t & 63) == 0) { s_peak[t >> 6] = __builtin_bit_cast(float, wmax); s_idx[t >> 6] = (int)widx; s_sum[t >> 6] = (double)wsum; }
     __syncthreads();   // also orders this item's exchange-2 reads before the next item's exchange-1 writes
     if (t == 0) {
-      float bp = s_peak[0];
-      int bi = s_idx[0];
-      double bs = s_sum[0];
-      for (int w = 1; w < kBlock / 64; w++) {
-        if (s_peak[w] > bp || (s_peak[w] == bp && s_idx[w] < bi)) { bp = s_peak[w]; bi = s_idx[w]; }
-        bs += s_sum[w];
-      }
       RowRec r;
-      r.peak = bp;
-      r.idx = bi;
-      r.sum = bs;
+      combine_tagged(kBlock / 64, [&](int w) { return s_peak[w]; }, [&](int w) { return s_idx[w]; }, tie_scale, r.peak, r.idx);
+      r.sum = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3];
       rows[(e * P + p) * (long)D + d] = r;
     }
   }
@@ -899,7 +904,7 @@ __device__ __forceinline__ void scan_item_wave(const RowRec* rows, int D, int N,
   for (int d = lane; d < D; d += 64) {
     const RowRec r = load_rowrec_agent(rows + d);
     const double m = normalised ? (double)r.peak / (r.sum / (double)N) : (double)r.peak;
-    if (m > best) { best = m; bidx = r.idx; bd = d; }
+    if (m > best) { best = m; bidx = r.idx & kIdxMask; bd = d; }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -941,7 +946,7 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_fused4k_kernel(const float2*
                                                                     const double* __restrict__ freq, const float2* __restrict__ nco_tab,
                                                                     const float2* __restrict__ tw, RowRec* __restrict__ rows, int E, int P,
                                                                     int D, int pch, int nchunk, int by_epoch, unsigned* __restrict__ arrivals,
-                                                                    gacq_peak* __restrict__ peaks, int normalised) {
+                                                                    gacq_peak* __restrict__ peaks, int normalised, float tie_scale) {
   __shared__ v2 lds[kLdsElems];
   __shared__ float s_peak[kBlock / 64];
   __shared__ int s_idx[kBlock / 64];
@@ -1044,23 +1049,15 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_fused4k_kernel(const float2*
     for (int k = 1; k < kR; k++) sum_f += m[k];
     float wmaxf;
     unsigned widx;
-    wave_first_max(m, (unsigned)__builtin_amdgcn_readfirstlane(t & ~63), 1u, 256u, wmaxf, widx);
+    wave_first_max(m, (unsigned)__builtin_amdgcn_readfirstlane(t & ~63), 1u, 256u, tie_scale, wmaxf, widx);
     const unsigned wmax = __builtin_bit_cast(unsigned, wmaxf * inv_n);
     const float wsum = wave_add_f32(sum_f * inv_n);
     if ((t & 63) == 0) { s_peak[t >> 6] = __builtin_bit_cast(float, wmax); s_idx[t >> 6] = (int)widx; s_sum[t >> 6] = (double)wsum; }
     __syncthreads();   // also orders this item's exchange-2 reads before the next item's exchange-1 writes
     if (t == 0) {
-      float bp = s_peak[0];
-      int bi = s_idx[0];
-      double bs = s_sum[0];
-      for (int w = 1; w < kBlock / 64; w++) {
-        if (s_peak[w] > bp || (s_peak[w] == bp && s_idx[w] < bi)) { bp = s_peak[w]; bi = s_idx[w]; }
-        bs += s_sum[w];
-      }
       RowRec r;
-      r.peak = bp;
-      r.idx = bi;
-      r.sum = bs;
+      combine_tagged(kBlock / 64, [&](int w) { return s_peak[w]; }, [&](int w) { return s_idx[w]; }, tie_scale, r.peak, r.idx);
+      r.sum = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3];
       if (SCAN) store_rowrec_agent(rows + (e * P + p) * (long)D + d, r);
       else rows[(e * P + p) * (long)D + d] = r;
     }
@@ -1137,14 +1134,14 @@ int lds_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n,
 bool lds_fused_supported(const gacq_ctx* ctx, int N, int P, int F) { return N == kBig && F == P && ctx->opt[GACQ_OPT_FUSED_16K]; }
 
 int lds_fused_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n, int N, const float2* spectra, const int* d_items,
-                     const int* d_fset, const double* d_freq, const float2* tab, int nitems, int D, int B, RowRec* rows) {
+                     const int* d_fset, const double* d_freq, const float2* tab, int nitems, int D, int B, RowRec* rows, float tie_scale) {
   if (N != kBig) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "fused LDS search: N=%d not supported", N);
   const float2* twn;
   int rc = twiddle_cache(ctx, "W16384_lo", kBig, 1024, &twn);
   if (rc != GACQ_OK) return rc;
   GACQ_HIP(ctx, hipFuncSetAttribute((const void*)lds16k_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes));
   hipLaunchKernelGGL(lds16k_fused_kernel<false>, dim3((unsigned)((long)nepoch * D * nitems)), dim3(kBigThreads), kBigLdsBytes, ctx->stream, x,
-                     nsamp, spectra, d_items, d_fset, d_freq, tab, twn, rows, n, nitems, D, B);
+                     nsamp, spectra, d_items, d_fset, d_freq, tab, twn, rows, n, nitems, D, B, tie_scale);
   GACQ_HIP(ctx, hipGetLastError());
   return GACQ_OK;
 }
@@ -1154,7 +1151,9 @@ int lds_fused_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, i
 // Single-launch search: worth it while every workgroup can be resident at once with at most a handful of rows each (one epoch of
 // 32 items x 40 bins: 640 workgroups of 1 forward + 2 inverse transforms); beyond that the two-kernel path / the batch kernel win.
 bool lds_search1_supported(const gacq_ctx* ctx, int N, int B, int F, long units, int nitems) {
-  return N == kLdsN && B == 1 && F == 1 && ctx->opt[GACQ_OPT_SEARCH1] != 0 && units <= 1024 && units * nitems <= 4096;
+  // the in-kernel Doppler scan has no re-evaluation hook: the single-launch form runs only with tie-safe locations switched off
+  return N == kLdsN && B == 1 && F == 1 && ctx->opt[GACQ_OPT_SEARCH1] != 0 && ctx->opt[GACQ_OPT_TIE_SAFE] == 0 && units <= 1024 &&
+         units * nitems <= 4096;
 }
 
 bool lds_fused4k_supported(const gacq_ctx* ctx, int N, int B, int F, long units) {
@@ -1162,8 +1161,8 @@ bool lds_fused4k_supported(const gacq_ctx* ctx, int N, int B, int F, long units)
 }
 
 int lds_fused4k_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, const float2* spectra, const int* d_items,
-                       const double* d_freq, const float2* tab, int nitems, int D, RowRec* rows, unsigned* arrivals, gacq_peak* peaks,
-                       int normalised) {
+                       const double* d_freq, const float2* tab, int nitems, int D, RowRec* rows, float tie_scale, unsigned* arrivals,
+                       gacq_peak* peaks, int normalised) {
   const float2* tw;
   int rc = twiddle_table(ctx, &tw);
   if (rc != GACQ_OK) return rc;
@@ -1180,16 +1179,17 @@ int lds_fused4k_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch,
   }
   if (ctx->opt[GACQ_OPT_LDS_PCH] >= 1) pch = (int)ctx->opt[GACQ_OPT_LDS_PCH];
   pch = std::min(pch, nitems);
+  if (arrivals) pch = std::min(pch, 64);      // the hand-over counts one arrival per lane of wave 0
   const int nchunk = (nitems + pch - 1) / pch;
   const int by_epoch = nepoch >= 64 ? 1 : 0;
   const long units8 = by_epoch ? (long)((nepoch + 7) / 8) * D : (units + 7) / 8;      // units per XCD
   const dim3 grid((unsigned)(8 * units8 * nchunk));
   if (arrivals)
     hipLaunchKernelGGL((lds_fused4k_kernel<2, false, true>), grid, dim3(kBlock), 0, ctx->stream, x, nsamp, spectra, d_items, d_freq, tab, tw, rows,
-                       nepoch, nitems, D, pch, nchunk, by_epoch, arrivals, peaks, normalised);
+                       nepoch, nitems, D, pch, nchunk, by_epoch, arrivals, peaks, normalised, tie_scale);
   else
     hipLaunchKernelGGL((lds_fused4k_kernel<4, true, false>), grid, dim3(kBlock), 0, ctx->stream, x, nsamp, spectra, d_items, d_freq, tab, tw, rows,
-                       nepoch, nitems, D, pch, nchunk, by_epoch, (unsigned*)nullptr, (gacq_peak*)nullptr, 0);
+                       nepoch, nitems, D, pch, nchunk, by_epoch, (unsigned*)nullptr, (gacq_peak*)nullptr, 0, tie_scale);
   GACQ_HIP(ctx, hipGetLastError());
   return GACQ_OK;
 }
@@ -1204,7 +1204,7 @@ int lds_debug_nco(gacq_ctx* ctx, int N, int n, const double* d_freq, bool fused,
     GACQ_HIP(ctx, hipFuncSetAttribute((const void*)lds16k_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes));
     hipLaunchKernelGGL(lds16k_fused_kernel<true>, dim3(1), dim3(kBigThreads), kBigLdsBytes, ctx->stream, (const float2*)nullptr, (size_t)0,
                        (const float2*)nullptr, (const int*)ctx->fset.p, (const int*)ctx->fset.p, d_freq, (const float2*)nullptr,
-                       (const float2*)nullptr, (RowRec*)d_idx, n, 1, 1, 1);
+                       (const float2*)nullptr, (RowRec*)d_idx, n, 1, 1, 1, 1.0f);
   } else if (N == kBig) {
     GACQ_HIP(ctx, hipFuncSetAttribute((const void*)lds16k_forward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes));
     hipLaunchKernelGGL(lds16k_forward_kernel<true>, dim3(1), dim3(kBigThreads), kBigLdsBytes, ctx->stream, (const float2*)nullptr, (size_t)0,
@@ -1218,7 +1218,7 @@ int lds_debug_nco(gacq_ctx* ctx, int N, int n, const double* d_freq, bool fused,
 }
 
 int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const int* d_items, const int* d_fset, int nepoch,
-                  int nitems, int F, int D, int B, int N, RowRec* rows) {
+                  int nitems, int F, int D, int B, int N, RowRec* rows, float tie_scale) {
   if (!lds_supported(N)) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "LDS FFT engine: N=%d not supported", N);
   if (N == kBig) {
     const float2* twn;
@@ -1240,7 +1240,7 @@ int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const i
     const long groups = (units8 + ugroup - 1) / ugroup;
     GACQ_HIP(ctx, hipFuncSetAttribute((const void*)lds16k_correlate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes));
     hipLaunchKernelGGL(lds16k_correlate_kernel, dim3((unsigned)(8 * groups * ugroup * nchunk)), dim3(kBigThreads), kBigLdsBytes, ctx->stream, X,
-                       spectra, d_items, d_fset, twn, rows, nepoch, nitems, F, D, B, pch, nchunk, ugroup);
+                       spectra, d_items, d_fset, twn, rows, nepoch, nitems, F, D, B, pch, nchunk, ugroup, tie_scale);
     GACQ_HIP(ctx, hipGetLastError());
     return GACQ_OK;
   }
@@ -1261,7 +1261,7 @@ int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const i
   const bool b1 = (B == 1) && (F == 1);
   auto kern = b1 ? lds_correlate_kernel<2, true, true, false> : lds_correlate_kernel<2, false, false, false>;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, X, spectra, d_items, d_fset, tw, rows, nepoch,
-                     nitems, F, D, B, pch, nchunk);
+                     nitems, F, D, B, pch, nchunk, tie_scale);
   GACQ_HIP(ctx, hipGetLastError());
   return GACQ_OK;
 }

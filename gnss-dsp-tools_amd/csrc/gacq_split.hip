@@ -98,8 +98,8 @@ __device__ __forceinline__ v2 ld_stream(const float2* p) {
 template <int R, bool TW, bool B1>
 __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_inverse_kernel(
     const float2* __restrict__ Z, RowRec* __restrict__ partial, const float2* __restrict__ tw, int M, int Mp, int B, int chunks, float inv_n,
-    float* __restrict__ q_out, int paired) {
-  __shared__ float s_peak[kBlock / 64];
+    float* __restrict__ q_out, int paired, float tie_scale) {
+  __shared__ float s_peak[kBlock / 64], s_second[kBlock / 64];
   __shared__ int s_idx[kBlock / 64];
   __shared__ double s_sum[kBlock / 64];
   constexpr bool kNT = B1 || R != 31;              // the multi-block R = 31 kernel (E6B, B3I, E5: 0.94 -> 0.99 ms) is the one case that loses
@@ -112,8 +112,7 @@ __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_i
   // instead of 15 x 8 bytes per lane -- changed nothing on the writing side and cost the reader 4 %: not kept.)
   const int pos = chunk * kBlock + threadIdx.x;
   const int n2 = paired ? ((pos & 511) >> 1) + 256 * (((pos >> 9) << 1) | (pos & 1)) : pos;
-  float peak = -1.0f;
-  int idx = 0x7fffffff;
+  Top2 top;                                        // (maximum, first argmax, runner-up): the runner-up makes the location tie-safe
   double sum = 0.0;
   if (n2 < M) {
     // loads first, asm afterwards: the machine scheduler does not move loads across inline asm
@@ -142,7 +141,7 @@ __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_i
       OuterDft<R, true>::run(v, [&](int n1, v2 val) {
         const float m = __builtin_amdgcn_sqrtf(norm2(val)) * inv_n;      // np.absolute(ifft(..)), 1/N folded in
         if (n1 == expect) {
-          if (m > peak) { peak = m; idx = M * n1 + n2; }
+          top.add(m, M * n1 + n2);
           sum_f += m;
           expect++;
         } else {
@@ -152,7 +151,7 @@ __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_i
 #pragma unroll
       for (int n1 = 0; n1 < R; n1++) {
         if (n1 >= expect) {                            // compile-time after unrolling: expect is a constant by now
-          if (late[n1] > peak) { peak = late[n1]; idx = M * n1 + n2; }
+          top.add(late[n1], M * n1 + n2);
           sum_f += late[n1];
         }
       }
@@ -177,7 +176,7 @@ __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_i
     }
 #pragma unroll
     for (int n1 = 0; n1 < R; n1++) {          // ascending idx = M n1 + n2: strict '>' keeps the first maximum
-      if (q[n1] > peak) { peak = q[n1]; idx = M * n1 + n2; }
+      top.add(q[n1], M * n1 + n2);
       sum += (double)q[n1];
       if (q_out) q_out[M * n1 + n2] = q[n1];
     }
@@ -185,23 +184,24 @@ __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_i
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
-    const float op = __shfl_down(peak, off);
-    const int oi = __shfl_down(idx, off);
+    const float op = __shfl_down(top.peak, off);
+    const int oi = __shfl_down(top.idx, off);
+    const float o2 = __shfl_down(top.second, off);
     const double os = __shfl_down(sum, off);
-    if (op > peak || (op == peak && oi < idx)) { peak = op; idx = oi; }
+    top.merge(op, oi, o2);
     sum += os;
   }
   const int t = threadIdx.x;
-  if ((t & 63) == 0) { s_peak[t >> 6] = peak; s_idx[t >> 6] = idx; s_sum[t >> 6] = sum; }
+  if ((t & 63) == 0) { s_peak[t >> 6] = top.peak; s_idx[t >> 6] = top.idx; s_second[t >> 6] = top.second; s_sum[t >> 6] = sum; }
   __syncthreads();
   if (t == 0) {
     for (int w = 1; w < kBlock / 64; w++) {
-      if (s_peak[w] > peak || (s_peak[w] == peak && s_idx[w] < idx)) { peak = s_peak[w]; idx = s_idx[w]; }
+      top.merge(s_peak[w], s_idx[w], s_second[w]);
       sum += s_sum[w];
     }
     RowRec r;
-    r.peak = peak;
-    r.idx = idx;
+    r.peak = top.peak;
+    r.idx = top.tagged(tie_scale);
     r.sum = sum;
     partial[g * chunks + chunk] = r;      // = blockIdx.x
   }
@@ -407,15 +407,14 @@ __global__ __launch_bounds__(NT * TEAMS, (DT == 1 ? 5 : (DT == 2 && R0 * R1 * R2
 }
 
 // partial[(g, chunk)] -> rows[g0 + g]
-__global__ void split_combine_kernel(const RowRec* __restrict__ partial, RowRec* __restrict__ rows, long g0, long ng, int chunks) {
+__global__ void split_combine_kernel(const RowRec* __restrict__ partial, RowRec* __restrict__ rows, long g0, long ng, int chunks, float tie_scale) {
   const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= ng) return;
-  RowRec best = partial[g * chunks];
-  for (int c = 1; c < chunks; c++) {
-    const RowRec r = partial[g * chunks + c];
-    if (r.peak > best.peak || (r.peak == best.peak && r.idx < best.idx)) { best.peak = r.peak; best.idx = r.idx; }
-    best.sum += r.sum;
-  }
+  const RowRec* part = partial + g * chunks;
+  RowRec best;
+  combine_tagged(chunks, [&](int c) { return part[c].peak; }, [&](int c) { return part[c].idx; }, tie_scale, best.peak, best.idx);
+  best.sum = part[0].sum;
+  for (int c = 1; c < chunks; c++) best.sum += part[c].sum;
   rows[g0 + g] = best;
 }
 
@@ -445,18 +444,18 @@ int launch_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, long rows, int 
 
 template <int R>
 int launch_inverse(gacq_ctx* ctx, const float2* Z, RowRec* partial, const float2* tw, int M, int Mp, int B, long ng, float inv_n,
-                   float* q_out, bool twiddle, int paired) {
+                   float* q_out, bool twiddle, int paired, float tie_scale) {
   const int chunks = (M + kBlock - 1) / kBlock;
   const dim3 grid((unsigned)(ng * chunks));
   const bool b1 = (B == 1) && !q_out;
   if (twiddle && b1)
-    hipLaunchKernelGGL((split_outer_inverse_kernel<R, true, true>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, Mp, B, chunks, inv_n, q_out, paired);
+    hipLaunchKernelGGL((split_outer_inverse_kernel<R, true, true>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, Mp, B, chunks, inv_n, q_out, paired, tie_scale);
   else if (twiddle)
-    hipLaunchKernelGGL((split_outer_inverse_kernel<R, true, false>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, Mp, B, chunks, inv_n, q_out, paired);
+    hipLaunchKernelGGL((split_outer_inverse_kernel<R, true, false>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, Mp, B, chunks, inv_n, q_out, paired, tie_scale);
   else if (b1)
-    hipLaunchKernelGGL((split_outer_inverse_kernel<R, false, true>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, Mp, B, chunks, inv_n, q_out, paired);
+    hipLaunchKernelGGL((split_outer_inverse_kernel<R, false, true>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, Mp, B, chunks, inv_n, q_out, paired, tie_scale);
   else
-    hipLaunchKernelGGL((split_outer_inverse_kernel<R, false, false>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, Mp, B, chunks, inv_n, q_out, paired);
+    hipLaunchKernelGGL((split_outer_inverse_kernel<R, false, false>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, Mp, B, chunks, inv_n, q_out, paired, tie_scale);
   GACQ_HIP(ctx, hipGetLastError());
   return GACQ_OK;
 }
@@ -604,8 +603,8 @@ int split_debug_nco(gacq_ctx* ctx, int N, int n, const double* d_freq, int* d_id
   return GACQ_OK;
 }
 
-int split_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng, int B, int N, float* q_out, bool inner, bool twiddle_only,
-                         int Mp) {
+int split_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng, int B, int N, float* q_out, float tie_scale, bool inner,
+                         bool twiddle_only, int Mp) {
   const int R = split_radix(N);
   if (!R) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "split engine: N=%d not supported", N);
   const int M = N / R;
@@ -623,15 +622,15 @@ int split_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long n
   RowRec* partial = (RowRec*)ctx->partial.p;
   const float inv_n = 1.0f / (float)N;
   switch (R) {
-    case 31: rc = launch_inverse<31>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner, paired); break;
-    case 40: rc = launch_inverse<40>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner, paired); break;
-    case 20: rc = launch_inverse<20>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner, paired); break;
-    case 16: rc = launch_inverse<16>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner, paired); break;
-    default: rc = launch_inverse<4>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner, paired); break;
+    case 31: rc = launch_inverse<31>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner, paired, tie_scale); break;
+    case 40: rc = launch_inverse<40>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner, paired, tie_scale); break;
+    case 20: rc = launch_inverse<20>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner, paired, tie_scale); break;
+    case 16: rc = launch_inverse<16>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner, paired, tie_scale); break;
+    default: rc = launch_inverse<4>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner, paired, tie_scale); break;
   }
   if (rc != GACQ_OK) return rc;
   hipLaunchKernelGGL(split_combine_kernel, dim3((unsigned)((ng + 127) / 128)), dim3(128), 0, ctx->stream, (const RowRec*)partial, rows,
-                     g0, ng, chunks);
+                     g0, ng, chunks, tie_scale);
   GACQ_HIP(ctx, hipGetLastError());
   return GACQ_OK;
 }

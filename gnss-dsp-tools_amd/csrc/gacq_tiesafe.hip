@@ -1,0 +1,315 @@
+// Tie-safe peak locations: complex128 re-evaluation of near-tied rows, entirely on the device.
+//
+// The reference computes search() in complex128 and takes np.argmax / the strict-'>' Doppler scan on fp64 values
+// (acquire-gps-l1.py:30-39).  The fp32 engines agree with it to ~1e-6 in the metric, which is inside north_star's 1e-5 bar -- but
+// when the runner-up lag or bin is closer than that to the winner, fp32 rounding decides which one is reported (about one search
+// in 50 000 on noise).  The row reductions therefore flag rows whose runner-up lag is within eps of the maximum, the Doppler scan
+// (best_doppler_kernel) does the same across bins and appends every (epoch, item) it cannot decide to a device-side list together
+// with its candidate rows; the kernels here then
+//   tie_recheck_kernel   recompute exactly those rows in complex128 -- table-NCO mix, FFT, C_p * conj(.), inverse FFT, |.|/N,
+//                        sum over blocks, (max, first argmax, sum) -- for any FFT length with prime factors in {2, 3, 5, 7, 11, 13, 31} (a
+//                        mixed-radix Stockham transform through a global-memory scratch row, one workgroup per row), and
+//   tie_resolve_kernel   redo the strict-'>' scan of the ambiguous pairs on the complex128 values and write their records.
+// Nothing returns to the host: the lists are filled, consumed and reset inside the stream, a launch without ambiguous pairs
+// costs two empty kernels.  The arithmetic is engine 5's (gacq_verify.hip) with another FFT implementation; both are held to
+// the reference's goldens at 1e-10.
+#include "gacq_common.h"
+
+#include <algorithm>
+#include <cmath>
+
+using namespace gacq;
+
+namespace {
+
+constexpr int kTieThreads = 256;
+constexpr int kMaxPasses = 20;
+struct Radices { int count; unsigned char r[kMaxPasses]; };
+
+__device__ __forceinline__ double2 cmul64(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// W_N^k = exp(-2 pi i k / N), k < N, evaluated with sincospi on the exactly reduced argument
+__global__ void twiddle64_kernel(double2* __restrict__ w, int N) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= N) return;
+  double s, c;
+  sincospi(-2.0 * (double)k / (double)N, &s, &c);
+  w[k] = make_double2(c, s);
+}
+
+// One radix-R Stockham pass (decimation in frequency, autosort) over the whole row by the whole workgroup:
+//   y[q + s (R p + k)] = W_n^{p k} * sum_j a[q + s (p + m j)] W_R^{j k},   n = R m, p < m, q < s
+template <int R>
+__device__ void stockham_pass(const double2* __restrict__ a, double2* __restrict__ y, const double2* __restrict__ WN, int N, int n, int s) {
+  const int m = n / R, step_r = N / R, step_n = N / n;
+  for (int i = threadIdx.x; i < N / R; i += kTieThreads) {
+    const int p = i / s, q = i - p * s;
+    double2 v[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) v[j] = a[q + s * (p + m * j)];
+    constexpr int kUnrollK = R <= 5 ? R : 1;          // the large radices keep the k loop rolled (R x R products otherwise)
+#pragma unroll kUnrollK
+    for (int k = 0; k < R; k++) {
+      double2 acc = v[0];
+#pragma unroll
+      for (int j = 1; j < R; j++) {
+        const double2 w = WN[((j * k) % R) * step_r];
+        acc.x += v[j].x * w.x - v[j].y * w.y;
+        acc.y += v[j].x * w.y + v[j].y * w.x;
+      }
+      if (k) acc = cmul64(acc, WN[(int)(((long)p * k) % n) * step_n]);
+      y[q + s * (R * p + k)] = acc;
+    }
+  }
+}
+
+// forward FFT of the row in `a` (N values) using `b` as the second buffer; returns the buffer that holds the result
+__device__ double2* fft_row(double2* a, double2* b, const double2* __restrict__ WN, int N, const Radices& rad) {
+  int n = N, s = 1;
+  for (int ip = 0; ip < rad.count; ip++) {
+    const int r = rad.r[ip];
+    __syncthreads();
+    switch (r) {
+      case 2: stockham_pass<2>(a, b, WN, N, n, s); break;
+      case 3: stockham_pass<3>(a, b, WN, N, n, s); break;
+      case 4: stockham_pass<4>(a, b, WN, N, n, s); break;
+      case 5: stockham_pass<5>(a, b, WN, N, n, s); break;
+      case 7: stockham_pass<7>(a, b, WN, N, n, s); break;
+      case 11: stockham_pass<11>(a, b, WN, N, n, s); break;
+      case 13: stockham_pass<13>(a, b, WN, N, n, s); break;
+      default: stockham_pass<31>(a, b, WN, N, n, s); break;
+    }
+    double2* t = a; a = b; b = t;
+    n /= r;
+    s *= r;
+  }
+  __syncthreads();
+  return a;
+}
+
+// One workgroup per listed row: q[k] = sum_b | ifft( C_p * conj(fft(x[b n : b n + N] * nco)) )[k] | in complex128
+// (acquire-gps-l1.py:28-35; |ifft(Y)| = |fft(conj(Y))| / N, so one forward transform routine serves both directions).
+__global__ __launch_bounds__(kTieThreads) void tie_recheck_kernel(TieLists tl, const float2* __restrict__ x, size_t epoch_stride,
+                                                                   const double2* __restrict__ C64, const int* __restrict__ items,
+                                                                   const int* __restrict__ fset, const double* __restrict__ freq,
+                                                                   const double2* __restrict__ tab64, const double2* __restrict__ WN,
+                                                                   char* __restrict__ scratch, int n, int N, int P, int D, int B, Radices rad) {
+  __shared__ double s_peak[kTieThreads], s_sum[kTieThreads];
+  __shared__ int s_idx[kTieThreads];
+  const unsigned count = min(tl.c->nrows, (unsigned)tl.cap);
+  char* mine = scratch + (size_t)blockIdx.x * ((size_t)N * 40);
+  double2* bufa = reinterpret_cast<double2*>(mine);
+  double2* bufb = bufa + N;
+  double* q = reinterpret_cast<double*>(bufb + N);
+  const double inv_n = 1.0 / (double)N;
+  const int t = threadIdx.x;
+  for (unsigned slot = blockIdx.x; slot < count; slot += gridDim.x) {
+    const TieRow row = tl.rows[slot];
+    if (row.ep < 0) continue;                                            // voided slot of a pair that did not fit (uniform over the workgroup)
+    const long e = row.ep / P;
+    const int p = row.ep - (int)e * P;
+    const double f = freq[(long)fset[p] * D + row.d];
+    const double2* Cp = C64 + (long)items[p] * N;
+    for (int i = t; i < N; i += kTieThreads) q[i] = 0.0;
+    for (int b = 0; b < B; b++) {
+      const float2* src = x + e * epoch_stride + (size_t)b * n;
+      for (int i = t; i < N; i += kTieThreads) {
+        const float2 sv = src[i];
+        const double2 w = tab64[nco_index(f, i)];                     // gnsstools/nco.py:6-10
+        bufa[i] = make_double2((double)sv.x * w.x - (double)sv.y * w.y, (double)sv.x * w.y + (double)sv.y * w.x);
+      }
+      double2* X = fft_row(bufa, bufb, WN, N, rad);
+      double2* other = (X == bufa) ? bufb : bufa;
+      for (int i = t; i < N; i += kTieThreads) {
+        const double2 xv = X[i], cv = Cp[i];                          // conj(C_p * conj(X)) = conj(C_p) * X
+        X[i] = make_double2(cv.x * xv.x + cv.y * xv.y, cv.x * xv.y - cv.y * xv.x);
+      }
+      double2* Z = fft_row(X, other, WN, N, rad);
+      for (int i = t; i < N; i += kTieThreads) q[i] += hypot(Z[i].x * inv_n, Z[i].y * inv_n);
+      __syncthreads();                                                 // the row buffers are rewritten by the next block's mix
+    }
+    double peak = -1.0, sum = 0.0;
+    int idx = 0x7fffffff;
+    for (int i = t; i < N; i += kTieThreads) {                         // ascending i per thread: strict '>' keeps the first maximum
+      const double v = q[i];
+      if (v > peak) { peak = v; idx = i; }
+      sum += v;
+    }
+    s_peak[t] = peak; s_sum[t] = sum; s_idx[t] = idx;
+    __syncthreads();
+    for (int off = kTieThreads / 2; off > 0; off >>= 1) {
+      if (t < off) {
+        const double op = s_peak[t + off];
+        const int oi = s_idx[t + off];
+        if (op > s_peak[t] || (op == s_peak[t] && oi < s_idx[t])) { s_peak[t] = op; s_idx[t] = oi; }
+        s_sum[t] += s_sum[t + off];
+      }
+      __syncthreads();
+    }
+    if (t == 0) { TieRec r; r.peak = s_peak[0]; r.sum = s_sum[0]; r.idx = s_idx[0]; r.pad = 0; tl.recs[slot] = r; }
+    __syncthreads();
+  }
+}
+
+// Strict-'>' scan of every ambiguous (epoch, item) over its re-evaluated rows, in Doppler order, running best starting at 0
+// (acquire-gps-l1.py:25,36-39).  Rows that were not re-evaluated lie more than eps below the fp32 winner and cannot win.  One
+// workgroup; resets the list counters for the next launch.  d_shift: Doppler index of the grid's first bin in the caller's
+// numbering (0 for a plain search).
+__global__ __launch_bounds__(256) void tie_resolve_kernel(TieLists tl, gacq_peak* __restrict__ out, const gacq_peak* __restrict__ fp32_guess, int N,
+                                                           int normalised) {
+  const unsigned neps = min(tl.c->neps, (unsigned)tl.cap);
+  unsigned moved = 0;
+  for (unsigned i = threadIdx.x; i < neps; i += blockDim.x) {
+    const TieEp ep = tl.eps[i];
+    double best = 0.0;
+    int bidx = -1, bd = -1;
+    for (int s = ep.slot0; s < ep.slot0 + ep.cnt; s++) {
+      const TieRec r = tl.recs[s];
+      const double m = normalised ? r.peak / (r.sum / (double)N) : r.peak;
+      if (m > best) { best = m; bidx = r.idx; bd = tl.rows[s].d; }
+    }
+    gacq_peak o;
+    o.metric = best;
+    o.idx = bidx;
+    o.d_index = bd;
+    const gacq_peak g = fp32_guess[i];
+    if (g.idx != bidx || g.d_index != bd) moved++;
+    out[ep.ep] = o;
+  }
+  if (moved) atomicAdd(&tl.c->moved, (unsigned long long)moved);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    tl.c->flagged += neps;
+    tl.c->rows += min(tl.c->nrows, (unsigned)tl.cap);
+    tl.c->nrows = 0;
+    tl.c->neps = 0;
+  }
+}
+
+bool factorise(int N, Radices& rad) {
+  rad.count = 0;
+  for (int r : {4, 2, 3, 5, 7, 11, 13, 31}) {
+    while (N % r == 0) {
+      if (rad.count == kMaxPasses) return false;
+      rad.r[rad.count++] = (unsigned char)r;
+      N /= r;
+    }
+  }
+  return N == 1;
+}
+
+}  // namespace
+
+namespace gacq {
+
+bool tie_supported(int N) {
+  Radices rad;
+  return factorise(N, rad);
+}
+
+int tie_capacity(const gacq_ctx* ctx, long nep) {
+  if (ctx->opt[GACQ_OPT_TIE_CAP] > 0) return (int)std::min<long>(ctx->opt[GACQ_OPT_TIE_CAP], 1L << 24);
+  return (int)std::min<long>(64 + nep / 16, 1L << 20);
+}
+
+float tie_scale_of(const gacq_ctx* ctx) {
+  const long ppb = std::max<long>(0, std::min<long>(ctx->opt[GACQ_OPT_TIE_EPS_PPB], 1000000000L));
+  return (float)(1.0 - (double)ppb * 1e-9);
+}
+
+// layout of ctx->tie: [TieCounters | fp32 guesses (gacq_peak x cap) | TieEp x cap | TieRow x cap | TieRec x cap]
+int tie_lists(gacq_ctx* ctx, long nep, TieLists* out, gacq_peak** guesses) {
+  const int cap = tie_capacity(ctx, nep);
+  const size_t bytes = 64 + (size_t)cap * (sizeof(gacq_peak) + sizeof(TieEp) + sizeof(TieRow) + sizeof(TieRec));
+  if (cap > ctx->tie_cap || !ctx->tie.p) {
+    TieCounters keep{};
+    if (ctx->tie.p) {
+      GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      GACQ_HIP(ctx, hipMemcpy(&keep, ctx->tie.p, sizeof keep, hipMemcpyDeviceToHost));
+    }
+    int rc = ensure(ctx, ctx->tie, bytes);
+    if (rc != GACQ_OK) return rc;
+    keep.nrows = keep.neps = 0;
+    GACQ_HIP(ctx, hipMemcpy(ctx->tie.p, &keep, sizeof keep, hipMemcpyHostToDevice));
+    ctx->tie_cap = cap;
+  }
+  // the lists are always laid out for the allocated capacity; a smaller request only lowers the fill limit
+  char* base = (char*)ctx->tie.p;
+  const int lay = ctx->tie_cap;
+  out->c = (TieCounters*)base;
+  *guesses = (gacq_peak*)(base + 64);
+  out->eps = (TieEp*)(base + 64 + (size_t)lay * sizeof(gacq_peak));
+  out->rows = (TieRow*)((char*)out->eps + (size_t)lay * sizeof(TieEp));
+  out->recs = (TieRec*)((char*)out->rows + (size_t)lay * sizeof(TieRow));
+  out->cap = cap;
+  return GACQ_OK;
+}
+
+int verify_spectra(gacq_sig* s);      // gacq_verify.hip: complex128 code spectra, built on first use
+
+int tie_prepare(gacq_sig* sig) {
+  if (!tie_supported(sig->N)) return GACQ_OK;
+  return verify_spectra(sig);
+}
+
+// Re-evaluate the listed rows and rewrite the records of the ambiguous pairs; asynchronous on the ctx stream.
+// ctx->freq / fset / items hold the grid of the search that filled the lists.
+int tie_resolve(gacq_sig* sig, const TieLists& tl, const gacq_peak* guesses, const float2* d_x, size_t nsamp, int P, int D, int B, gacq_peak* d_out) {
+  gacq_ctx* ctx = sig->ctx;
+  const int N = sig->N;
+  Radices rad;
+  if (!factorise(N, rad)) return set_error(ctx, GACQ_ERR_INTERNAL, "tie_resolve: N=%d has a prime factor > 31", N);
+  const void* p = nullptr;
+  int rc;
+  auto it = ctx->tables.find("nco64");
+  if (it == ctx->tables.end()) {
+    std::vector<double2> h(kNcoTableSize);
+    for (int k = 0; k < kNcoTableSize; k++) {
+      const double a = 2.0 * M_PI * (double)k * (1.0 / kNcoTableSize);       // np.exp(2*pi*1j*np.arange(NT)*(1.0/NT))  nco.py:4
+      h[k] = make_double2(std::cos(a), std::sin(a));
+    }
+    if ((rc = table_cache(ctx, "nco64", h.data(), sizeof(double2) * kNcoTableSize, &p)) != GACQ_OK) return rc;
+  } else {
+    p = it->second.p;
+  }
+  const double2* tab64 = (const double2*)p;
+  const std::string key = "W64_" + std::to_string(N);
+  auto wt = ctx->tables.find(key);
+  if (wt == ctx->tables.end()) {
+    DevBuf b;
+    GACQ_HIP(ctx, hipMalloc(&b.p, sizeof(double2) * (size_t)N));
+    b.cap = sizeof(double2) * (size_t)N;
+    hipLaunchKernelGGL(twiddle64_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, (double2*)b.p, N);
+    GACQ_HIP(ctx, hipGetLastError());
+    wt = ctx->tables.emplace(key, b).first;
+  }
+  const double2* WN = (const double2*)wt->second.p;
+  // workgroups in flight: enough to take a burst of rows side by side, bounded by 64 MiB of row scratch (40 bytes per point)
+  const size_t row_bytes = (size_t)N * 40;
+  const int G = (int)std::max<size_t>(4, std::min<size_t>(64, ((size_t)64 << 20) / row_bytes));
+  if ((rc = ensure(ctx, ctx->tie_scratch, row_bytes * G)) != GACQ_OK) return rc;
+  hipLaunchKernelGGL(tie_recheck_kernel, dim3((unsigned)G), dim3(kTieThreads), 0, ctx->stream, tl, d_x, nsamp, (const double2*)sig->spectra64,
+                     (const int*)ctx->items.p, (const int*)ctx->fset.p, (const double*)ctx->freq.p, tab64, WN, (char*)ctx->tie_scratch.p,
+                     sig->desc.n, N, P, D, B, rad);
+  GACQ_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(tie_resolve_kernel, dim3(1), dim3(256), 0, ctx->stream, tl, d_out, guesses, N, sig->desc.metric_mode);
+  GACQ_HIP(ctx, hipGetLastError());
+  return GACQ_OK;
+}
+
+}  // namespace gacq
+
+extern "C" int gacq_get_tie_stats(gacq_ctx* ctx, long long out[4]) {
+  if (!ctx || !out) return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_get_tie_stats: bad argument");
+  out[0] = out[1] = out[2] = out[3] = 0;
+  if (!ctx->tie.p) return GACQ_OK;
+  GACQ_DEVICE(ctx);
+  GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  TieCounters c;
+  GACQ_HIP(ctx, hipMemcpy(&c, ctx->tie.p, sizeof c, hipMemcpyDeviceToHost));
+  out[0] = (long long)c.flagged;
+  out[1] = (long long)c.rows;
+  out[2] = (long long)c.overflow;
+  out[3] = (long long)c.moved;
+  return GACQ_OK;
+}

@@ -57,7 +57,8 @@ class ShardedSearch:
 
             def finish(gathered):
                 if gathered.is_cuda:
-                    return self.engine.merge_peaks_dev(gathered, b[:-1])
+                    # tie-safe merge: slice winners within eps of each other are re-evaluated in complex128 (every rank holds x)
+                    return self.engine.merge_peaks_tiesafe_dev(name, x, items, dopplers, blocks, gathered, b[:-1])
                 return merge_peaks_host(gathered.numpy(), b[:-1])
             return local, finish
         # item split: every rank searches the whole Doppler grid for a contiguous slice of the items; slices are padded to
@@ -135,11 +136,11 @@ class ShardedSearch:
             bounds.append(b)
             shapes.append(tuple(loc.shape))
         if self._solo():
-            return PendingJobs(self, locals_, None, None, shapes, bounds)
+            return PendingJobs(self, locals_, None, None, shapes, bounds, jobs)
         flat = torch.cat([t.view(-1) for t in locals_])
         gathered = torch.empty(self.world * flat.numel(), dtype=flat.dtype, device=flat.device)
         work = self.dist.all_gather_into_tensor(gathered, flat, group=self.group, async_op=async_op)      # the ONE collective
-        return PendingJobs(self, locals_, gathered.view(self.world, flat.numel()), work if async_op else None, shapes, bounds)
+        return PendingJobs(self, locals_, gathered.view(self.world, flat.numel()), work if async_op else None, shapes, bounds, jobs)
 
     def results(self, name, items, merged, dopplers):
         """Merged peaks -> per-epoch lists of the reference's (metric, code, doppler) tuples."""
@@ -167,8 +168,9 @@ class PendingSearch:
 class PendingJobs:
     """A sharded multi-job search whose single exchange may still be in flight (ShardedSearch.search_jobs_async)."""
 
-    def __init__(self, owner, locals_, gathered, work, shapes, bounds):
+    def __init__(self, owner, locals_, gathered, work, shapes, bounds, jobs=None):
         self.owner, self.locals_, self.gathered, self.work, self.shapes, self.bounds = owner, locals_, gathered, work, shapes, bounds
+        self.jobs = jobs
 
     def shards(self):
         """The un-merged exchange buffer [world, sum of job record counts * 2] (None on a single rank): what every rank
@@ -183,11 +185,19 @@ class PendingJobs:
             return self.locals_
         g = self.shards()
         out, off = [], 0
-        for shp, b in zip(self.shapes, self.bounds):
+        for k, (shp, b) in enumerate(zip(self.shapes, self.bounds)):
             cnt = int(np.prod(shp))
             part = g[:, off:off + cnt].contiguous().view((self.owner.world,) + shp)
             off += cnt
-            out.append(self.owner.engine.merge_peaks_dev(part, b[:-1]) if part.is_cuda else merge_peaks_host(part.numpy(), b[:-1]))
+            if not part.is_cuda:
+                out.append(merge_peaks_host(part.numpy(), b[:-1]))
+                continue
+            job, eng = self.jobs[k], self.owner.engine
+            if job.get("family"):
+                base, fam, _ = eng._family(job["family"], job["items"])
+                out.append(eng.merge_peaks_tiesafe_dev(fam.sig, job["x"], fam.prns, job["dopplers"], job["blocks"], part, b[:-1], _signal=fam))
+            else:
+                out.append(eng.merge_peaks_tiesafe_dev(job["name"], job["x"], job["items"], job["dopplers"], job["blocks"], part, b[:-1]))
         return out
 
 

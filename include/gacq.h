@@ -128,7 +128,15 @@ int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes);
                                 /*     memory through the PCIe BAR (large-BAR devices) instead of pinned staging + DMA                  */
 #define GACQ_OPT_WATCH_RESULTS 12 /* [1] gacq_search (BAR upload path only): wait for completion by watching the pinned result records for  */
                                 /*     the last kernel's stores (bounded spin, then hipStreamSynchronize) instead of a runtime sync          */
-#define GACQ_NOPTS 13
+#define GACQ_OPT_TIE_SAFE 13      /* [1] tie-safe peak locations: every (epoch, item) whose winning lag or Doppler bin has a runner-up    */
+                                /*     within GACQ_OPT_TIE_EPS_PPB of it is re-evaluated in complex128 on the device (the reference's     */
+                                /*     arithmetic type, acquire-gps-l1.py:30-39) before its record is written, so the reported location is */
+                                /*     the complex128 one and not whichever side of a near-tie the fp32 rounding fell on                   */
+#define GACQ_OPT_TIE_EPS_PPB 14   /* [8000] relative gap, in parts per billion, below which two magnitudes / metrics count as tied         */
+                                /*     (8e-6 ~ 6 x the worst fp32-vs-complex128 metric error observed); 1000000000 re-evaluates every row  */
+#define GACQ_OPT_TIE_CAP 15       /* [0 = auto: 64 + (epochs x items) / 16] rows one call can re-evaluate; pairs beyond it keep their fp32  */
+                                /*     answer and are counted in gacq_get_tie_stats()[2]                                                    */
+#define GACQ_NOPTS 16
 int gacq_set_option(gacq_ctx* ctx, int option, long value);
 int gacq_get_option(gacq_ctx* ctx, int option, long* value);
 
@@ -193,12 +201,26 @@ void gacq_group_signal_destroy(gacq_gsig* sig);
 int gacq_group_search_batch(gacq_gsig* sig, const float* x_iq, size_t nsamp, int nepoch, const int* items, int nitems,
                             const double* dopplers, int nd, const double* item_bias_hz, int blocks, gacq_result* out);
 
+/* Tie-safe bookkeeping since gacq_create (synchronises the ctx stream): out[0] ambiguous (epoch, item) pairs found, out[1] rows
+ * re-evaluated in complex128, out[2] pairs that kept their fp32 answer because the re-evaluation list was full or the FFT length has
+ * a prime factor the complex128 row kernel does not carry (it has 2, 3, 5, 7, 11, 13 and 31: every length the reference's scripts use), out[3] pairs whose location the re-evaluation changed. */
+int gacq_get_tie_stats(gacq_ctx* ctx, long long out[4]);
+
 /* Device-side shard merge: d_peaks [nshard][n] (as gathered from the ranks, shard s covering Doppler
  * indices from shard_d0[s]) -> d_out [n] with global d_index; shards scanned in order with strict '>'
  * so the lowest Doppler bin wins ties exactly like the reference's scan (acquire-gps-l1.py:36-39).
  * Asynchronous on the ctx stream. */
 int gacq_merge_peaks_dev(gacq_ctx* ctx, const void* d_peaks, int nshard, const int* shard_d0, long n,
                          void* d_out);
+
+/* The same merge for callers that run with tie-safe locations (GACQ_OPT_TIE_SAFE, the default): shard winners whose metrics come
+ * within GACQ_OPT_TIE_EPS_PPB of the best one are re-evaluated in complex128 on this device before the scan decides -- every rank
+ * holds the samples and all code spectra, so any rank can do it -- which makes the merged record the one an unsharded tie-safe
+ * search writes, bit for bit.  The search arguments are those of the search the shards came from, with the FULL Doppler grid
+ * (d_x: [nepoch][nsamp] on the device).  Asynchronous on the ctx stream. */
+int gacq_merge_peaks_tiesafe_dev(gacq_sig* sig, const void* d_x, size_t nsamp, int nepoch, const int* items, int nitems,
+                                 const double* dopplers, int nd, const double* item_bias_hz, int blocks, const void* d_peaks,
+                                 int nshard, const int* shard_d0, void* d_out);
 
 /* Host-side last step (acquire-gps-l1.py:36-40): merge `nshard` peaks per item in shard order with
  * strict '>' (shard s covers Doppler indices [shard_d0[s], ...)), then convert to the reference's

@@ -4,8 +4,8 @@ workspace limit, tuning switches) draws through
   (a) the default engine with default switches and a roomy workspace,
   (b) the same engine with random switches (items / Doppler bins per workgroup, fused kernels on/off, teams) and a random small
       workspace (group chunks, epoch chunks, Doppler slices)            -> must equal (a) byte for byte,
-  (c) the complex128 verification pipeline (engine 5)                   -> same peak location, metric within 2e-6; a different
-      location only counts as a near-tie if the two metrics agree to 1e-6.
+  (c) the complex128 verification pipeline (engine 5)                   -> the SAME peak location, always (tie-safe locations:
+      near-tied candidates are re-evaluated in complex128 on the device, gacq_tiesafe.hip), metric within 2e-6.
 usage: tools/fuzz_engines.py [seconds] [seed]"""
 import json
 import os
@@ -103,13 +103,12 @@ def main():
             bugs += 1
             print("METRIC off vs complex128:", float(rel[same].max()), json.dumps(desc), flush=True)
         for k in np.nonzero(~same)[0]:
-            if rel[k] < 1e-6:
-                flips += 1
-            else:
-                bugs += 1
-                print("LOCATION differs vs complex128 (not a near-tie, rel %.3g):" % rel[k], json.dumps(desc), flush=True)
+            flips += 1
+            bugs += 1
+            print("LOCATION differs vs complex128 (rel metric difference %.3g):" % rel[k], json.dumps(desc), flush=True)
     print(json.dumps({"draws": n, "searches": searches, "seconds": round(time.time() - t0, 1), "draws_by_fft_length": by_n, "failures": bugs,
-                      "near_tie_location_flips_vs_complex128": flips, "worst_rel_metric_err_vs_complex128": worst}))
+                      "near_tie_location_flips_vs_complex128": flips, "worst_rel_metric_err_vs_complex128": worst,
+                      "tie_safe": ref.tie_stats()}))
     ref.close()
     ver.close()
     sys.exit(1 if bugs else 0)
