@@ -251,16 +251,22 @@ def condense(o, wall_s):
     return d
 
 
-def reference_precision(args, env, f32_value, epochs=64, seconds=1.0):
-    """The headline workload (config 2) in the reference's own arithmetic type: engine 5 keeps every value complex128 / fp64 on
-    the device (mix, rocFFT double-precision transforms, conj-multiply, magnitudes, metric).  Timed for >= `seconds`, and its
-    peaks are compared with the fp32 engine's on the same epochs (locations must be identical, metrics within 1e-5)."""
+FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X data sheet, FP64 vector (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz); SURVEY App. A plans with 79
+
+
+def reference_precision(args, env, f32_value, epochs=1024, seconds=1.0):
+    """The headline workload (config 2, the same 1024-epoch step) in the reference's own arithmetic type: engine 5 keeps every value
+    complex128 / fp64 on the device.  For N = 4096, B = 1 that is ONE kernel per search (fused4k_c128_kernel: table-NCO mix, forward
+    transform, C_p * conj(.), inverse transform, |.|, row reduction, all in fp64 in one workgroup's registers + LDS).  Timed for >=
+    `seconds` with its own roofline (useful FP64 flop over the kernel's HIP-event time against the FP64 vector peak); the fp32 engine is
+    timed in the SAME loop (same epochs, same synchronisation cadence) for a like-for-like ratio, and the two engines' peak records are
+    compared on the same epochs (locations must be identical -- tie-safe locations -- and metrics within 1e-5)."""
     from gnss_dsp_tools_amd import acquire
     dev = env["dev"]
     job = build_jobs(CONFIGS[2], epochs, dev)[0]
     sig, items, dop, B = job["sig"], job["items"], job["dop"], job["B"]
-    res = {}
-    peaks = {}
+    cells = epochs * len(items) * len(dop) * sig.nfft
+    rate, peaks, res = {}, {}, {}
     for label, which in (("f64", 5), ("f32", 0)):
         eng = acquire.Engine(env["local_rank"], engine=which)
         eng.use_torch_stream(dev)
@@ -269,21 +275,44 @@ def reference_precision(args, env, f32_value, epochs=64, seconds=1.0):
                 pk = eng.search_batch_dev(sig, job["x"], items, dop, B)
             torch.cuda.synchronize(dev)
             peaks[label] = pk.cpu().numpy().view(acquire.PEAK_DTYPE).reshape(epochs, len(items))
+            n, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < seconds:
+                for _ in range(2):
+                    eng.search_batch_dev(sig, job["x"], items, dop, B)
+                torch.cuda.synchronize(dev)
+                n += 2
+            dt = time.perf_counter() - t0
+            rate[label] = {"value": n * cells / dt, "ms_per_step": dt / n * 1e3, "steps_timed": n, "seconds_timed": dt}
             if which == 5:
-                n, t0 = 0, time.perf_counter()
-                while time.perf_counter() - t0 < seconds:
-                    for _ in range(2):
-                        eng.search_batch_dev(sig, job["x"], items, dop, B)
-                    torch.cuda.synchronize(dev)
-                    n += 2
-                dt = time.perf_counter() - t0
-                cells = epochs * len(items) * len(dop) * sig.nfft
-                res = {"engine": "5: complex128 verification pipeline (fp64 table-NCO mix, rocFFT double-precision transforms, fp64 conj-multiply, "
-                                 "magnitudes, metric and Doppler scan), the reference's arithmetic type", "dtype": "f64",
-                       "workload": "BASELINE config 2, %d epochs/step resident in HBM" % epochs, "value": n * cells / dt, "unit": "cells/s",
-                       "ms_per_step": dt / n * 1e3, "steps_timed": n, "seconds_timed": dt, "f32_over_f64": f32_value / (n * cells / dt)}
+                # the kernel's own duration from HIP events on the launch stream (stage 6 = the fused row kernel)
+                eng.set_profiling(True)
+                eng.reset_stage_times()
+                for _ in range(4):
+                    eng.search_batch_dev(sig, job["x"], items, dop, B)
+                torch.cuda.synchronize(dev)
+                st = eng.stage_times()
+                eng.set_profiling(False)
+                k_ms, k_n = st["lds_correlate"]
+                rows = epochs * len(dop) * (len(items) + 1)                      # inverse rows + ONE forward row per (epoch, Doppler bin)
+                Nf = sig.nfft
+                flop = epochs * (len(items) * len(dop) * (5 * Nf * 12 + 10 * Nf) + len(dop) * (5 * Nf * 12 + 6 * Nf))
+                if k_n:
+                    avg_ms = k_ms / k_n
+                    ach = flop / (avg_ms * 1e-3) / 1e12
+                    res["roofline"] = {"kernel": "fused4k_c128_kernel", "bound": "valu", "unit": "TFLOP/s", "achieved": ach,
+                                       "peak": FP64_VECTOR_PEAK_TFLOPS, "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "avg_kernel_ms": avg_ms,
+                                       "useful_flop_per_launch": flop, "rows_per_launch": rows,
+                                       "note": "useful FP64 flop of the rows one launch transforms (5 N log2 N per transform, 6 N per complex "
+                                               "product, 4 N for |.|; one forward transform per (epoch, Doppler bin) counts) over the kernel's "
+                                               "HIP-event duration, against the FP64 vector peak"}
         finally:
             eng.close()
+    res.update({"engine": "5: complex128 on the device (fp64 table-NCO mix, transforms, conj-multiply, magnitudes, metric and Doppler scan), the "
+                          "reference's arithmetic type; N = 4096, B = 1: one fused kernel per search (fused4k_c128_kernel)", "dtype": "f64",
+                "workload": "BASELINE config 2, %d epochs/step resident in HBM" % epochs, "unit": "cells/s"})
+    res.update(rate["f64"])
+    res["f32_same_loop"] = rate["f32"]
+    res["f32_over_f64"] = rate["f32"]["value"] / rate["f64"]["value"]
     a, b = peaks["f32"], peaks["f64"]
     res["f32_vs_f64_on_the_same_%d_epochs" % epochs] = {
         "searches": int(a.size), "peak_location_mismatches": int(((a["idx"] != b["idx"]) | (a["d_index"] != b["d_index"])).sum()),

@@ -76,7 +76,7 @@ struct gacq_ctx {
   gacq::DevBuf tab, xstage, X, Y, rows, freq, fset, items, out_peaks, d0, partial, fe_a, fe_b, fe_taps, chunk_peaks, arrivals;
   gacq::DevBuf tie, tie_scratch;       // tie-safe re-evaluation: counters + lists, and the complex128 row scratch (gacq_tiesafe.hip)
   int tie_cap = 0;                     // list capacity the `tie` buffer was laid out for
-  long opt[GACQ_NOPTS] = {1, 1, -1, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 1, 8000, 0};   // gacq_set_option values (defaults documented in include/gacq.h)
+  long opt[GACQ_NOPTS] = {1, 1, -1, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 1, 8000, 0, 1};   // gacq_set_option values (defaults documented in include/gacq.h)
   gacq::DevBuf pin_x, pin_peaks;       // pinned host staging for the host-buffer entry point (gacq_search)
   gacq::DevBuf bar_x;                  // fine-grained device memory the host writes directly through the PCIe BAR (small gacq_search inputs)
   bool large_bar = false;              // hipDeviceProp_t.isLargeBar: device memory is host-addressable

@@ -486,7 +486,7 @@ int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes) {
 int gacq_set_option(gacq_ctx* ctx, int option, long value) {
   if (!ctx || option < 0 || option >= GACQ_NOPTS) return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_set_option: unknown option %d", option);
   // accepted range per option (GACQ_OPT_* order): switches 0/1(/2), counts bounded by what the kernels' index arithmetic carries
-  static const long kMax[GACQ_NOPTS] = {1, 1, 1000, 4096, 4096, 4, 2, 3, 1, 64, 1, 1, 1, 1, 1000000000L, 1L << 24};
+  static const long kMax[GACQ_NOPTS] = {1, 1, 1000, 4096, 4096, 4, 2, 3, 1, 64, 1, 1, 1, 1, 1000000000L, 1L << 24, 1};
   const long lo = (option == GACQ_OPT_LDS_VARIANT) ? -1 : 0;
   if (value < lo || value > kMax[option])
     return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_set_option: value %ld out of range [%ld, %ld] for option %d", value, lo, kMax[option], option);

@@ -1,0 +1,122 @@
+// Length-4096 complex128 transform in one 256-thread workgroup (16 points per lane, three radix-16 passes, two LDS exchanges):
+// the decomposition of gacq_ldsfft.hip's fft4096 in the reference's own arithmetic type (numpy complex128,
+// acquire-gps-l1.py:30-33).  Shared by the fused complex128 search kernel of engine 5 (gacq_verify.hip) and by the re-evaluation
+// of near-tied rows (gacq_tiesafe.hip).  Plain fp64 arithmetic (v_fma_f64 / v_add_f64 / v_mul_f64: half the fp32 vector rate on
+// this part); real and imaginary parts go through LDS as two 8-byte planes, so the bank-conflict-free index patterns of the fp32
+// engine (8-byte elements, row pitch 257 in the second exchange) carry over unchanged.  LDS: 2 x 16 x 257 x 8 B = 65.8 KB per
+// workgroup -> two workgroups per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace gacq {
+namespace f64 {
+
+constexpr int kN = 4096;
+constexpr int kPitch = 257;
+constexpr int kPlane = 16 * kPitch;                      // doubles per plane
+constexpr int kLdsBytes = 2 * kPlane * (int)sizeof(double);
+
+struct cd { double x, y; };
+__device__ __forceinline__ cd operator+(cd a, cd b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cd operator-(cd a, cd b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cd operator*(cd a, cd b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ cd conj(cd a) { return {a.x, -a.y}; }
+__device__ __forceinline__ cd add_i(cd a, cd b) { return {a.x - b.y, a.y + b.x}; }       // a + i b
+__device__ __forceinline__ cd sub_i(cd a, cd b) { return {a.x + b.y, a.y - b.x}; }       // a - i b
+
+// sqrt(a) for a >= 0 from v_rsq_f64 and two Newton steps (Goldschmidt form): a dozen fp64 operations without the scaling branches of
+// the library routine; the result is within an ulp of the correctly rounded value, far below the 1e-10 the complex128 paths are held to
+__device__ __forceinline__ double sqrt_pos(double a) {
+  const double y = __builtin_amdgcn_rsq(a);
+  double g = a * y, h = 0.5 * y;
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  const double d = __builtin_fma(-g, g, a);
+  g = __builtin_fma(d, h, g);
+  return a > 0.0 ? g : 0.0;
+}
+
+__device__ __forceinline__ constexpr int rev16(int k) { return 4 * (k & 3) + (k >> 2); }
+
+template <bool INV> __device__ __forceinline__ void dft4(cd& a, cd& b, cd& c, cd& d) {
+  const cd s0 = a + c, d0 = a - c, s1 = b + d, t = b - d;
+  a = s0 + s1;
+  c = s0 - s1;
+  b = INV ? add_i(d0, t) : sub_i(d0, t);
+  d = INV ? sub_i(d0, t) : add_i(d0, t);
+}
+
+// W16^m (forward exp(-2 pi i m / 16); INV: conjugate)
+template <bool INV> __device__ __forceinline__ cd w16(int m) {
+  constexpr double c1 = 0.92387953251128673848, s1 = 0.38268343236508978178, h = 0.70710678118654752440;
+  const double re = (m == 1) ? c1 : (m == 2) ? h : (m == 3) ? s1 : (m == 6) ? -h : (m == 9) ? -c1 : 0.0;
+  const double im = (m == 1) ? s1 : (m == 2) ? h : (m == 3) ? c1 : (m == 6) ? h : (m == 9) ? -s1 : 0.0;
+  return {re, INV ? im : -im};
+}
+
+// In-place 16-point DFT; X[k] is left in register rev16(k)
+template <bool INV> __device__ __forceinline__ void dft16(cd (&v)[16]) {
+#pragma unroll
+  for (int n0 = 0; n0 < 4; n0++) dft4<INV>(v[n0], v[n0 + 4], v[n0 + 8], v[n0 + 12]);      // A[n0][k0] at v[n0 + 4 k0]
+  v[5] = v[5] * w16<INV>(1);
+  v[6] = v[6] * w16<INV>(2);
+  v[7] = v[7] * w16<INV>(3);
+  v[9] = v[9] * w16<INV>(2);
+  v[10] = INV ? cd{-v[10].y, v[10].x} : cd{v[10].y, -v[10].x};                              // W16^4 = -i (inverse: +i)
+  v[11] = v[11] * w16<INV>(6);
+  v[13] = v[13] * w16<INV>(3);
+  v[14] = v[14] * w16<INV>(6);
+  v[15] = v[15] * w16<INV>(9);
+#pragma unroll
+  for (int k0 = 0; k0 < 4; k0++) dft4<INV>(v[4 * k0], v[4 * k0 + 1], v[4 * k0 + 2], v[4 * k0 + 3]);   // X[k0 + 4 k1] at v[4 k0 + k1]
+}
+
+// v[rev16(k)] *= w^k, k = 1..15 (product tree of depth <= 4)
+__device__ __forceinline__ void apply_powers(cd (&v)[16], cd w1) {
+  const cd w2 = w1 * w1, w3 = w2 * w1, w4 = w2 * w2;
+  v[rev16(1)] = v[rev16(1)] * w1;    v[rev16(2)] = v[rev16(2)] * w2;    v[rev16(3)] = v[rev16(3)] * w3;
+  const cd w5 = w4 * w1, w6 = w3 * w3, w7 = w4 * w3, w8 = w4 * w4;
+  v[rev16(4)] = v[rev16(4)] * w4;    v[rev16(5)] = v[rev16(5)] * w5;    v[rev16(6)] = v[rev16(6)] * w6;    v[rev16(7)] = v[rev16(7)] * w7;
+  const cd w9 = w8 * w1, w10 = w5 * w5, w11 = w8 * w3, w12 = w6 * w6;
+  v[rev16(8)] = v[rev16(8)] * w8;    v[rev16(9)] = v[rev16(9)] * w9;    v[rev16(10)] = v[rev16(10)] * w10; v[rev16(11)] = v[rev16(11)] * w11;
+  v[rev16(12)] = v[rev16(12)] * w12;
+  const cd w13 = w8 * w5, w14 = w7 * w7, w15 = w8 * w7;
+  v[rev16(13)] = v[rev16(13)] * w13; v[rev16(14)] = v[rev16(14)] * w14; v[rev16(15)] = v[rev16(15)] * w15;
+}
+
+// In: v[j] = x[t + 256 j]; out: v[rev16(k2)] = X[t + 256 k2] (unnormalised for INV).  wa = W_4096^t, wb = W_256^(t & 15) (forward
+// values).  lds: kLdsBytes.  The caller puts a barrier between two transforms that use the same LDS buffer.
+template <bool INV> __device__ __forceinline__ void fft4096(cd (&v)[16], double* lds, cd wa, cd wb, int t) {
+  double* lre = lds;
+  double* lim = lds + kPlane;
+  if (INV) { wa.y = -wa.y; wb.y = -wb.y; }
+  dft16<INV>(v);
+  apply_powers(v, wa);
+  {  // exchange 1: (n0, n1; k0) -> (n0, k0; n1)
+    const int wbase = (t & 15) + 256 * (t >> 4);
+#pragma unroll
+    for (int k = 0; k < 16; k++) { lre[wbase + 16 * k] = v[rev16(k)].x; lim[wbase + 16 * k] = v[rev16(k)].y; }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) { v[j].x = lre[t + 256 * j]; v[j].y = lim[t + 256 * j]; }
+  }
+  dft16<INV>(v);
+  apply_powers(v, wb);
+  __syncthreads();
+  {  // exchange 2: (n0, k0; k1) -> (k0, k1; n0), row pitch 257
+    const int wbase = (t >> 4) + kPitch * (t & 15);
+#pragma unroll
+    for (int k = 0; k < 16; k++) { lre[wbase + 16 * k] = v[rev16(k)].x; lim[wbase + 16 * k] = v[rev16(k)].y; }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) { v[j].x = lre[t + kPitch * j]; v[j].y = lim[t + kPitch * j]; }
+  }
+  dft16<INV>(v);
+}
+
+}  // namespace f64
+}  // namespace gacq

@@ -14,6 +14,7 @@
 // costs two empty kernels.  The arithmetic is engine 5's (gacq_verify.hip) with another FFT implementation; both are held to
 // the reference's goldens at 1e-10.
 #include "gacq_common.h"
+#include "gacq_fft64.h"
 
 #include <algorithm>
 #include <cmath>
@@ -151,6 +152,82 @@ __global__ __launch_bounds__(kTieThreads) void tie_recheck_kernel(TieLists tl, c
   }
 }
 
+// N = 4096 (GPS L1 C/A, Xona X1: the headline shape, where a step of 32768 searches has a handful of ambiguous pairs): the same row
+// on the LDS-resident complex128 transform of gacq_fft64.h -- ~10 us per row instead of ~100 us through the global-memory
+// Stockham passes above, so that the re-evaluation stays invisible next to the 5.6 ms search it follows.
+__global__ __launch_bounds__(256, 1) void tie_recheck4k_kernel(TieLists tl, const float2* __restrict__ x, size_t epoch_stride,
+                                                               const double2* __restrict__ C64, const int* __restrict__ items,
+                                                               const int* __restrict__ fset, const double* __restrict__ freq,
+                                                               const double2* __restrict__ tab64, const double2* __restrict__ WN, int n, int P,
+                                                               int D, int B) {
+  using namespace gacq::f64;
+  extern __shared__ __attribute__((aligned(16))) double lds64[];
+  __shared__ double s_peak[4], s_sum[4];
+  __shared__ int s_idx[4];
+  const unsigned count = min(tl.c->nrows, (unsigned)tl.cap);
+  const int t = threadIdx.x;
+  const double2 wa2 = WN[t], wb2 = WN[16 * (t & 15)];
+  const cd wa = {wa2.x, wa2.y}, wb = {wb2.x, wb2.y};
+  const double inv_n = 1.0 / (double)kN;
+  for (unsigned slot = blockIdx.x; slot < count; slot += gridDim.x) {
+    const TieRow row = tl.rows[slot];
+    if (row.ep < 0) continue;
+    const long e = row.ep / P;
+    const int p = row.ep - (int)e * P;
+    const double f = freq[(long)fset[p] * D + row.d];
+    const double2* cp = C64 + (long)items[p] * kN + t;
+    double q[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) q[k] = 0.0;
+    for (int b = 0; b < B; b++) {
+      const float2* src = x + e * epoch_stride + (size_t)b * n;
+      cd v[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const int i = t + 256 * j;
+        const float2 sv = src[i];
+        const double2 w = tab64[nco_index(f, i)];
+        v[j] = cd{(double)sv.x, (double)sv.y} * cd{w.x, w.y};
+      }
+      fft4096<false>(v, lds64, wa, wb, t);
+      cd y[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) { const double2 c = cp[256 * j]; y[j] = cd{c.x, c.y} * conj(v[rev16(j)]); }
+      __syncthreads();
+      fft4096<true>(y, lds64, wa, wb, t);
+#pragma unroll
+      for (int k = 0; k < 16; k++) { const cd r = y[rev16(k)]; q[k] += sqrt_pos(r.x * r.x + r.y * r.y) * inv_n; }
+      __syncthreads();
+    }
+    double peak = -1.0, sum = 0.0;
+    int idx = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      if (q[k] > peak) { peak = q[k]; idx = t + 256 * k; }
+      sum += q[k];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double op = __shfl_down(peak, off);
+      const int oi = __shfl_down(idx, off);
+      const double os = __shfl_down(sum, off);
+      if (op > peak || (op == peak && oi < idx)) { peak = op; idx = oi; }
+      sum += os;
+    }
+    if ((t & 63) == 0) { s_peak[t >> 6] = peak; s_idx[t >> 6] = idx; s_sum[t >> 6] = sum; }
+    __syncthreads();
+    if (t == 0) {
+      for (int w = 1; w < 4; w++) {
+        if (s_peak[w] > peak || (s_peak[w] == peak && s_idx[w] < idx)) { peak = s_peak[w]; idx = s_idx[w]; }
+        sum += s_sum[w];
+      }
+      TieRec r; r.peak = peak; r.sum = sum; r.idx = idx; r.pad = 0;
+      tl.recs[slot] = r;
+    }
+    __syncthreads();
+  }
+}
+
 // Strict-'>' scan of every ambiguous (epoch, item) over its re-evaluated rows, in Doppler order, running best starting at 0
 // (acquire-gps-l1.py:25,36-39).  Rows that were not re-evaluated lie more than eps below the fp32 winner and cannot win.  One
 // workgroup; resets the list counters for the next launch.  d_shift: Doppler index of the grid's first bin in the caller's
@@ -284,6 +361,15 @@ int tie_resolve(gacq_sig* sig, const TieLists& tl, const gacq_peak* guesses, con
     wt = ctx->tables.emplace(key, b).first;
   }
   const double2* WN = (const double2*)wt->second.p;
+  if (N == gacq::f64::kN) {
+    GACQ_HIP(ctx, hipFuncSetAttribute((const void*)tie_recheck4k_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, gacq::f64::kLdsBytes));
+    hipLaunchKernelGGL(tie_recheck4k_kernel, dim3(128), dim3(256), gacq::f64::kLdsBytes, ctx->stream, tl, d_x, nsamp, (const double2*)sig->spectra64,
+                       (const int*)ctx->items.p, (const int*)ctx->fset.p, (const double*)ctx->freq.p, tab64, WN, sig->desc.n, P, D, B);
+    GACQ_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(tie_resolve_kernel, dim3(1), dim3(256), 0, ctx->stream, tl, d_out, guesses, N, sig->desc.metric_mode);
+    GACQ_HIP(ctx, hipGetLastError());
+    return GACQ_OK;
+  }
   // workgroups in flight: enough to take a burst of rows side by side, bounded by 64 MiB of row scratch (40 bytes per point)
   const size_t row_bytes = (size_t)N * 40;
   const int G = (int)std::max<size_t>(4, std::min<size_t>(64, ((size_t)64 << 20) / row_bytes));

@@ -6,6 +6,7 @@
 // when an fp32 engine and the oracle disagree on a near-tied peak, engine 5 says which side the rounding fell on.  Slow by
 // design (twice the bytes, a quarter of the flops/s); selected only by gacq_set_engine(ctx, 5), never by auto.
 #include "gacq_common.h"
+#include "gacq_fft64.h"
 
 #include <cmath>
 
@@ -105,6 +106,101 @@ __global__ void best_doppler64_kernel(const RowRec64* __restrict__ rows, gacq_pe
   out[ep] = o;
 }
 
+// ---- N = 4096, one block, one carrier: the whole row in one workgroup, complex128 ---------------------------------------------------
+// The structure of lds_fused4k_kernel (gacq_ldsfft.hip) in the reference's arithmetic type: workgroup = (epoch, Doppler bin, chunk of
+// pch items); prologue: x window, table-NCO mix, forward transform, conjugate -- the spectrum stays in registers (the transform's
+// output convention is the inverse transform's input convention); then per item C_p * conj(X), inverse transform, |.| / N and the
+// (max, first argmax, sum) of the row.  Nothing but x, the complex128 code spectra (natural order: lane t reads C[t + 256 j], 16
+// bytes per lane, 1 KiB per wave and instruction) and one 24-byte record per row touches HBM; the rocFFT pipeline this replaces
+// moves 5 x 64 KB per row.  64 KB of LDS per workgroup (gacq_fft64.h) -> two workgroups per CU, <= 256 VGPRs.
+__global__ __launch_bounds__(kBlock, 2) void fused4k_c128_kernel(const float2* __restrict__ x, size_t epoch_stride, const double2* __restrict__ C,
+                                                                 const int* __restrict__ items, const double* __restrict__ freq,
+                                                                 const double2* __restrict__ tab, const double2* __restrict__ tw,
+                                                                 RowRec64* __restrict__ rows, int E, int P, int D, int pch, int nchunk) {
+  using namespace gacq::f64;
+  extern __shared__ __attribute__((aligned(16))) double lds64[];
+  __shared__ double s_peak[kBlock / 64], s_sum[kBlock / 64];
+  __shared__ int s_idx[kBlock / 64];
+  const int t = threadIdx.x;
+  // placement as in lds_fused4k_kernel: all workgroups of an epoch run on XCD e % 8 (the sample block is fetched into one L2)
+  const int xcd = blockIdx.x & 7;
+  const unsigned j8 = blockIdx.x >> 3;
+  const unsigned per_epoch = (unsigned)D * (unsigned)nchunk;
+  const unsigned e8 = (j8 / per_epoch) * 8 + xcd;
+  if (e8 >= (unsigned)E) return;
+  const long e = e8;
+  const int d = (int)((j8 % per_epoch) / (unsigned)nchunk);
+  const int p0 = (int)(j8 % (unsigned)nchunk) * pch;
+  const int p1 = min(P, p0 + pch);
+  const double2 wa2 = tw[t], wb2 = tw[16 * (t & 15)];
+  const cd wa = {wa2.x, wa2.y}, wb = {wb2.x, wb2.y};
+  cd xr[16];
+  {
+    const double f = freq[d];
+    const float2* src = x + e * epoch_stride;
+    cd v[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const int i = t + 256 * j;
+      const float2 sv = src[i];
+      const double2 w = tab[nco_index(f, i)];                     // gnsstools/nco.py:6-10
+      v[j] = cd{(double)sv.x, (double)sv.y} * cd{w.x, w.y};
+    }
+    fft4096<false>(v, lds64, wa, wb, t);
+#pragma unroll
+    for (int j = 0; j < 16; j++) xr[j] = conj(v[rev16(j)]);      // np.conj(fft.fft(b))  acquire-gps-l1.py:32
+    __syncthreads();
+  }
+  const double inv_n = 1.0 / (double)kN;
+  for (int p = p0; p < p1; p++) {
+    const double2* cp = C + (long)items[p] * kN + t;
+    cd v[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const double2 c = cp[256 * j]; v[j] = cd{c.x, c.y}; }
+#pragma unroll
+    for (int j = 0; j < 16; j++) v[j] = v[j] * xr[j];
+    fft4096<true>(v, lds64, wa, wb, t);
+    double peak = -1.0, sum = 0.0;
+    int idx = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {                                // lane t holds lags t + 256 k, ascending in k
+      const cd r = v[rev16(k)];
+      const double m = sqrt_pos(r.x * r.x + r.y * r.y) * inv_n;      // np.absolute(ifft(...)); 1/N is a power of two
+      if (m > peak) { peak = m; idx = t + 256 * k; }
+      sum += m;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double op = __shfl_down(peak, off);
+      const int oi = __shfl_down(idx, off);
+      const double os = __shfl_down(sum, off);
+      if (op > peak || (op == peak && oi < idx)) { peak = op; idx = oi; }
+      sum += os;
+    }
+    if ((t & 63) == 0) { s_peak[t >> 6] = peak; s_idx[t >> 6] = idx; s_sum[t >> 6] = sum; }
+    __syncthreads();      // also orders this item's exchange-2 reads before the next item's exchange-1 writes
+    if (t == 0) {
+      for (int w = 1; w < kBlock / 64; w++) {
+        if (s_peak[w] > peak || (s_peak[w] == peak && s_idx[w] < idx)) { peak = s_peak[w]; idx = s_idx[w]; }
+        sum += s_sum[w];
+      }
+      RowRec64 r;
+      r.peak = peak; r.sum = sum; r.idx = idx; r.pad = 0;
+      rows[(e * P + p) * (long)D + d] = r;
+    }
+    __syncthreads();      // the reduction scratch is rewritten by the next item
+  }
+}
+
+// W_4096^k in fp64 (sincospi on the exactly reduced argument, device-side)
+__global__ void twiddle4096_64_kernel(double2* __restrict__ w) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= 4096) return;
+  double s, c;
+  sincospi(-2.0 * (double)k / 4096.0, &s, &c);
+  w[k] = make_double2(c, s);
+}
+
 int nco_table64(gacq_ctx* ctx, const double2** out) {
   auto it = ctx->tables.find("nco64");
   if (it != ctx->tables.end()) { *out = (const double2*)it->second.p; return GACQ_OK; }
@@ -117,6 +213,20 @@ int nco_table64(gacq_ctx* ctx, const double2** out) {
   const int rc = table_cache(ctx, "nco64", h.data(), sizeof(double2) * kNcoTableSize, &p);
   *out = (const double2*)p;
   return rc;
+}
+
+int twiddle64_4096(gacq_ctx* ctx, const double2** out) {
+  auto it = ctx->tables.find("W64_4096");
+  if (it == ctx->tables.end()) {
+    DevBuf b;
+    GACQ_HIP(ctx, hipMalloc(&b.p, sizeof(double2) * 4096));
+    b.cap = sizeof(double2) * 4096;
+    hipLaunchKernelGGL(twiddle4096_64_kernel, dim3(16), dim3(256), 0, ctx->stream, (double2*)b.p);
+    GACQ_HIP(ctx, hipGetLastError());
+    it = ctx->tables.emplace("W64_4096", b).first;
+  }
+  *out = (const double2*)it->second.p;
+  return GACQ_OK;
 }
 
 }  // namespace
@@ -146,6 +256,31 @@ int verify_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, in
   if ((rc = verify_spectra(sig)) != GACQ_OK) return rc;
   const double2* tab;
   if ((rc = nco_table64(ctx, &tab)) != GACQ_OK) return rc;
+  if (N == 4096 && B == 1 && F == 1 && !d_qrow && ctx->opt[GACQ_OPT_FUSED_C128]) {
+    // one kernel per search instead of the five-stage pipeline: the row never leaves the workgroup
+    const double2* tw;
+    if ((rc = twiddle64_4096(ctx, &tw)) != GACQ_OK) return rc;
+    if ((rc = ensure(ctx, ctx->rows, sizeof(RowRec64) * (size_t)nepoch * P * D)) != GACQ_OK) return rc;
+    RowRec64* rows = (RowRec64*)ctx->rows.p;
+    // one forward transform per workgroup: amortised over up to 32 items while >= ~1024 workgroups remain (2 resident per CU)
+    int pch = 4;
+    while (pch < 32 && (long)nepoch * D * ((P + 2 * pch - 1) / (2 * pch)) >= 1024) pch *= 2;
+    pch = std::min(pch, P);
+    const int nchunk = (P + pch - 1) / pch;
+    const long e8 = (nepoch + 7) / 8;
+    GACQ_HIP(ctx, hipFuncSetAttribute((const void*)fused4k_c128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, gacq::f64::kLdsBytes));
+    stage_begin(ctx, 6);
+    hipLaunchKernelGGL(fused4k_c128_kernel, dim3((unsigned)(8 * e8 * D * nchunk)), dim3(kBlock), gacq::f64::kLdsBytes, st, d_x, nsamp,
+                       (const double2*)sig->spectra64, (const int*)ctx->items.p, (const double*)ctx->freq.p, tab, tw, rows, nepoch, P, D, pch, nchunk);
+    stage_end(ctx);
+    GACQ_HIP(ctx, hipGetLastError());
+    const long nep = (long)nepoch * P;
+    stage_begin(ctx, 5);
+    hipLaunchKernelGGL(best_doppler64_kernel, dim3((unsigned)((nep + 63) / 64)), dim3(64), 0, st, (const RowRec64*)rows, d_out, nep, D, N, sig->desc.metric_mode);
+    stage_end(ctx);
+    GACQ_HIP(ctx, hipGetLastError());
+    return GACQ_OK;
+  }
   const size_t x_epoch_bytes = sizeof(double2) * (size_t)F * D * B * N;
   const int Ec = (int)std::max<size_t>(1, std::min<size_t>((size_t)nepoch, ctx->ws_limit / std::max<size_t>(1, x_epoch_bytes)));
   if ((rc = ensure(ctx, ctx->X, x_epoch_bytes * Ec)) != GACQ_OK) return rc;

@@ -136,7 +136,9 @@ int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes);
                                 /*     (8e-6 ~ 6 x the worst fp32-vs-complex128 metric error observed); 1000000000 re-evaluates every row  */
 #define GACQ_OPT_TIE_CAP 15       /* [0 = auto: 64 + (epochs x items) / 16] rows one call can re-evaluate; pairs beyond it keep their fp32  */
                                 /*     answer and are counted in gacq_get_tie_stats()[2]                                                    */
-#define GACQ_NOPTS 16
+#define GACQ_OPT_FUSED_C128 16     /* [1] engine 5, N = 4096, B = 1, one carrier: the whole complex128 search row in one workgroup (one kernel     */
+                                /*     instead of the five-stage rocFFT double-precision pipeline); 0 = always the pipeline                  */
+#define GACQ_NOPTS 17
 int gacq_set_option(gacq_ctx* ctx, int option, long value);
 int gacq_get_option(gacq_ctx* ctx, int option, long* value);
 

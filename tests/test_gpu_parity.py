@@ -532,8 +532,13 @@ def test_bench_measures_hbm_traffic_live_with_pmc_child_runs():
         assert c["traffic_measured_in_this_run"] and c["traffic_measured_bytes_per_launch"] >= 0.9 * c["compulsory_hbm_bytes_per_launch"], c
     ref = j["reference_precision"]
     assert ref["dtype"] == "f64" and ref["value"] > 1e9 and ref["seconds_timed"] >= 1.0, ref
-    agree = ref["f32_vs_f64_on_the_same_64_epochs"]
-    assert agree["searches"] == 64 * 32 and agree["peak_location_mismatches"] == 0 and agree["max_rel_metric_error"] < 1e-5, agree
+    agree = ref["f32_vs_f64_on_the_same_1024_epochs"]
+    assert agree["searches"] == 1024 * 32 and agree["peak_location_mismatches"] == 0 and agree["max_rel_metric_error"] < 1e-5, agree
+    # round 4: the complex128 leg is one fused kernel per search with its own roofline entry, the fp32 engine timed in the same loop
+    rr = ref["roofline"]
+    assert rr["kernel"] == "fused4k_c128_kernel" and rr["peak"] == 78.6 and 0.05 < rr["frac"] < 1.0 and rr["avg_kernel_ms"] <= ref["ms_per_step"], rr
+    assert ref["value"] > 1.5e11 and ref["f32_same_loop"]["seconds_timed"] >= 1.0, ref
+    assert abs(ref["f32_over_f64"] - ref["f32_same_loop"]["value"] / ref["value"]) < 1e-9
 
 
 def test_bench_rank_slice_projection_mode():
@@ -1024,6 +1029,41 @@ def test_complex128_verification_engine_matches_reference_to_1e_10(engine, golde
     for g, w, item in zip(got, case["results"], case["items"]):
         assert float(g[2]) == w[2] and float(g[1]) == pytest.approx(w[1], rel=1e-12, abs=1e-9), (cid, item, g, w)
         assert float(g[0]) == pytest.approx(w[0], rel=1e-10), (cid, item, g, w)
+
+
+def test_fused_complex128_4096_kernel_equals_the_rocfft_double_pipeline(engine):
+    """Engine 5 for N = 4096, B = 1 is one kernel per search (fused4k_c128_kernel); option fused_c128 = 0 brings back the five-stage
+    rocFFT double-precision pipeline.  Same locations, metrics equal to 1e-12, for several item-chunk regimes (few epochs: small
+    chunks; many epochs: 32 items per workgroup) and on noise-only epochs; the stage timers prove which one ran."""
+    import torch
+    from gnss_dsp_tools_amd import acquire, signals, synth
+    sig = signals.get("gps-l1")
+    dop = acquire.doppler_grid([-5000.0, 5000.0, 250.0])
+    try:
+        engine.set_engine(5)
+        for E, items, sats in ((1, [7], None), (3, list(range(1, 33)), None), (40, [3, 3, 9, 31, 12], []), (96, list(range(1, 33)), [])):
+            xs = synth.make_epochs(sig, 1, 5150 + E, synth.default_sats(items) if sats is None else sats, E, nsamp=4096)
+            xd = torch.from_numpy(xs).cuda()
+            engine.set_option("fused_c128", 0)
+            want = engine.search_batch_dev(sig, xd, items, dop, 1)
+            torch.cuda.synchronize()
+            want = want.cpu().numpy().view(acquire.PEAK_DTYPE)
+            engine.set_option("fused_c128", 1)
+            engine.set_profiling(True)
+            engine.reset_stage_times()
+            got = engine.search_batch_dev(sig, xd, items, dop, 1)
+            torch.cuda.synchronize()
+            st = engine.stage_times()
+            engine.set_profiling(False)
+            assert st["lds_correlate"][1] == 1 and st["best_doppler"][1] == 1, st
+            got = got.cpu().numpy().view(acquire.PEAK_DTYPE)
+            np.testing.assert_array_equal(got["idx"], want["idx"])
+            np.testing.assert_array_equal(got["d_index"], want["d_index"])
+            np.testing.assert_allclose(got["metric"], want["metric"], rtol=1e-12)
+    finally:
+        engine.set_profiling(False)
+        engine.set_option("fused_c128", 1)
+        engine.set_engine(0)
 
 
 def test_fp32_engines_agree_with_the_complex128_engine_on_near_ties(engine):
