@@ -447,12 +447,31 @@ def main():
     ap.add_argument("--emulate-ranks", type=int, default=0, metavar="N",
                     help="PROJECTION, not a measurement: on this one GPU, time every rank's slice of an N-rank job (the Doppler slices "
                          "ShardedSearch would cut) one after the other and report the slowest slice, per-slice roofline and exchange bytes")
+    ap.add_argument("--dry-run-cpu", default="", metavar="FILE.py:FUNCTION",
+                    help="NOT A MEASUREMENT: run the N-rank launch path on CPU tensors over gloo with FUNCTION(name, x, items, dopplers, blocks) "
+                         "-> peaks as the per-rank compute (tests pass an oracle-backed stand-in); no GPU is touched")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)     # launched by torch.distributed.run
+    if args.dry_run_cpu:
+        import importlib.util
+        path, fname = args.dry_run_cpu.rsplit(":", 1)
+        spec = importlib.util.spec_from_file_location("gacq_dry_run_compute", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        if use_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        env = {"world": world, "rank": rank, "local_rank": local_rank, "use_dist": use_dist, "dev": torch.device("cpu")}
+        out = run_dry(args, env, getattr(mod, fname))
+        if rank == 0:
+            print(json.dumps(out))
+        if use_dist:
+            dist.destroy_process_group()
+        return
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -522,6 +541,117 @@ def build_jobs(cfg, E_total, dev):
     return jobs
 
 
+def make_run_steps(lanes, jobs):
+    """k independent steps, alternating between `lanes` = [(context factory, ShardedSearch)].  With N > 1 the all-gather of step i
+    runs under the local compute of step i+1 (asynchronous collective, merge deferred by one step)."""
+    def run_steps(k):
+        pend = [None] * len(lanes)
+        out = None
+        for i in range(k):
+            ctx, shl = lanes[i % len(lanes)]
+            with ctx():
+                nxt = shl.search_jobs_async(jobs)                             # next search queued before the previous merge:
+                if pend[i % len(lanes)] is not None:                          # its kernels cover the previous exchange
+                    out = pend[i % len(lanes)].wait()
+                pend[i % len(lanes)] = nxt
+        for (ctx, _), p in zip(lanes, pend):
+            if p is not None:
+                with ctx():
+                    out = p.wait()
+        return out
+    return run_steps
+
+
+def make_timed(run_steps, dev, use_dist):
+    """timed(k) -> (last merged result, seconds): exactly k steps bracketed by a device synchronise + barrier on both sides, MAX over
+    ranks (the contract the driver's scaling runs rely on)."""
+    def sync_dev():
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+
+    def timed(k):
+        sync_dev()
+        if use_dist:
+            dist.barrier()
+        t0 = time.perf_counter()
+        out = run_steps(k)
+        sync_dev()
+        if use_dist:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return out, dt
+    return timed
+
+
+def shard_census(sh, jobs, world, dev):
+    """One more step with the un-merged exchange buffer kept: every rank must hold `world` shards, and noise alone gives every
+    (epoch, item) of every shard a positive metric, so an all-positive shard is one that really arrived.  Returns (shards, merged)."""
+    pj = sh.search_jobs_async(jobs)
+    g = pj.shards()
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    assert g.shape[0] == world, ("exchange buffer has %d shards, world is %d" % (g.shape[0], world))
+    metrics = g.view(world, -1, 2)[:, :, 0]
+    assert bool((metrics > 0).all()), "a shard of the all-gather arrived empty"
+    return int(g.shape[0]), pj.wait()
+
+
+def run_dry(args, env, local_fn):
+    """--dry-run-cpu MODULE.py:FUNCTION -- NOT A MEASUREMENT.  The driver-style launch of `bench.py --gpus N` (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* from the environment, one process per rank) on CPU tensors over gloo, with the per-rank compute supplied by
+    the caller (tests/ pass an oracle-backed stand-in; the product engine needs a GPU and has no CPU fallback).  Exercises what the
+    8-GPU scaling run depends on before hardware ever sees it: the rank environment, Doppler slicing per rank (ShardedSearch), the
+    single all-gather with two steps in flight, the tie-exact merge, the shard census, the barrier-bracketed MAX-reduced timing and
+    the shape of the JSON line.  The workload is a miniature of the chosen BASELINE configuration (3 items, 8 Doppler bins)."""
+    world, rank, dev = env["world"], env["rank"], env["dev"]
+    from gnss_dsp_tools_amd import acquire, sharded, signals, synth
+    cfg = CONFIGS[args.config]
+    epochs = args.epochs or 1
+    E_total = epochs * world if args.scaling == "weak" else epochs
+    jobs = []
+    for name, items, ds, ms in cfg["jobs"]:
+        if isinstance(name, tuple):                                  # family jobs need the stacked device signal: first member only
+            name, items = name[0], items[0]
+        sig = signals.get(name)
+        B = min(2, ms[1] if isinstance(ms, tuple) else sig.blocks(ms))
+        items = list(items)[:3]
+        dop = acquire.doppler_grid(ds)[:8]
+        xs = synth.make_epochs(sig, B, synth.BASE_SEED + cfg["seed"], synth.default_sats(items), E_total, nsamp=sig.samples_needed(B))
+        jobs.append({"sig": sig, "name": sig.name, "family": None, "items": items, "P": len(items), "dop": dop, "dopplers": dop, "blocks": B, "B": B,
+                     "x": torch.from_numpy(xs), "label": sig.name})
+    cells_step = sum(E_total * j["P"] * len(j["dop"]) * j["sig"].nfft for j in jobs)
+    sh = sharded.ShardedSearch(local_fn=local_fn, always_gather=args.force_gather)
+    import contextlib
+    run_steps = make_run_steps([(contextlib.nullcontext, sh)], jobs)
+    timed = make_timed(run_steps, dev, env["use_dist"])
+    run_steps(args.warmup)
+    merged, dt = timed(args.steps)
+    shards_seen = 1
+    if not sh._solo():
+        shards_seen, merged = shard_census(sh, jobs, world, dev)
+    # every rank holds the same merged records; rank 0 checks them against a single-rank scan of the whole grid
+    ok = True
+    if rank == 0:
+        for job, m in zip(jobs, merged):
+            whole = local_fn(job["name"], job["x"], job["items"], job["dop"], job["B"])
+            ok = ok and bool((m.view(torch.int64) == whole.view(torch.int64)).all())
+    if rank != 0:
+        return None
+    return {"dry_run": True, "note": "NOT A MEASUREMENT: CPU tensors over gloo, per-rank compute supplied by the caller (" + args.dry_run_cpu + ")",
+            "metric": "acquisition cells/s (PRN x Doppler x code-phase), " + "+".join(j["label"] for j in jobs), "value": None, "unit": "cells/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64 (stand-in)", "data": "synthetic",
+            "config": {"workload": "miniature of BASELINE config %d (3 items, 8 Doppler bins, %d epoch(s)/step)" % (args.config, E_total),
+                       "baseline_config": args.config, "signals": [j["label"] for j in jobs], "epochs_per_step": E_total, "cells_per_step": cells_step,
+                       "doppler_bins_per_rank": [[sharded.doppler_bounds(len(j["dop"]), world)[r + 1] - sharded.doppler_bounds(len(j["dop"]), world)[r]
+                                                  for r in range(world)] for j in jobs],
+                       "shards_seen_by_every_rank": shards_seen, "merged_equals_single_rank_scan": ok}}
+
+
 def run(args, env):
     """One benchmark of one BASELINE configuration: returns the JSON line's dict (rank 0; other ranks return None)."""
     world, rank, local_rank, use_dist, dev = env["world"], env["rank"], env["local_rank"], env["use_dist"], env["dev"]
@@ -557,40 +687,8 @@ def run(args, env):
         with torch.cuda.stream(st):
             lanes.append((st, e2, sharded.ShardedSearch(engine=e2, always_gather=args.force_gather)))
 
-    def run_steps(k):
-        pend = [None] * len(lanes)
-        out = None
-        for i in range(k):
-            st, _, shl = lanes[i % len(lanes)]
-            with torch.cuda.stream(st):
-                nxt = shl.search_jobs_async(jobs)                             # next search queued before the previous merge:
-                if pend[i % len(lanes)] is not None:                          # its kernels cover the previous exchange
-                    out = pend[i % len(lanes)].wait()
-                pend[i % len(lanes)] = nxt
-        for (st, _, _), p in zip(lanes, pend):
-            if p is not None:
-                with torch.cuda.stream(st):
-                    out = p.wait()
-        return out
-
-    def sync_all():
-        torch.cuda.synchronize(dev)
-        if use_dist:
-            dist.barrier()
-
-    def timed(k):
-        sync_all()
-        t0 = time.perf_counter()
-        out = run_steps(k)
-        torch.cuda.synchronize(dev)
-        if use_dist:
-            dist.barrier()
-        dt = time.perf_counter() - t0
-        if use_dist:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return out, dt
+    run_steps = make_run_steps([((lambda st=st: torch.cuda.stream(st)), shl) for st, _, shl in lanes], jobs)
+    timed = make_timed(run_steps, dev, use_dist)
 
     # Clock ramp: after the idle seconds of start-up (signal build, H2D) the GPU needs tens of milliseconds of load before it
     # clocks up (tools/exp_cfg2.py timeline: 0.66 -> 0.45 -> 0.41 ms per step over the first ~100 steps after 0.5 s idle, flat
@@ -635,14 +733,7 @@ def run(args, env):
     #     every (epoch, item) of every shard a positive metric, so an all-positive shard is one that really arrived
     shards_seen = 1
     if exchanged:
-        pj = sh.search_jobs_async(jobs)
-        g = pj.shards()
-        torch.cuda.synchronize(dev)
-        assert g.shape[0] == world, ("exchange buffer has %d shards, world is %d" % (g.shape[0], world))
-        metrics = g.view(world, -1, 2)[:, :, 0]
-        assert bool((metrics > 0).all()), "a shard of the all-gather arrived empty"
-        shards_seen = int(g.shape[0])
-        merged = pj.wait()
+        shards_seen, merged = shard_census(sh, jobs, world, dev)
     # (b) the strong injected satellites sit at their delays in epoch 0 (padded searches see two code periods: n-d or 2n-d)
     if not args.no_self_check:
         for job, m in zip(jobs, merged):

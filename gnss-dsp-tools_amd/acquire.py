@@ -101,7 +101,8 @@ class AcqSignal:
 
 
 class Engine:
-    """One acquisition context bound to one GPU (one process per GPU)."""
+    """One acquisition context bound to one GPU (one process per GPU).  Like the gacq_ctx it wraps, an Engine is single-threaded:
+    the plan cache, the reusable result buffer and the library's workspaces are per context -- use one Engine per thread."""
 
     def __init__(self, device=0, engine=0, workspace_bytes=None):
         h = ctypes.c_void_p()
@@ -206,7 +207,7 @@ class Engine:
         """Map reference 'items' (PRNs, or GLONASS channels) to (AcqSignal, item indices, per-item bias).  The last plan is kept: a
         scan calls search_all with the same item list for every block of samples."""
         sig = _signals.get(name) if isinstance(name, str) else name
-        key = (sig.name, tuple(items))
+        key = (sig.name, id(sig), tuple(items))          # id: a caller-made descriptor may reuse the name of a built-in one
         if getattr(self, "_plan_key", None) == key:
             return self._plan_val
         val = self._plan_uncached(sig, items)
@@ -411,6 +412,20 @@ class Engine:
         out = torch.empty(n_out, dtype=torch.complex64, device=iq_int8.device)
         nat.check(nat.lib.gacq_frontend_dev(self._ctx, ctypes.c_void_p(iq_int8.data_ptr()), n_in, float(fs), float(coffset),
                                             taps.ctypes.data_as(nat.c_double_p), len(taps), sig.fs, n_out,
+                                            ctypes.c_void_p(out.data_ptr())), self._ctx)
+        return out
+
+    def mix_int8_dev(self, iq_int8, fs, coffset):
+        """nco.mix(x, -coffset/fs, 0) on the GPU (gacq_mix_int8_dev; gnsstools/nco.py:30-41): int8 I/Q (numpy [n, 2] / flat, or a torch
+        int8 CUDA tensor) -> torch complex64 CUDA tensor at the same rate, the input of the device-resident long-code search and
+        correlators (longcode.search_*, tracking.correlate_batch accept it as x)."""
+        import torch
+        if not torch.is_tensor(iq_int8):
+            iq_int8 = torch.from_numpy(np.array(iq_int8, dtype=np.int8, copy=True)).to("cuda:%d" % self.device)
+        iq_int8 = iq_int8.contiguous().view(-1)
+        n = iq_int8.numel() // 2
+        out = torch.empty(n, dtype=torch.complex64, device=iq_int8.device)
+        nat.check(nat.lib.gacq_mix_int8_dev(self._ctx, ctypes.c_void_p(iq_int8.data_ptr()), n, float(fs), float(coffset),
                                             ctypes.c_void_p(out.data_ptr())), self._ctx)
         return out
 

@@ -79,6 +79,7 @@ struct gacq_ctx {
   long opt[GACQ_NOPTS] = {1, 1, -1, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 1, 8000, 0, 1};   // gacq_set_option values (defaults documented in include/gacq.h)
   gacq::DevBuf pin_x, pin_peaks;       // pinned host staging for the host-buffer entry point (gacq_search)
   gacq::DevBuf bar_x;                  // fine-grained device memory the host writes directly through the PCIe BAR (small gacq_search inputs)
+  gacq::DevBuf bar_s;                  // the same for the correlator specs of gacq_correlate_batch_dev
   bool large_bar = false;              // hipDeviceProp_t.isLargeBar: device memory is host-addressable
   gacq::BatchRing* ring = nullptr;     // staging ring of gacq_search_batch / gacq_group_search_batch, created on first use
   bool profiling = false;
@@ -111,6 +112,9 @@ namespace gacq {
 int set_error(gacq_ctx* ctx, int code, const char* fmt, ...);
 void ring_destroy(gacq_ctx* ctx);
 int ensure(gacq_ctx* ctx, DevBuf& b, size_t bytes);
+// latency path: host write through the PCIe BAR into fine-grained device memory / completion by watching pinned result records
+bool bar_write(gacq_ctx* ctx, DevBuf& b, const void* src, size_t bytes);
+bool watch_records(const volatile unsigned long long* words, size_t count, size_t stride, size_t at, unsigned long long sentinel, int timeout_us);
 int ensure_pinned(gacq_ctx* ctx, DevBuf& b, size_t bytes);      // hipHostMalloc'd, device-accessible
 // W_N^k = exp(-2 pi i k / N) for k < count, fp64-evaluated and rounded once to fp32; cached per ctx under `key`
 int twiddle_cache(gacq_ctx* ctx, const std::string& key, int N, int count, const float2** out);
@@ -143,7 +147,7 @@ int lds_fused4k_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch,
 // the single-launch form pays for small batches only (every workgroup resident at once)
 bool lds_search1_supported(const gacq_ctx* ctx, int N, int B, int F, long units, int nitems);
 int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const int* d_items, const int* d_fset,
-                  int nepoch, int nitems, int F, int D, int B, int N, RowRec* rows, float tie_scale);
+                  int nepoch, int nitems, int F, int D, int B, int N, RowRec* rows, float tie_scale, float* q_out = nullptr);
 
 // test hook (gacq_debug_nco_indices): the forward kernel's own NCO index expression for one row, d_idx[N]; fused: the
 // one-kernel N = 16384 search

@@ -23,6 +23,21 @@
 using namespace gacq;
 
 namespace {
+// spin-wait hint and store fence of the host CPU (the BAR / watch path of gacq_search); portable no-ops elsewhere
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  asm volatile("yield" ::: "memory");
+#endif
+}
+inline void cpu_store_fence() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_sfence();
+#else
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+#endif
+}
 constexpr size_t kPinnedStageMax = 1u << 20;     // host inputs up to 1 MiB are staged through pinned memory
 constexpr size_t kBarWriteMax = 1u << 18;        // host inputs up to 256 KiB are written straight into device memory through the BAR
 thread_local std::string g_last_error;     // last error of calls made without a ctx, per calling thread
@@ -42,6 +57,61 @@ int set_error(gacq_ctx* ctx, int code, const char* fmt, ...) {
   g_last_error = buf;
   if (ctx) ctx->err = buf;
   return code;
+}
+
+// Latency-path upload: the host writes `bytes` straight into fine-grained device memory through the PCIe BAR (large-BAR devices; one
+// write-combined memcpy, ~1 us for 32 KB, no staging copy, no DMA engine) and fences, so that the launch doorbell that follows is
+// ordered behind the stores.  Returns false when the device (or this allocation) cannot be written that way -- the caller then
+// stages through pinned memory.  The caller guarantees that no kernel still reads the buffer (synchronous entry points).
+bool bar_write(gacq_ctx* ctx, DevBuf& b, const void* src, size_t bytes) {
+  if (!ctx->large_bar || bytes > kBarWriteMax || !ctx->opt[GACQ_OPT_BAR_UPLOAD]) return false;
+  if (bytes > b.cap) {
+    if (b.p) {
+      if (hipDeviceSynchronize() != hipSuccess || hipFree(b.p) != hipSuccess) { (void)hipGetLastError(); return false; }
+      b.p = nullptr;
+      b.cap = 0;
+    }
+    const size_t want = std::max<size_t>(bytes + bytes / 8, 65536);
+    if (hipExtMallocWithFlags(&b.p, want, hipDeviceMallocFinegrained) != hipSuccess) {
+      (void)hipGetLastError();
+      b.p = nullptr;
+      ctx->large_bar = false;            // fall back to the staged copy for good
+      return false;
+    }
+    b.cap = want;
+    // isLargeBar says device memory is host-addressable; that THIS allocation is mapped at the same address is checked once per
+    // allocation: the host writes a word through the BAR, the runtime copies it back from the device side
+    volatile unsigned long long* probe = (volatile unsigned long long*)b.p;
+    const unsigned long long token = 0x6761637170726f62ULL;
+    unsigned long long back = 0;
+    *probe = token;
+    cpu_store_fence();
+    if (!(hipMemcpy(&back, b.p, 8, hipMemcpyDeviceToHost) == hipSuccess && back == token)) {
+      (void)hipGetLastError();
+      (void)hipFree(b.p);
+      b.p = nullptr;
+      b.cap = 0;
+      ctx->large_bar = false;
+      return false;
+    }
+  }
+  std::memcpy(b.p, src, bytes);
+  cpu_store_fence();
+  return true;
+}
+
+// Completion by watching: the last kernel of a call writes `count` records of `stride` 8-byte words into device-visible pinned
+// memory whose word `at` the host pre-set to `sentinel`; true once no sentinel is left, false after `timeout_us` (the caller then
+// synchronises the stream, which is also where a faulted launch is reported).
+bool watch_records(const volatile unsigned long long* words, size_t count, size_t stride, size_t at, unsigned long long sentinel, int timeout_us) {
+  const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(timeout_us);
+  size_t first_pending = 0;
+  for (unsigned spin = 0;; spin++) {
+    while (first_pending < count && words[first_pending * stride + at] != sentinel) first_pending++;
+    if (first_pending == count) { std::atomic_thread_fence(std::memory_order_acquire); return true; }
+    cpu_relax();
+    if ((spin & 63) == 63 && std::chrono::steady_clock::now() > t_end) return false;
+  }
 }
 
 int ensure(gacq_ctx* ctx, DevBuf& b, size_t bytes) {
@@ -454,6 +524,7 @@ void gacq_destroy(gacq_ctx* ctx) {
   if (ctx->pin_x.p) (void)hipHostFree(ctx->pin_x.p);
   if (ctx->pin_peaks.p) (void)hipHostFree(ctx->pin_peaks.p);
   if (ctx->bar_x.p) (void)hipFree(ctx->bar_x.p);
+  if (ctx->bar_s.p) (void)hipFree(ctx->bar_s.p);
   for (auto& kv : ctx->tables) if (kv.second.p) (void)hipFree(kv.second.p);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -700,7 +771,7 @@ struct LdsPath {
 LdsPath lds_path(const gacq_ctx* ctx, int N, int nepoch, int P, int F, int D, int B, bool row_dump) {
   LdsPath p;
   p.use_lds = (ctx->engine == 2) || (ctx->engine == 0 && lds_supported(N) && !row_dump);
-  if (!p.use_lds || !lds_supported(N) || row_dump) return p;
+  if (!p.use_lds || !lds_supported(N) || row_dump) return p;      // a row dump (engine 2) goes through the two-kernel path
   p.fused16k = lds_fused_supported(ctx, N, P, F);
   p.search1 = !p.fused16k && lds_search1_supported(ctx, N, B, F, (long)nepoch * D, P);      // only with GACQ_OPT_TIE_SAFE off
   p.fused4k = p.search1 || (!p.fused16k && lds_fused4k_supported(ctx, N, B, F, (long)nepoch * D));
@@ -757,8 +828,8 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
 
   const LdsPath path = lds_path(ctx, N, nepoch, P, F, D, B, d_qrow != nullptr);
   const bool use_lds = path.use_lds;
-  if (ctx->engine == 2 && (!lds_supported(N) || d_qrow))
-    return set_error(ctx, GACQ_ERR_UNSUPPORTED, "engine 2 (LDS FFT) does not support N=%d%s", N, d_qrow ? " with row dump" : "");
+  if (ctx->engine == 2 && !lds_supported(N))
+    return set_error(ctx, GACQ_ERR_UNSUPPORTED, "engine 2 (LDS FFT) does not support N=%d", N);
   const int R = split_radix(N);
   const bool split_lds_ok = R != 0 && N / R == 4096;
   const bool use_split_lds = (ctx->engine == 4) || (ctx->engine == 0 && split_lds_ok);
@@ -820,7 +891,7 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
       stage_end(ctx);
       if (rc != GACQ_OK) return rc;
       stage_begin(ctx, 6);
-      rc = lds_correlate(ctx, X, sig->spectra_lds, (const int*)ctx->items.p, (const int*)ctx->fset.p, ne, P, F, D, B, N, rows, tscale);
+      rc = lds_correlate(ctx, X, sig->spectra_lds, (const int*)ctx->items.p, (const int*)ctx->fset.p, ne, P, F, D, B, N, rows, tscale, d_qrow);
       stage_end(ctx);
       if (rc != GACQ_OK) return rc;
     } else {
@@ -1124,22 +1195,10 @@ int gacq_search(gacq_sig* sig, const float* x_iq, size_t nsamp, const int* items
   if ((rc = ensure_pinned(ctx, ctx->pin_peaks, sizeof(gacq_peak) * nitems)) != GACQ_OK) return rc;
   const size_t xbytes = sizeof(float2) * need;
   const void* d_x = nullptr;
-  if (ctx->large_bar && xbytes <= kBarWriteMax && ctx->opt[GACQ_OPT_BAR_UPLOAD]) {
-    // Small inputs (a 1 ms GPS L1 block is 32 KB): the host writes them straight into fine-grained device memory through the PCIe
-    // BAR -- one write-combined memcpy (~1 us for 32 KB), no staging copy, no DMA engine (a 32 KB pinned H2D costs ~7 us of
-    // latency in front of the kernels).  The doorbell write of the kernel launch is ordered after these stores.  This call is
-    // synchronous, so the buffer is never rewritten while a kernel still reads it.
-    if (xbytes > ctx->bar_x.cap) {
-      if (ctx->bar_x.p) { GACQ_HIP(ctx, hipDeviceSynchronize()); GACQ_HIP(ctx, hipFree(ctx->bar_x.p)); ctx->bar_x.p = nullptr; ctx->bar_x.cap = 0; }
-      const size_t want = std::max<size_t>(xbytes + xbytes / 8, 65536);
-      if (hipExtMallocWithFlags(&ctx->bar_x.p, want, hipDeviceMallocFinegrained) == hipSuccess) ctx->bar_x.cap = want;
-      else { (void)hipGetLastError(); ctx->bar_x.p = nullptr; ctx->large_bar = false; }      // fall back to the staged copy for good
-    }
-    if (ctx->bar_x.p) {
-      std::memcpy(ctx->bar_x.p, x_iq, xbytes);
-      d_x = ctx->bar_x.p;
-    }
-  }
+  // Small inputs (a 1 ms GPS L1 block is 32 KB): written by the host straight into fine-grained device memory through the PCIe BAR
+  // (a 32 KB pinned H2D costs ~7 us of latency in front of the kernels).  This call is synchronous, so the buffer is never
+  // rewritten while a kernel still reads it.
+  if (bar_write(ctx, ctx->bar_x, x_iq, xbytes)) d_x = ctx->bar_x.p;
   if (!d_x) {
     // Staged path: small inputs go through a pinned staging buffer (one host memcpy, then a true async DMA); a pageable
     // hipMemcpyAsync stages internally and costs ~10 us more per call.  Large inputs are copied directly.
@@ -1174,7 +1233,7 @@ int gacq_search(gacq_sig* sig, const float* x_iq, size_t nsamp, const int* items
       // both 8-byte halves of a record through volatile reads (little endian: d_index is the upper half of the second word)
       while (first_pending < nitems && words[2 * first_pending] != kSentinelBits && (int)(words[2 * first_pending + 1] >> 32) != -2) first_pending++;
       if (first_pending == nitems) { complete = true; break; }
-      __builtin_ia32_pause();
+      cpu_relax();
       if ((spin & 63) == 63 && std::chrono::steady_clock::now() > t_end) break;
     }
     std::atomic_thread_fence(std::memory_order_acquire);
@@ -1236,7 +1295,9 @@ int gacq_debug_row(gacq_sig* sig, const float* x_iq, size_t nsamp, int item, dou
     return set_error(ctx, GACQ_ERR_HIP, "gacq_debug_row: H2D failed");
   }
   const int saved = ctx->engine;
-  ctx->engine = (saved == 3 || saved == 4 || saved == 5) ? saved : 1;      // row dump: rocFFT pipeline, split engines, fp64 pipeline
+  // row dump: the engine that was asked for -- rocFFT pipeline (also what auto means here), LDS kernels (two-kernel path), split
+  // engines, fp64 pipeline
+  ctx->engine = (saved >= 2 && saved <= 5) ? saved : 1;
   rc = launch_search(sig, (const float2*)ctx->xstage.p, need, 1, &item, 1, &doppler, 1, bias_hz != 0.0 ? &bias_hz : nullptr, blocks,
                      (gacq_peak*)ctx->out_peaks.p, d_q);
   ctx->engine = saved;

@@ -466,11 +466,12 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_permute_kernel(const float
 // into the wave's own region as soon as the cross-wave exchange of the current row has been read out, i.e. under the last
 // radix-16 pass and the magnitudes -- the register file (16 + 16 complex + 16 accumulators of 128 VGPRs) has no room for a
 // prefetch, the LDS is idle exactly then.  Blocks -> (unit, chunk): see lds_correlate().
+template <bool QDUMP>
 __global__ __launch_bounds__(kBigThreads) void lds16k_correlate_kernel(const float2* __restrict__ X, const float2* __restrict__ C,
                                                                         const int* __restrict__ items, const int* __restrict__ fset,
                                                                         const float2* __restrict__ twn, RowRec* __restrict__ rows,
                                                                         int E, int P, int F, int D, int B, int pch, int nchunk, int ugroup,
-                                                                        float tie_scale) {
+                                                                        float tie_scale, float* __restrict__ q_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v2* lds = reinterpret_cast<v2*>(smem);
   const int t = threadIdx.x;
@@ -538,6 +539,10 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_correlate_kernel(const flo
       GACQ_MARK16(6);
     }
     xrow = xnext_item;
+    if (QDUMP) {                                         // gacq_debug_row: the accumulated magnitude row itself (one row per launch)
+#pragma unroll
+      for (int k = 0; k < kR; k++) q_out[t + 1024 * k] = q[k];
+    }
     float sum_f = q[0];
 #pragma unroll
     for (int k = 1; k < kR; k++) sum_f += q[k];
@@ -752,11 +757,12 @@ __global__ __launch_bounds__(kBlock) void lds_permute_kernel(const float2* __res
 //   OPAQUE  recompute the twiddle powers w^1..w^15 per pass instead of letting the compiler hoist all
 //           2 x 15 of them out of the item loop (60 VGPRs that would cost two waves of occupancy)
 //   PRETW   keep all 2 x 15 twiddle powers in registers for the whole item loop (60 VGPRs, saves 56 ops per row)
-template <int MINW, bool B1, bool CACHEX, bool OPAQUE, bool PRETW = false>
+template <int MINW, bool B1, bool CACHEX, bool OPAQUE, bool PRETW = false, bool QDUMP = false>
 __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float2* __restrict__ X, const float2* __restrict__ C,
                                                                       const int* __restrict__ items, const int* __restrict__ fset,
                                                                       const float2* __restrict__ tw, RowRec* __restrict__ rows,
-                                                                      int E, int P, int F, int D, int B, int pch, int nchunk, float tie_scale) {
+                                                                      int E, int P, int F, int D, int B, int pch, int nchunk, float tie_scale,
+                                                                      float* __restrict__ q_out) {
   __shared__ v2 lds[kLdsElems];
   __shared__ float s_peak[kBlock / 64];
   __shared__ int s_idx[kBlock / 64];
@@ -849,6 +855,10 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float
           q[k] += __builtin_amdgcn_sqrtf(norm2(r)) * inv_n;
         }
       }
+    }
+    if (QDUMP) {                                         // gacq_debug_row: the accumulated magnitude row itself (one row per launch)
+#pragma unroll
+      for (int k = 0; k < kR; k++) q_out[t + 256 * k] = B1 ? q[k] * inv_n : q[k];
     }
     float sum_f = q[0];
 #pragma unroll
@@ -1218,7 +1228,8 @@ int lds_debug_nco(gacq_ctx* ctx, int N, int n, const double* d_freq, bool fused,
 }
 
 int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const int* d_items, const int* d_fset, int nepoch,
-                  int nitems, int F, int D, int B, int N, RowRec* rows, float tie_scale) {
+                  int nitems, int F, int D, int B, int N, RowRec* rows, float tie_scale, float* q_out) {
+  if (q_out && (nepoch != 1 || nitems != 1 || D != 1)) return set_error(ctx, GACQ_ERR_BAD_ARG, "LDS FFT engine: a row dump takes exactly one row");
   if (!lds_supported(N)) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "LDS FFT engine: N=%d not supported", N);
   if (N == kBig) {
     const float2* twn;
@@ -1238,9 +1249,10 @@ int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const i
     if (ctx->opt[GACQ_OPT_LDS_UGROUP] >= 1) ugroup = (int)ctx->opt[GACQ_OPT_LDS_UGROUP];
     const long units8 = (units + 7) / 8;                                 // units per XCD
     const long groups = (units8 + ugroup - 1) / ugroup;
-    GACQ_HIP(ctx, hipFuncSetAttribute((const void*)lds16k_correlate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes));
-    hipLaunchKernelGGL(lds16k_correlate_kernel, dim3((unsigned)(8 * groups * ugroup * nchunk)), dim3(kBigThreads), kBigLdsBytes, ctx->stream, X,
-                       spectra, d_items, d_fset, twn, rows, nepoch, nitems, F, D, B, pch, nchunk, ugroup, tie_scale);
+    auto kern16 = q_out ? lds16k_correlate_kernel<true> : lds16k_correlate_kernel<false>;
+    GACQ_HIP(ctx, hipFuncSetAttribute((const void*)kern16, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes));
+    hipLaunchKernelGGL(kern16, dim3((unsigned)(8 * groups * ugroup * nchunk)), dim3(kBigThreads), kBigLdsBytes, ctx->stream, X,
+                       spectra, d_items, d_fset, twn, rows, nepoch, nitems, F, D, B, pch, nchunk, ugroup, tie_scale, q_out);
     GACQ_HIP(ctx, hipGetLastError());
     return GACQ_OK;
   }
@@ -1259,9 +1271,10 @@ int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const i
   // hoisted> led the round-1 A/B of ten register/occupancy variants (profiles/r01_ab_variants_*.log, all within 5 %); the others
   // are gone from the build.
   const bool b1 = (B == 1) && (F == 1);
-  auto kern = b1 ? lds_correlate_kernel<2, true, true, false> : lds_correlate_kernel<2, false, false, false>;
+  auto kern = q_out ? (b1 ? lds_correlate_kernel<2, true, true, false, false, true> : lds_correlate_kernel<2, false, false, false, false, true>)
+                    : (b1 ? lds_correlate_kernel<2, true, true, false> : lds_correlate_kernel<2, false, false, false>);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, X, spectra, d_items, d_fset, tw, rows, nepoch,
-                     nitems, F, D, B, pch, nchunk, tie_scale);
+                     nitems, F, D, B, pch, nchunk, tie_scale, q_out);
   GACQ_HIP(ctx, hipGetLastError());
   return GACQ_OK;
 }

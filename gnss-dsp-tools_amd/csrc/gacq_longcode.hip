@@ -96,9 +96,12 @@ int device_chips(gacq_ctx* ctx, const char* code, int prn, const uint8_t** out, 
 
 // x: host complex64 after the caller's carrier-offset wipe-off (iq_int8 == nullptr), or the raw interleaved int8 I/Q of the
 // file, wiped off here on the device with the front-end's fixed-point NCO (nco.mix(x,-coffset/fs,0), acquire-gps-l2cl.py:72)
+// d_x: complex64 samples ALREADY on the device (the front-end's output, or gacq_mix_int8_dev's): nothing is uploaded but the K x blocks
+// start phases, and the reference's "one x kept in memory from acquisition into the long-code search" (acquire-gps-l2cl.py:60-76)
+// holds on the GPU as well.
 static int longcode_run(gacq_ctx* ctx, const float* x_iq, const int8_t* iq_int8, double coffset_hz, size_t nsamp, double fs, const char* code,
-                        int prn, double carrier_hz, const double* phase0, int K, int blocks, int n, double* q_out) {
-  if (!ctx || (!x_iq && !iq_int8) || !code || !phase0 || !q_out || K <= 0 || blocks < 0 || n <= 0 || !(fs > 0.0) || !std::isfinite(coffset_hz))
+                        int prn, double carrier_hz, const double* phase0, int K, int blocks, int n, double* q_out, const float2* d_x = nullptr) {
+  if (!ctx || (!x_iq && !iq_int8 && !d_x) || !code || !phase0 || !q_out || K <= 0 || blocks < 0 || n <= 0 || !(fs > 0.0) || !std::isfinite(coffset_hz))
     return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_longcode_search: bad argument");
   if (blocks == 0) { memset(q_out, 0, sizeof(double) * K); return GACQ_OK; }
   if (nsamp < (size_t)blocks * n)
@@ -117,13 +120,15 @@ static int longcode_run(gacq_ctx* ctx, const float* x_iq, const int8_t* iq_int8,
   const long total = (long)n * blocks;
   const int chunks = (n + kLcChunk - 1) / kLcChunk;
   const size_t npart = (size_t)K * blocks * chunks;
-  if ((rc = ensure(ctx, ctx->xstage, sizeof(float2) * (size_t)total)) != GACQ_OK) return rc;
+  if (!d_x && (rc = ensure(ctx, ctx->xstage, sizeof(float2) * (size_t)total)) != GACQ_OK) return rc;
   if ((rc = ensure(ctx, ctx->fe_a, sizeof(float2) * (size_t)total)) != GACQ_OK) return rc;
   if ((rc = ensure(ctx, ctx->partial, sizeof(double2) * npart + sizeof(double) * (size_t)K * (blocks + 1))) != GACQ_OK) return rc;
   double2* d_partial = (double2*)ctx->partial.p;
   double* d_phase = (double*)(d_partial + npart);
   double* d_q = d_phase + (size_t)K * blocks;
-  if (iq_int8) {
+  if (d_x) {
+    // device-resident input: nothing to stage
+  } else if (iq_int8) {
     // the int8 pairs are staged in the (not yet used) mixed-block buffer, wiped off into xstage as complex64
     GACQ_HIP(ctx, hipMemcpyAsync(ctx->fe_a.p, iq_int8, 2 * (size_t)total, hipMemcpyHostToDevice, st));
     if ((rc = frontend_mix(ctx, ctx->fe_a.p, total, fs, coffset_hz, (float2*)ctx->xstage.p)) != GACQ_OK) return rc;
@@ -132,7 +137,7 @@ static int longcode_run(gacq_ctx* ctx, const float* x_iq, const int8_t* iq_int8,
   }
   GACQ_HIP(ctx, hipMemcpyAsync(d_phase, phase0, sizeof(double) * (size_t)K * blocks, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(longcode_mix_kernel, dim3((unsigned)((total + kLcBlock - 1) / kLcBlock)), dim3(kLcBlock), 0, st,
-                     (const float2*)ctx->xstage.p, (float2*)ctx->fe_a.p, (long)n, blocks, f, (const float2*)ctx->tab.p);
+                     d_x ? d_x : (const float2*)ctx->xstage.p, (float2*)ctx->fe_a.p, (long)n, blocks, f, (const float2*)ctx->tab.p);
   GACQ_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(longcode_dot_kernel, dim3((unsigned)npart), dim3(kLcBlock), 0, st, (const float2*)ctx->fe_a.p, d_chips, L,
                      (const double*)d_phase, incr, (long)n, blocks, chunks, d_partial);
@@ -154,4 +159,17 @@ extern "C" int gacq_longcode_search_int8(gacq_ctx* ctx, const int8_t* iq_int8, s
                                          const char* code, int prn, double carrier_hz, const double* phase0, int K, int blocks, int n,
                                          double* q_out) {
   return longcode_run(ctx, nullptr, iq_int8, carrier_offset_hz, nsamp, fs, code, prn, carrier_hz, phase0, K, blocks, n, q_out);
+}
+
+extern "C" int gacq_longcode_search_dev(gacq_ctx* ctx, const void* d_x, size_t nsamp, double fs, const char* code, int prn, double carrier_hz,
+                                        const double* phase0, int K, int blocks, int n, double* q_out) {
+  if (!d_x) return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_longcode_search_dev: d_x is NULL");
+  return longcode_run(ctx, nullptr, nullptr, 0.0, nsamp, fs, code, prn, carrier_hz, phase0, K, blocks, n, q_out, (const float2*)d_x);
+}
+
+extern "C" int gacq_mix_int8_dev(gacq_ctx* ctx, const void* d_iq_int8, size_t nsamp, double fs, double carrier_offset_hz, void* d_out) {
+  if (!ctx || !d_iq_int8 || !d_out || nsamp == 0 || !(fs > 0.0) || !std::isfinite(carrier_offset_hz))
+    return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_mix_int8_dev: bad argument");
+  GACQ_DEVICE(ctx);
+  return frontend_mix(ctx, d_iq_int8, (long)nsamp, fs, carrier_offset_hz, (float2*)d_out);
 }

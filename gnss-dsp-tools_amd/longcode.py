@@ -26,6 +26,19 @@ def _run(engine, x, fs, code, prn, carrier_hz, phase0, blocks, n, coffset=None):
     K = phase0.shape[0]
     if blocks <= 0:
         return np.zeros(K)
+    if hasattr(x, "is_cuda") and x.is_cuda:
+        # complex64 samples already on the GPU (Engine.mix_int8_dev / frontend output): only the start phases travel
+        import torch
+        if not (x.dtype == torch.complex64 and x.dim() == 1 and x.is_contiguous()) or coffset is not None:
+            raise ValueError("device input must be a contiguous 1-D complex64 CUDA tensor, already wiped off (coffset=None)")
+        if x.numel() < blocks * n:
+            raise ValueError("operands could not be broadcast together: search needs %d samples, x has %d" % (blocks * n, x.numel()))
+        ph = np.ascontiguousarray(phase0, dtype=np.float64)
+        q = np.empty(K, dtype=np.float64)
+        nat.check(nat.lib.gacq_longcode_search_dev(eng._ctx, ctypes.c_void_p(x.data_ptr()), x.numel(), float(fs), code.encode(), int(prn),
+                                                   float(carrier_hz), ph.ctypes.data_as(nat.c_double_p), K, int(blocks), int(n),
+                                                   q.ctypes.data_as(nat.c_double_p)), eng._ctx)
+        return q
     x = np.asarray(x)
     if len(x) < blocks * n:
         raise ValueError("operands could not be broadcast together: search needs %d samples, x has %d" % (blocks * n, len(x)))

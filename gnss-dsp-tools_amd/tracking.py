@@ -16,11 +16,33 @@ KIND = {"gps.l1cd": 1, "beidou.b1cd": 1, "beidou.b1cp": 1,          # boc11[int(
         "gps.l2cm": 4, "gps.l2cl": 5}                                # RZ [1,0] / [0,1]          gps/l2cm.py:81-92, l2cl.py
 
 
+def _is_device_block(x):
+    """a 1-D contiguous complex64 torch tensor on the GPU (e.g. a slice of Engine.frontend_dev's output)"""
+    return hasattr(x, "is_cuda") and x.is_cuda
+
+
 def correlate_batch(code, x, prns, chips, frac, incr, engine=None):
-    """K correlators over the same block x: returns complex128[K].  prns/chips/frac/incr broadcast to a common length."""
+    """K correlators over the same block x: returns complex128[K].  prns/chips/frac/incr broadcast to a common length.
+    x: numpy complex block (staged with the specs in one copy), or a complex64 torch tensor ALREADY on the GPU -- the front-end's
+    output or the samples an acquisition just searched -- in which case only the K specs travel (gacq_correlate_batch_dev)."""
     eng = engine or acquire.default_engine()
     prns, chips, frac, incr = np.broadcast_arrays(np.atleast_1d(prns), np.atleast_1d(chips), np.atleast_1d(frac), np.atleast_1d(incr))
     K = len(prns)
+    if _is_device_block(x):
+        import ctypes
+        import torch
+        if not (x.dtype == torch.complex64 and x.dim() == 1 and x.is_contiguous()):
+            raise ValueError("device block must be a contiguous 1-D complex64 CUDA tensor")
+        p = np.ascontiguousarray(prns, dtype=np.int32)
+        c = np.ascontiguousarray(chips, dtype=np.float64)
+        f = np.ascontiguousarray(frac, dtype=np.float64)
+        r = np.ascontiguousarray(incr, dtype=np.float64)
+        out = np.empty(K, dtype=np.complex128)
+        nat.check(nat.lib.gacq_correlate_batch_dev(eng._ctx, ctypes.c_void_p(x.data_ptr()), x.numel(), code.encode(), KIND.get(code, 0),
+                                                   p.ctypes.data_as(nat.c_int_p), c.ctypes.data_as(nat.c_double_p),
+                                                   f.ctypes.data_as(nat.c_double_p), r.ctypes.data_as(nat.c_double_p), K,
+                                                   out.ctypes.data_as(nat.c_double_p)), eng._ctx)
+        return out
     xc = np.ascontiguousarray(x, dtype=np.complex64)
     p = np.ascontiguousarray(prns, dtype=np.int32)
     c = np.ascontiguousarray(chips, dtype=np.float64)

@@ -161,7 +161,12 @@ int gacq_signal_spectrum(gacq_sig* sig, int item, float* out_iq);
  *   item_bias_hz  NULL, or per-item carrier bias added to the Doppler before the NCO
  *                 (GLONASS FDMA: 562500*chan, acquire-glonass-l1.py:28)
  *   blocks    number of non-coherent blocks B (the per-signal ms->B rule stays in the caller)
- * Replaces acquire-gps-l1.py:25-40 for all items at once (and the mp.Pool.map at :105-108). */
+ * Replaces acquire-gps-l1.py:25-40 for all items at once (and the mp.Pool.map at :105-108).
+ * Completion: the call returns when all `nitems` results are in `out`.  For small inputs on large-BAR devices (options
+ * GACQ_OPT_BAR_UPLOAD / GACQ_OPT_WATCH_RESULTS, both on by default) it learns that by watching the pinned result records the last
+ * kernel writes (bounded: 200 us, then hipStreamSynchronize, which is also where a faulted launch is reported) and does NOT
+ * synchronise the ctx stream: trailing empty launches (the tie-safe re-evaluation kernels of a search without near-ties) may still
+ * be queued when it returns.  They touch library-owned memory only; any later call on the ctx is ordered behind them. */
 int gacq_search(gacq_sig* sig, const float* x_iq, size_t nsamp, const int* items, int nitems,
                 const double* dopplers, int nd, const double* item_bias_hz, int blocks,
                 gacq_result* out);
@@ -267,6 +272,19 @@ int gacq_longcode_search_int8(gacq_ctx* ctx, const int8_t* iq_int8, size_t nsamp
  * ------------------------------------------------------------------------------------------- */
 int gacq_correlate_batch(gacq_ctx* ctx, const float* x_iq, size_t n, const char* code, int kind, const int* prns,
                          const double* chips, const double* frac, const double* incr, int K, double* out_iq);
+
+/* Device-resident forms of the two entry points above: d_x is complex64 ALREADY on the device (gacq_frontend_dev's or
+ * gacq_mix_int8_dev's output, or the very samples gacq_search_batch_dev just searched) -- the reference keeps one x in memory from
+ * acquisition into the long-code search (acquire-gps-l2cl.py:60-76) and into correlate() every millisecond
+ * (track-gps-l1.py:48-50).  Only the start phases / the K correlator specs travel to the device; results come back through pinned
+ * memory into q_out / out_iq.  Same kernels, byte-identical results. */
+int gacq_longcode_search_dev(gacq_ctx* ctx, const void* d_x, size_t nsamp, double fs, const char* code, int prn, double carrier_hz,
+                             const double* phase0, int K, int blocks, int n, double* q_out);
+int gacq_correlate_batch_dev(gacq_ctx* ctx, const void* d_x, size_t n, const char* code, int kind, const int* prns,
+                             const double* chips, const double* frac, const double* incr, int K, double* out_iq);
+/* nco.mix(x, -coffset/fs, 0) alone on the device (gnsstools/nco.py:30-41; acquire-gps-l2cl.py:72): d_iq_int8 interleaved signed 8-bit
+ * I/Q -> d_out complex64 [nsamp] at the same rate.  Asynchronous on the ctx stream. */
+int gacq_mix_int8_dev(gacq_ctx* ctx, const void* d_iq_int8, size_t nsamp, double fs, double carrier_offset_hz, void* d_out);
 
 /* Per-stage GPU time from HIP events recorded on the launch stream (profiling aid for bench.py).
  * Stages: 0 mix/forward, 1 forward FFT (rocFFT), 2 conj-multiply, 3 inverse FFT (rocFFT),

@@ -93,3 +93,32 @@ def test_gpu_int8_input_with_device_wipe_off_equals_host_wipe_off(engine):
     assert a[1] == b[1] and a[0] == pytest.approx(b[0], rel=1e-6)
     with pytest.raises(ValueError):
         longcode.search_l2cl(raw.astype(np.int16), item, dop, cp, ms, g["fs"], engine=engine, coffset=g["coffset"])
+
+
+@pytest.mark.gpu
+def test_gpu_device_resident_chain_equals_the_host_buffer_entry_points(engine):
+    """gacq_mix_int8_dev + gacq_longcode_search_dev: the file's int8 samples go to the GPU once, the carrier wipe-off and the long-code
+    search run on the resident block -- the reference keeps one x in memory from acquisition into the long-code search
+    (acquire-gps-l2cl.py:60-76).  Same kernels as gacq_longcode_search_int8 / gacq_longcode_search: the q vectors are byte-identical,
+    for L2CL (75 candidates) and the GLONASS P code (1000 candidates)."""
+    import torch
+    from gnss_dsp_tools_amd import longcode
+    g = json.load(open(os.path.join(GOLD, "cli_gps_l2cl.json")))
+    ms = int(g["argv"][1])
+    n = int(g["fs"] * 0.001 * (ms + 5))
+    raw = np.fromfile(os.path.join(GOLD, g["file"]), dtype=np.int8, count=2 * n).reshape(n, 2)
+    item, dop, cp = int(g["tail"][0]), float(g["tail"][1]), float(g["tail"][2])
+    x_dev = engine.mix_int8_dev(raw, g["fs"], g["coffset"])                      # one H2D, wipe-off on the device
+    assert x_dev.is_cuda and x_dev.dtype == torch.complex64 and x_dev.numel() == n
+    a = longcode.search_l2cl(raw, item, dop, cp, ms, g["fs"], engine=engine, coffset=g["coffset"])
+    b = longcode.search_l2cl(x_dev, item, dop, cp, ms, g["fs"], engine=engine)
+    assert a == b                                                                  # (metric, k): identical bits
+    # complex host input vs the same samples resident on the device, P code
+    case = [c for c in CASES if c["script"] == "glonass-l1-p"][0]
+    x = _iq(case)
+    want = longcode.search_glonass_p(x, case["item"], case["doppler"], case["code_phase"], case["ms"], case["fs"], band="l1", engine=engine)
+    got = longcode.search_glonass_p(torch.from_numpy(x).cuda(), case["item"], case["doppler"], case["code_phase"], case["ms"], case["fs"],
+                                    band="l1", engine=engine)
+    assert got == want and got[1] == case["k"]
+    with pytest.raises(ValueError):
+        longcode.search_l2cl(x_dev[:1000], item, dop, cp, ms, g["fs"], engine=engine)

@@ -53,3 +53,24 @@ def test_gpu_early_prompt_late_batch_equals_oracle(engine):
     y = (0.5 * c + 0.1 * rng.standard_normal(n)).astype(np.complex64)
     e, p, l = tracking.early_prompt_late("gps.ca", y, [9], [100.25], cf, 0.5, engine=engine)[0]
     assert abs(p) > 1.5 * abs(e) and abs(abs(e) - abs(l)) < 0.1 * abs(p)
+
+
+@pytest.mark.gpu
+def test_gpu_device_resident_correlators_equal_the_host_buffer_call(engine):
+    """gacq_correlate_batch_dev: the block is already on the GPU (the front-end's output / the samples an acquisition searched), only
+    the K correlator specs travel -- written through the PCIe BAR, results watched for in pinned memory.  Byte-identical to
+    gacq_correlate_batch for every subcarrier kind, for a 1 ms block (one launch) and a block long enough to need the second kernel,
+    repeated calls included (sentinel / buffer reuse)."""
+    import torch
+    from gnss_dsp_tools_amd import tracking
+    rng = np.random.default_rng(23)
+    for code, n, prns in (("gps.ca", 4092, [3, 17, 30, 5]), ("galileo.e1b", 8184, [11, 12]), ("gps.l1cp", 20000, [7]), ("gps.l2cm", 5000, [9, 2])):
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+        xd = torch.from_numpy(x).cuda()
+        code_p = rng.uniform(0.0, 1000.0, len(prns))
+        for rep in range(3):
+            want = tracking.early_prompt_late(code, x, prns, code_p, 0.25, 0.05 + 0.1 * rep, engine=engine)
+            got = tracking.early_prompt_late(code, xd, prns, code_p, 0.25, 0.05 + 0.1 * rep, engine=engine)
+            assert got.tobytes() == want.tobytes(), (code, rep)
+    with pytest.raises(ValueError):
+        tracking.correlate_batch("gps.ca", xd.to(torch.complex128), [1], 0.0, 0.0, 0.25, engine=engine)
