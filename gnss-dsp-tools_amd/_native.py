@@ -132,6 +132,7 @@ SYMBOLS = {
     "gacq_correlate_batch_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_int, c_int_p,
                                                 c_double_p, c_double_p, c_double_p, ctypes.c_int, c_double_p]),
     "gacq_mix_int8_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]),
+    "gacq_stream_probe": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, c_double_p]),
     "gacq_set_profiling": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "gacq_get_stage_time": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, ctypes.POINTER(ctypes.c_long)]),
     "gacq_reset_stage_times": (ctypes.c_int, [ctypes.c_void_p]),

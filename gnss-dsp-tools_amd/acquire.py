@@ -157,6 +157,12 @@ class Engine:
         nat.check(nat.lib.gacq_get_tie_stats(self._ctx, v), self._ctx)
         return {"ambiguous_pairs": v[0], "rows_reevaluated": v[1], "kept_fp32": v[2], "locations_changed": v[3]}
 
+    def stream_probe(self, kind, nbytes=2 << 30, reps=10):
+        """gacq_stream_probe: GB/s a tuned streaming kernel reaches on this device; kind "fill", "read" or "copy" (read + write bytes)."""
+        v = ctypes.c_double()
+        nat.check(nat.lib.gacq_stream_probe(self._ctx, {"fill": 0, "read": 1, "copy": 2}[kind], int(nbytes), int(reps), ctypes.byref(v)), self._ctx)
+        return v.value
+
     def set_profiling(self, on):
         nat.check(nat.lib.gacq_set_profiling(self._ctx, int(bool(on))), self._ctx)
 

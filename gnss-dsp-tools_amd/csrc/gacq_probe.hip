@@ -1,0 +1,92 @@
+// What this device's HBM delivers to tuned streaming kernels, measured where the benchmark runs: the yardstick the HBM-bound kernels
+// of the split engines are held against next to the 8 TB/s of the data sheet (bench.py: roofline.stream_ceiling).  Each lane keeps
+// eight independent 16-byte accesses in flight, non-temporal (read-once / write-once streams), one 32 KiB tile per workgroup and
+// iteration, eight workgroups per CU -- the shape MI355X_MICROARCH.md's 6.3 TB/s float4 copy was measured with; the round-3
+// microbenchmark (one 16-byte access per lane and iteration, tools/hbm_bandwidth.hip) stayed 25 % below it for the copy.
+#include "gacq_common.h"
+
+using namespace gacq;
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+constexpr int kU = 8;
+
+__global__ __launch_bounds__(256) void stream_fill_kernel(f4* __restrict__ p, size_t ntiles, float v) {
+  for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    f4* dst = p + tile * (256 * kU) + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < kU; u++) __builtin_nontemporal_store(f4{v, v, v, v}, dst + 256 * u);
+  }
+}
+
+__global__ __launch_bounds__(256) void stream_read_kernel(const f4* __restrict__ p, size_t ntiles, float* __restrict__ sink) {
+  f4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const f4* src = p + tile * (256 * kU) + threadIdx.x;
+    f4 v[kU];
+#pragma unroll
+    for (int u = 0; u < kU; u++) v[u] = __builtin_nontemporal_load(src + 256 * u);
+#pragma unroll
+    for (int u = 0; u < kU; u++) acc += v[u];
+  }
+  if (acc.x + acc.y + acc.z + acc.w == 1.2345f) *sink = acc.x;      // never true for the fill pattern: keeps the loads alive
+}
+
+__global__ __launch_bounds__(256) void stream_copy_kernel(const f4* __restrict__ a, f4* __restrict__ b, size_t ntiles) {
+  for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const f4* src = a + tile * (256 * kU) + threadIdx.x;
+    f4* dst = b + tile * (256 * kU) + threadIdx.x;
+    f4 v[kU];
+#pragma unroll
+    for (int u = 0; u < kU; u++) v[u] = __builtin_nontemporal_load(src + 256 * u);
+#pragma unroll
+    for (int u = 0; u < kU; u++) __builtin_nontemporal_store(v[u], dst + 256 * u);
+  }
+}
+
+}  // namespace
+
+extern "C" int gacq_stream_probe(gacq_ctx* ctx, int kind, size_t bytes, int reps, double* gbytes_per_s) {
+  if (!ctx || !gbytes_per_s || kind < 0 || kind > 2 || reps <= 0 || reps > 1000 || bytes < ((size_t)1 << 20) || bytes > ((size_t)16 << 30))
+    return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_stream_probe: kind 0..2, 1 MiB <= bytes <= 16 GiB, 1 <= reps <= 1000");
+  GACQ_DEVICE(ctx);
+  const size_t tile_bytes = (size_t)256 * kU * 16;
+  const size_t ntiles = bytes / tile_bytes;
+  void *a = nullptr, *b = nullptr;
+  float* sink = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = GACQ_OK;
+  auto cleanup = [&]() {
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (sink) (void)hipFree(sink);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+  };
+  if (hipMalloc(&a, ntiles * tile_bytes) != hipSuccess || (kind == 2 && hipMalloc(&b, ntiles * tile_bytes) != hipSuccess) ||
+      hipMalloc((void**)&sink, 4) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+    (void)hipGetLastError();
+    cleanup();
+    return set_error(ctx, GACQ_ERR_HIP, "gacq_stream_probe: allocation of %zu bytes failed", bytes);
+  }
+  hipDeviceProp_t prop;
+  const int cus = hipGetDeviceProperties(&prop, ctx->device) == hipSuccess ? prop.multiProcessorCount : 256;
+  const dim3 grid((unsigned)std::min<size_t>(ntiles, (size_t)cus * 8)), block(256);
+  hipStream_t st = ctx->stream;
+  auto launch = [&]() {
+    if (kind == 0) hipLaunchKernelGGL(stream_fill_kernel, grid, block, 0, st, (f4*)a, ntiles, 1.0f);
+    else if (kind == 1) hipLaunchKernelGGL(stream_read_kernel, grid, block, 0, st, (const f4*)a, ntiles, sink);
+    else hipLaunchKernelGGL(stream_copy_kernel, grid, block, 0, st, (const f4*)a, (f4*)b, ntiles);
+  };
+  hipLaunchKernelGGL(stream_fill_kernel, grid, block, 0, st, (f4*)a, ntiles, 1.0f);      // defined contents for the read / copy probes
+  for (int w = 0; w < 2; w++) launch();
+  if (hipEventRecord(e0, st) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "gacq_stream_probe: event record failed");
+  for (int r = 0; r < reps && rc == GACQ_OK; r++) launch();
+  float ms = 0.f;
+  if (rc == GACQ_OK && (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || hipGetLastError() != hipSuccess))
+    rc = set_error(ctx, GACQ_ERR_HIP, "gacq_stream_probe: timing failed");
+  if (rc == GACQ_OK) *gbytes_per_s = (kind == 2 ? 2.0 : 1.0) * (double)(ntiles * tile_bytes) * reps / ((double)ms * 1e-3) / 1e9;
+  cleanup();
+  return rc;
+}

@@ -295,6 +295,12 @@ int gacq_get_stage_time(gacq_ctx* ctx, int stage, double* total_ms, long* launch
 int gacq_reset_stage_times(gacq_ctx* ctx);
 const char* gacq_stage_name(int stage);
 
+/* What this device's HBM delivers to a tuned streaming kernel (eight 16-byte non-temporal accesses in flight per lane): kind 0 = fill
+ * (stores), 1 = read, 2 = copy (read + write bytes counted); `bytes` per launch, `reps` timed launches after two warm-up launches,
+ * HIP events on the ctx stream.  The yardstick bench.py holds the HBM-bound kernels against next to the 8 TB/s of the data sheet
+ * (roofline.stream_ceiling), measured in the run that reports it.  Synchronous; allocates and frees its own buffers. */
+int gacq_stream_probe(gacq_ctx* ctx, int kind, size_t bytes, int reps, double* gbytes_per_s);
+
 /* Full accumulated magnitude row q[0..N) for one (item, doppler) -- debugging / golden rows. */
 int gacq_debug_row(gacq_sig* sig, const float* x_iq, size_t nsamp, int item, double doppler,
                    double bias_hz, int blocks, float* q_out);
