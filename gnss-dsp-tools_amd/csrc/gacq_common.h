@@ -90,6 +90,10 @@ struct gacq_ctx {
   std::vector<double> up_freq;
   std::vector<int> up_fset, up_items, up_d0;
   std::vector<float> up_taps;
+  // correlator calls repeat their (code, PRN list) every millisecond: the device chip-table pointers of the last call are kept
+  std::string tr_code;
+  std::vector<int> tr_prns;
+  std::vector<const void*> tr_chips;
   // device-resident constant tables (twiddles, long-code chips), keyed by name; owned by the ctx, freed in gacq_destroy
   std::map<std::string, gacq::DevBuf> tables;
 };

@@ -24,20 +24,51 @@ __device__ __forceinline__ cd conj(cd a) { return {a.x, -a.y}; }
 __device__ __forceinline__ cd add_i(cd a, cd b) { return {a.x - b.y, a.y + b.x}; }       // a + i b
 __device__ __forceinline__ cd sub_i(cd a, cd b) { return {a.x + b.y, a.y - b.x}; }       // a - i b
 
-// sqrt(a) for a >= 0 from v_rsq_f64 and two Newton steps (Goldschmidt form): a dozen fp64 operations without the scaling branches of
-// the library routine; the result is within an ulp of the correctly rounded value, far below the 1e-10 the complex128 paths are held to
+// sqrt(a) for a >= 0 from v_rsq_f64 (relative error ~2^-23), one Goldschmidt step (-> ~2^-45) and one residual correction
+// (d = a - g^2, g += d h: the error squares once more): seven fp64 operations without the scaling branches of the library routine,
+// accurate to an ulp or two -- far below the 1e-10 the complex128 paths are held to
 __device__ __forceinline__ double sqrt_pos(double a) {
   const double y = __builtin_amdgcn_rsq(a);
   double g = a * y, h = 0.5 * y;
-  double r = __builtin_fma(-h, g, 0.5);
-  g = __builtin_fma(g, r, g);
-  h = __builtin_fma(h, r, h);
-  r = __builtin_fma(-h, g, 0.5);
+  const double r = __builtin_fma(-h, g, 0.5);
   g = __builtin_fma(g, r, g);
   h = __builtin_fma(h, r, h);
   const double d = __builtin_fma(-g, g, a);
   g = __builtin_fma(d, h, g);
   return a > 0.0 ? g : 0.0;
+}
+
+// Wave64 reductions of fp64 values on DPP (no LDS round trips, no divergent compare-and-swap chains): quad_perm xor-1, xor-2,
+// row_half_mirror, row_mirror leave every lane of a 16-lane row with the row's result; the four rows are combined through readlane.
+__device__ __forceinline__ double dpp_f64(double v, const int ctrl_sel) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+  switch (ctrl_sel) {
+    case 0: lo = __builtin_amdgcn_update_dpp(0u, lo, 0xB1, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0u, hi, 0xB1, 0xf, 0xf, false); break;    // quad_perm [1,0,3,2]
+    case 1: lo = __builtin_amdgcn_update_dpp(0u, lo, 0x4E, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0u, hi, 0x4E, 0xf, 0xf, false); break;    // quad_perm [2,3,0,1]
+    case 2: lo = __builtin_amdgcn_update_dpp(0u, lo, 0x141, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0u, hi, 0x141, 0xf, 0xf, false); break;  // row_half_mirror
+    default: lo = __builtin_amdgcn_update_dpp(0u, lo, 0x140, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0u, hi, 0x140, 0xf, 0xf, false); break; // row_mirror
+  }
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)b, lane), hi = __builtin_amdgcn_readlane((unsigned)(b >> 32), lane);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double wave_add_f64(double v) {      // wave-uniform result
+  v += dpp_f64(v, 0);
+  v += dpp_f64(v, 1);
+  v += dpp_f64(v, 2);
+  v += dpp_f64(v, 3);
+  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+__device__ __forceinline__ double wave_max_pos_f64(double v) {  // v >= 0: wave-uniform maximum
+  v = fmax(v, dpp_f64(v, 0));
+  v = fmax(v, dpp_f64(v, 1));
+  v = fmax(v, dpp_f64(v, 2));
+  v = fmax(v, dpp_f64(v, 3));
+  return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 
 __device__ __forceinline__ constexpr int rev16(int k) { return 4 * (k & 3) + (k >> 2); }
@@ -88,9 +119,21 @@ __device__ __forceinline__ void apply_powers(cd (&v)[16], cd w1) {
   v[rev16(13)] = v[rev16(13)] * w13; v[rev16(14)] = v[rev16(14)] * w14; v[rev16(15)] = v[rev16(15)] * w15;
 }
 
+// w^1 .. w^15 with the product tree of apply_powers (identical values)
+__device__ __forceinline__ void make_powers(cd (&pw)[15], cd w1) {
+  pw[0] = w1;
+  pw[1] = w1 * w1;         pw[2] = pw[1] * w1;      pw[3] = pw[1] * pw[1];
+  pw[4] = pw[3] * w1;      pw[5] = pw[2] * pw[2];   pw[6] = pw[3] * pw[2];   pw[7] = pw[3] * pw[3];
+  pw[8] = pw[7] * w1;      pw[9] = pw[4] * pw[4];   pw[10] = pw[7] * pw[2];  pw[11] = pw[5] * pw[5];
+  pw[12] = pw[7] * pw[4];  pw[13] = pw[6] * pw[6];  pw[14] = pw[7] * pw[6];
+}
+
 // In: v[j] = x[t + 256 j]; out: v[rev16(k2)] = X[t + 256 k2] (unnormalised for INV).  wa = W_4096^t, wb = W_256^(t & 15) (forward
 // values).  lds: kLdsBytes.  The caller puts a barrier between two transforms that use the same LDS buffer.
-template <bool INV> __device__ __forceinline__ void fft4096(cd (&v)[16], double* lds, cd wa, cd wb, int t) {
+// TAB2: the pass-2 powers (already conjugated for INV) come from an LDS table laid out [k - 1][lane class], tb2 already
+// offset by the lane's class t & 15 -- one 16-byte read per product instead of 14 complex products per row to rebuild them.
+template <bool INV, bool TAB2 = false>
+__device__ __forceinline__ void fft4096(cd (&v)[16], double* lds, cd wa, cd wb, int t, const cd* tb2 = nullptr) {
   double* lre = lds;
   double* lim = lds + kPlane;
   if (INV) { wa.y = -wa.y; wb.y = -wb.y; }
@@ -105,7 +148,12 @@ template <bool INV> __device__ __forceinline__ void fft4096(cd (&v)[16], double*
     for (int j = 0; j < 16; j++) { v[j].x = lre[t + 256 * j]; v[j].y = lim[t + 256 * j]; }
   }
   dft16<INV>(v);
-  apply_powers(v, wb);
+  if (TAB2) {
+#pragma unroll
+    for (int k = 1; k < 16; k++) v[rev16(k)] = v[rev16(k)] * tb2[16 * (k - 1)];
+  } else {
+    apply_powers(v, wb);
+  }
   __syncthreads();
   {  // exchange 2: (n0, k0; k1) -> (k0, k1; n0), row pitch 257
     const int wbase = (t >> 4) + kPitch * (t & 15);

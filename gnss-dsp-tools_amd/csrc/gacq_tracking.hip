@@ -12,6 +12,7 @@
 // boundary, i.e. with probability ~1e-8 per correlator call; tests/test_tracking.py holds the result to 1e-5 of the reference.
 #include "gacq_common.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -36,14 +37,19 @@ __global__ __launch_bounds__(kTrBlock) void correlate_partial_kernel(const float
   const CorrSpec sp = specs[blk / chunks];
   double ar = 0.0, ai = 0.0;
   const long i0 = (long)c * kTrChunk + threadIdx.x;
-#pragma unroll 4
+  const double inv_l = 1.0 / (double)L;
+  // fully unrolled: the 16 chip gathers and the 16 sample loads of a lane are independent, so one round trip covers them all (the call
+  // is latency-bound: 36 workgroups on an otherwise idle chip)
+#pragma unroll
   for (int j = 0; j < kTrPer; j++) {
     const long i = i0 + (long)j * kTrBlock;
     if (i < n) {
       const double di = (double)i;
       const double pos = sp.cp0 + __dmul_rn(sp.incr, di);
-      long idx = (long)floor(pos);
-      if (idx >= L) idx %= L;
+      // floor(pos) mod L without a 64-bit division: the quotient from an fp64 product can be off by one, fixed up by one compare each way
+      long idx = (long)floor(pos) - (long)floor(pos * inv_l) * L;
+      if (idx < 0) idx += L;
+      if (idx >= L) idx -= L;
       float w = sp.chips[idx] ? -1.f : 1.f;                          // 1.0 - 2.0*c[int(cp)]
       if (kind != 0) {
         const long b1 = (long)floor(sp.bp0 + __dmul_rn(2.0 * sp.incr, di)) & 1;        // int(bp), bp = (bp + 2 incr) % 2
@@ -98,19 +104,31 @@ static int correlate_run(gacq_ctx* ctx, const float* x_iq, const float2* d_xdev,
   if (len < 0) return set_error(ctx, GACQ_ERR_UNKNOWN_CODE, "gacq_correlate_batch: unknown code '%s'", code);
   const long L = len;
   std::vector<CorrSpec> specs(K);
-  for (int k = 0; k < K; k++) {
-    const std::string key = std::string("chips:") + code + ":" + std::to_string(prns[k]);
-    const void* dchips = nullptr;
-    auto it = ctx->tables.find(key);
-    if (it == ctx->tables.end()) {
-      std::vector<uint8_t> h(len);
-      const int rc = gacq_code_chips(code, prns[k], h.data(), len);
-      if (rc < 0) return set_error(ctx, rc, "gacq_correlate_batch: no PRN %d in '%s'", prns[k], code);
-      const int rc2 = table_cache(ctx, key, h.data(), (size_t)len, &dchips);
-      if (rc2 != GACQ_OK) return rc2;
-    } else {
-      dchips = it->second.p;
+  // chip tables: the (code, PRN list) of the previous call is kept with its device pointers -- a tracking loop repeats it every block
+  const bool same = ctx->tr_code == code && (int)ctx->tr_prns.size() == K && std::equal(prns, prns + K, ctx->tr_prns.begin());
+  if (!same) {
+    ctx->tr_code.clear();
+    ctx->tr_chips.assign(K, nullptr);
+    for (int k = 0; k < K; k++) {
+      const std::string key = std::string("chips:") + code + ":" + std::to_string(prns[k]);
+      const void* dchips = nullptr;
+      auto it = ctx->tables.find(key);
+      if (it == ctx->tables.end()) {
+        std::vector<uint8_t> h(len);
+        const int rc = gacq_code_chips(code, prns[k], h.data(), len);
+        if (rc < 0) return set_error(ctx, rc, "gacq_correlate_batch: no PRN %d in '%s'", prns[k], code);
+        const int rc2 = table_cache(ctx, key, h.data(), (size_t)len, &dchips);
+        if (rc2 != GACQ_OK) return rc2;
+      } else {
+        dchips = it->second.p;
+      }
+      ctx->tr_chips[k] = dchips;
     }
+    ctx->tr_prns.assign(prns, prns + K);
+    ctx->tr_code = code;
+  }
+  for (int k = 0; k < K; k++) {
+    const void* dchips = ctx->tr_chips[k];
     const double s = chips[k] + frac[k];
     specs[k].chips = (const uint8_t*)dchips;
     specs[k].cp0 = pymod(s, (double)L);            // cp  = (chips+frac) % code_length

@@ -134,6 +134,15 @@ __global__ __launch_bounds__(kBlock, 2) void fused4k_c128_kernel(const float2* _
   const int p1 = min(P, p0 + pch);
   const double2 wa2 = tw[t], wb2 = tw[16 * (t & 15)];
   const cd wa = {wa2.x, wa2.y}, wb = {wb2.x, wb2.y};
+  // pass-2 twiddle powers of the inverse transform, conj(W_256^c)^k for the 16 lane classes c = t & 15: built once per workgroup,
+  // read back from a 3.8 KB LDS table in the item loop (the trick of lds_fused4k_kernel<.., PREA>)
+  __shared__ cd s_tw2[15 * 16];
+  if (t < 16) {
+    cd pw[15];
+    make_powers(pw, conj(wb));                            // lanes 0..15: wb = W_256^t
+#pragma unroll
+    for (int k = 0; k < 15; k++) s_tw2[16 * k + t] = pw[k];
+  }
   cd xr[16];
   {
     const double f = freq[d];
@@ -159,24 +168,25 @@ __global__ __launch_bounds__(kBlock, 2) void fused4k_c128_kernel(const float2* _
     for (int j = 0; j < 16; j++) { const double2 c = cp[256 * j]; v[j] = cd{c.x, c.y}; }
 #pragma unroll
     for (int j = 0; j < 16; j++) v[j] = v[j] * xr[j];
-    fft4096<true>(v, lds64, wa, wb, t);
-    double peak = -1.0, sum = 0.0;
-    int idx = 0;
+    fft4096<true, true>(v, lds64, wa, wb, t, s_tw2 + (t & 15));
+    // (max, first argmax, sum) of the wave's 1024 magnitudes: maximum first (per lane, then over the wave on DPP), location second
+    // (one compare per register against the wave-uniform maximum, lane masks folded on the scalar unit) -- wave_first_max's scheme
+    double m[16], sum = 0.0, lmax = 0.0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {                                // lane t holds lags t + 256 k, ascending in k
       const cd r = v[rev16(k)];
-      const double m = sqrt_pos(r.x * r.x + r.y * r.y) * inv_n;      // np.absolute(ifft(...)); 1/N is a power of two
-      if (m > peak) { peak = m; idx = t + 256 * k; }
-      sum += m;
+      m[k] = sqrt_pos(r.x * r.x + r.y * r.y) * inv_n;             // np.absolute(ifft(...)); 1/N is a power of two
+      sum += m[k];
+      lmax = fmax(lmax, m[k]);
     }
+    double peak = wave_max_pos_f64(lmax);
+    int idx = 0x7fffffff;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const double op = __shfl_down(peak, off);
-      const int oi = __shfl_down(idx, off);
-      const double os = __shfl_down(sum, off);
-      if (op > peak || (op == peak && oi < idx)) { peak = op; idx = oi; }
-      sum += os;
+    for (int k = 15; k >= 0; k--) {                               // descending: the last assignment is the smallest k
+      const unsigned long long mk = __builtin_amdgcn_ballot_w64(m[k] == peak);
+      if (mk) idx = 256 * k + (t & ~63) + (int)__builtin_ctzll(mk);
     }
+    sum = wave_add_f64(sum);
     if ((t & 63) == 0) { s_peak[t >> 6] = peak; s_idx[t >> 6] = idx; s_sum[t >> 6] = sum; }
     __syncthreads();      // also orders this item's exchange-2 reads before the next item's exchange-1 writes
     if (t == 0) {

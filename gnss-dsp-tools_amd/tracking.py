@@ -70,3 +70,39 @@ def early_prompt_late(code, x, prns, code_p, cf, spacing, engine=None):
     off = np.array([-spacing, 0.0, spacing])
     out = correlate_batch(code, x, np.repeat(prns, 3), 0.0, (code_p[:, None] + off[None, :]).ravel(), np.repeat(cf, 3), engine)
     return out.reshape(len(prns), 3)
+
+
+class EplPlan:
+    """Early/prompt/late of a fixed satellite set, called once per block by a tracking loop (track-gps-l1.py:48-50): the PRN list, the
+    tap spacing and every array the C call needs are laid out once, a call only writes the 3 K start phases and rates in place and
+    hands the block over -- numpy's per-call broadcasting / repeating / pointer conversions cost as much as the GPU work itself on a
+    resident 1 ms block (tools/exp_epl_latency.py).  x: a complex64 torch CUDA tensor (resident block) or a numpy block."""
+
+    def __init__(self, code, prns, spacing, engine=None):
+        import ctypes
+        self.eng = engine or acquire.default_engine()
+        self.code = code.encode()
+        self.kind = KIND.get(code, 0)
+        self.n = len(prns)
+        self._off = np.array([-spacing, 0.0, spacing])
+        self._prn = np.ascontiguousarray(np.repeat(np.asarray(prns, dtype=np.int32), 3))
+        self._chips = np.zeros(3 * self.n)
+        self._frac = np.empty((self.n, 3))
+        self._incr = np.empty((self.n, 3))
+        self._out = np.empty((self.n, 3), dtype=np.complex128)
+        self._args = (self._prn.ctypes.data_as(nat.c_int_p), self._chips.ctypes.data_as(nat.c_double_p), self._frac.ctypes.data_as(nat.c_double_p),
+                      self._incr.ctypes.data_as(nat.c_double_p), 3 * self.n, self._out.ctypes.data_as(nat.c_double_p))
+        self._void = ctypes.c_void_p
+
+    def __call__(self, x, code_p, cf):
+        """complex128 [len(prns), 3] (a view of the plan's own result buffer: copy it to keep it across calls)."""
+        np.add(np.asarray(code_p, dtype=np.float64).reshape(-1, 1), self._off, out=self._frac)
+        self._incr[:] = np.asarray(cf, dtype=np.float64).reshape(-1, 1)
+        if _is_device_block(x):
+            rc = nat.lib.gacq_correlate_batch_dev(self.eng._ctx, self._void(x.data_ptr()), x.numel(), self.code, self.kind, *self._args)
+        else:
+            xc = np.ascontiguousarray(x, dtype=np.complex64)
+            rc = nat.lib.gacq_correlate_batch(self.eng._ctx, xc.ctypes.data_as(nat.c_float_p), len(xc), self.code, self.kind, *self._args)
+        if rc < 0:
+            nat.check(rc, self.eng._ctx)
+        return self._out

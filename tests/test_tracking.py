@@ -72,5 +72,8 @@ def test_gpu_device_resident_correlators_equal_the_host_buffer_call(engine):
             want = tracking.early_prompt_late(code, x, prns, code_p, 0.25, 0.05 + 0.1 * rep, engine=engine)
             got = tracking.early_prompt_late(code, xd, prns, code_p, 0.25, 0.05 + 0.1 * rep, engine=engine)
             assert got.tobytes() == want.tobytes(), (code, rep)
+        # the per-block plan of a tracking loop (arrays laid out once, phases written in place): same bits again
+        plan = tracking.EplPlan(code, prns, 0.25, engine=engine)
+        assert plan(xd, code_p, 0.25).tobytes() == want.tobytes() and plan(x, code_p, np.full(len(prns), 0.25)).tobytes() == want.tobytes()
     with pytest.raises(ValueError):
         tracking.correlate_batch("gps.ca", xd.to(torch.complex128), [1], 0.0, 0.0, 0.25, engine=engine)
