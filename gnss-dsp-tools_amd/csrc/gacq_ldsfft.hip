@@ -461,11 +461,17 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_permute_kernel(const float
   }
 }
 
-// correlate: workgroup = (epoch, Doppler bin, chunk of items); per item: sum_b |IFFT(C_p * X_b)|/N -> (max, argmax, sum).
-// The item's code spectrum stays in registers for all B blocks; the forward spectrum of the NEXT row is fetched by LDS-DMA
-// into the wave's own region as soon as the cross-wave exchange of the current row has been read out, i.e. under the last
-// radix-16 pass and the magnitudes -- the register file (16 + 16 complex + 16 accumulators of 128 VGPRs) has no room for a
-// prefetch, the LDS is idle exactly then.  Blocks -> (unit, chunk): see lds_correlate().
+// correlate: workgroup = (chunk of items, group of `ugroup` (epoch, Doppler) units of one XCD); per (item, unit):
+// sum_b |IFFT(C_p * X_b)|/N -> (max, argmax, sum).
+// Item-major since round 4: the item's code spectrum is loaded ONCE and stays in registers for every unit of the group and all B
+// blocks of each, so a spectrum row crosses into the CU once per (item, group) instead of once per (item, unit) -- B1I (63 spectra =
+// 8 MB against 4 MB of L2 per XCD, 200 units) fetched 1.6 GB of code spectra per launch in the unit-major order of round 3, 7.7 x the
+// kernel's compulsory bytes.  The workgroups resident on an XCD (consecutive in launch order: same group, different items) walk the
+// group's units side by side, so the forward spectrum of the (unit, block) they are all working on is fetched from HBM once and
+// served from that XCD's L2 to the rest.
+// The forward spectrum of the NEXT row is fetched by LDS-DMA into the wave's own region as soon as the cross-wave exchange of the
+// current row has been read out, i.e. under the last radix-16 pass and the magnitudes -- the register file (16 + 16 complex + 16
+// accumulators of 128 VGPRs) has no room for a prefetch, the LDS is idle exactly then.  Blocks -> (group, chunk): see lds_correlate().
 template <bool QDUMP>
 __global__ __launch_bounds__(kBigThreads) void lds16k_correlate_kernel(const float2* __restrict__ X, const float2* __restrict__ C,
                                                                         const int* __restrict__ items, const int* __restrict__ fset,
@@ -475,82 +481,87 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_correlate_kernel(const flo
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v2* lds = reinterpret_cast<v2*>(smem);
   const int t = threadIdx.x;
-  // placement: workgroup b runs on XCD b % 8.  Within an XCD consecutive workgroups walk ugroup units side by side
-  // (chunk-major, unit-minor), so that the workgroups resident on the XCD's 32 CUs share ugroup forward-spectrum sets
-  // (B x 128 KB each) and read the same code spectra at about the same time.
+  // placement: workgroup b runs on XCD b % 8; XCD x owns the units u = x (mod 8), in groups of `ugroup` consecutive owned units
   const int xcd = blockIdx.x & 7;
   const unsigned j = blockIdx.x >> 3;
-  const unsigned per_group = (unsigned)(nchunk * ugroup);
-  const unsigned ug = j / per_group, within = j % per_group;
-  const unsigned u = (ug * (unsigned)ugroup + within % (unsigned)ugroup) * 8 + xcd;
-  if (u >= (unsigned)E * (unsigned)D) return;
-  const long e = u / (unsigned)D;
-  const int d = (int)(u % (unsigned)D);
-  const int p0 = (int)(within / (unsigned)ugroup) * pch;
+  const unsigned grp = j / (unsigned)nchunk;
+  const int p0 = (int)(j % (unsigned)nchunk) * pch;
   const int p1 = min(P, p0 + pch);
+  const unsigned U = (unsigned)E * (unsigned)D;
+  const unsigned u0 = grp * (unsigned)ugroup * 8u + (unsigned)xcd;           // first unit of the group; the i-th is u0 + 8 i
+  if (u0 >= U) return;
+  const int nu = (int)min((unsigned)ugroup, (U - u0 + 7u) / 8u);
   v2* reg = lds + (t >> 6) * kRegion;
   const Tw16k tw = tw16k_load(twn, true);
   const unsigned lane_off = (unsigned)t * 16u;
   const float inv_n = 1.0f / (float)kBig;
-  // Every second unit an XCD works on walks its items backwards: a unit touches all P code spectra (B1I: 8 MB against 4 MB of L2), so
-  // the rows the next unit can still find in L2 are the ones touched LAST -- its workgroups start with those.
-  const bool backwards = (ug & 1) != 0;
-  const int pstep = backwards ? -1 : 1, pfirst = backwards ? p1 - 1 : p0;
-  const float2* xrow = X + (((e * F + fset[pfirst]) * D + d) * (long)B) * kBig;
+  // first forward-spectrum row of (item p, i-th unit of the group)
+  auto unit_row = [&](int p, int i) -> const float2* {
+    const unsigned u = u0 + 8u * (unsigned)i;
+    const long e = u / (unsigned)D;
+    const int d = (int)(u % (unsigned)D);
+    return X + (((e * F + fset[p]) * D + d) * (long)B) * kBig;
+  };
+  const float2* xrow = unit_row(p0, 0);
   dma_row(xrow, reg);
 #ifdef GACQ_PHASE_TIMING16
   unsigned long long acc16_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long mark16_ = __builtin_readcyclecounter();
 #endif
-  for (int ip = 0; ip < p1 - p0; ip++) {
-    const int p = pfirst + pstep * ip;
+  for (int p = p0; p < p1; p++) {
     const __amdgpu_buffer_rsrc_t cres = big_rsrc(C + (long)items[p] * kBig);
     v2 c[kR];
 #pragma unroll
     for (int jp = 0; jp < kR / 2; jp++) ld_pair_big(cres, lane_off, jp, c[2 * jp], c[2 * jp + 1]);
-    const float2* xnext_item = (ip + 1 < p1 - p0) ? X + (((e * F + fset[p + pstep]) * D + d) * (long)B) * kBig : nullptr;
-    float q[kR];
+    for (int i = 0; i < nu; i++) {
+      const unsigned u = u0 + 8u * (unsigned)i;
+      const long e = u / (unsigned)D;
+      const int d = (int)(u % (unsigned)D);
+      // the row after this unit's last block: the next unit of the group, else the next item's first unit, else nothing
+      const float2* xnext_unit = (i + 1 < nu) ? unit_row(p, i + 1) : ((p + 1 < p1) ? unit_row(p + 1, 0) : nullptr);
+      float q[kR];
 #pragma unroll
-    for (int k = 0; k < kR; k++) q[k] = 0.f;
-    for (int b = 0; b < B; b++) {
-      v2 v[kR];
-      GACQ_MARK16(0);                                    // previous row's tail (reduction, code-spectrum loads)
-      dma_wait_read(v, reg);
+      for (int k = 0; k < kR; k++) q[k] = 0.f;
+      for (int b = 0; b < B; b++) {
+        v2 v[kR];
+        GACQ_MARK16(0);                                    // previous row's tail (reduction, code-spectrum loads)
+        dma_wait_read(v, reg);
 #pragma unroll
-      for (int jj = 0; jj < kR; jj++) v[jj] = cmul(c[jj], v[jj]);
-      GACQ_MARK16(1);
-      ifft16k_private(v, reg, tw);
-      GACQ_MARK16(2);
-      lds_barrier();
-      GACQ_MARK16(3);
-      ifft16k_gather(v, lds);
-      lds_barrier();                                     // every wave has read this region: it may be overwritten
-      GACQ_SETPRIO(GACQ_P1);
-      GACQ_MARK16(4);
-      const float2* nx = (b + 1 < B) ? xrow + (long)(b + 1) * kBig : xnext_item;
-      if (nx) dma_row(nx, reg);
-      GACQ_MARK16(5);
-      ifft16k_final(v, tw);
+        for (int jj = 0; jj < kR; jj++) v[jj] = cmul(c[jj], v[jj]);
+        GACQ_MARK16(1);
+        ifft16k_private(v, reg, tw);
+        GACQ_MARK16(2);
+        lds_barrier();
+        GACQ_MARK16(3);
+        ifft16k_gather(v, lds);
+        lds_barrier();                                     // every wave has read this region: it may be overwritten
+        GACQ_SETPRIO(GACQ_P1);
+        GACQ_MARK16(4);
+        const float2* nx = (b + 1 < B) ? xrow + (long)(b + 1) * kBig : xnext_unit;
+        if (nx) dma_row(nx, reg);
+        GACQ_MARK16(5);
+        ifft16k_final(v, tw);
 #pragma unroll
-      for (int k = 0; k < kR; k++) {
-        const v2 r = v[rev16(k)];
-        q[k] += __builtin_amdgcn_sqrtf(norm2(r)) * inv_n;
+        for (int k = 0; k < kR; k++) {
+          const v2 r = v[rev16(k)];
+          q[k] += __builtin_amdgcn_sqrtf(norm2(r)) * inv_n;
+        }
+        GACQ_MARK16(6);
       }
-      GACQ_MARK16(6);
-    }
-    xrow = xnext_item;
-    if (QDUMP) {                                         // gacq_debug_row: the accumulated magnitude row itself (one row per launch)
+      xrow = xnext_unit;
+      if (QDUMP) {                                         // gacq_debug_row: the accumulated magnitude row itself (one row per launch)
 #pragma unroll
-      for (int k = 0; k < kR; k++) q_out[t + 1024 * k] = q[k];
-    }
-    float sum_f = q[0];
+        for (int k = 0; k < kR; k++) q_out[t + 1024 * k] = q[k];
+      }
+      float sum_f = q[0];
 #pragma unroll
-    for (int k = 1; k < kR; k++) sum_f += q[k];
-    // lane l of wave w holds lags 64 w + l + 1024 k: first maximum as in lds_correlate_kernel
-    float peak;
-    unsigned widx;
-    wave_first_max(q, (unsigned)__builtin_amdgcn_readfirstlane(t & ~63), 1u, 1024u, tie_scale, peak, widx);
-    big_reduce_store(smem, peak, widx, wave_add_f32(sum_f), tie_scale, rows + (e * P + p) * (long)D + d);
+      for (int k = 1; k < kR; k++) sum_f += q[k];
+      // lane l of wave w holds lags 64 w + l + 1024 k: first maximum as in lds_correlate_kernel
+      float peak;
+      unsigned widx;
+      wave_first_max(q, (unsigned)__builtin_amdgcn_readfirstlane(t & ~63), 1u, 1024u, tie_scale, peak, widx);
+      big_reduce_store(smem, peak, widx, wave_add_f32(sum_f), tie_scale, rows + (e * P + p) * (long)D + d);
+    }
   }
 #ifdef GACQ_PHASE_TIMING16
   if ((t & 63) == 0) {
@@ -1235,23 +1246,23 @@ int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const i
     const float2* twn;
     int rcb = twiddle_cache(ctx, "W16384_lo", kBig, 1024, &twn);
     if (rcb != GACQ_OK) return rcb;
-    // One 1024-thread workgroup per CU, 32 per XCD.  Items per workgroup: about P/32 -- the grid is then fine-grained enough that
-    // the last round of workgroups leaves few CUs idle (B1I, 63 items x 200 bins: 6400 workgroups = 25 rounds of 256) while a
-    // workgroup still amortises its start-up over >= 2 x B rows.  Measured (profiles/r03_16k_b1i_chunk_sweep.log): 2 items 3.04-3.06 ms,
-    // 1 item 3.07-3.15, 3 items 3.15-3.18, 4 items 3.15-3.21; walking two (epoch, Doppler) units side by side on an XCD (ugroup 2, so
-    // that both share the code spectra in L2) costs 3-4 % instead of paying: one unit at a time is the default.
+    // One 1024-thread workgroup per CU, 32 per XCD.  Workgroup = (one item, a group of G of the XCD's units): the item's code
+    // spectrum is read once per workgroup.  G as large as leaves >= ~8 workgroups per CU on an XCD (fine enough that the last
+    // round leaves few CUs idle), at most 8, evened out so that the groups of an XCD have the same size where possible.
+    // B1I (63 items, 200 units, B = 10): 25 units per XCD -> G = 5, 5 x 63 = 315 workgroups of 50 rows per XCD.
     const long units = (long)nepoch * D;
-    int pch = std::max(1, (nitems + 31) / 32);
+    int pch = 1;
     if (ctx->opt[GACQ_OPT_LDS_PCH] >= 1) pch = (int)ctx->opt[GACQ_OPT_LDS_PCH];
     pch = std::min(pch, nitems);
     const int nchunk = (nitems + pch - 1) / pch;
-    int ugroup = 1;
-    if (ctx->opt[GACQ_OPT_LDS_UGROUP] >= 1) ugroup = (int)ctx->opt[GACQ_OPT_LDS_UGROUP];
     const long units8 = (units + 7) / 8;                                 // units per XCD
+    long g0 = std::max<long>(1, std::min<long>(8, units8 * nchunk / 256));
+    int ugroup = (int)((units8 + ((units8 + g0 - 1) / g0) - 1) / ((units8 + g0 - 1) / g0));
+    if (ctx->opt[GACQ_OPT_LDS_UGROUP] >= 1) ugroup = (int)std::min<long>(ctx->opt[GACQ_OPT_LDS_UGROUP], units8);
     const long groups = (units8 + ugroup - 1) / ugroup;
     auto kern16 = q_out ? lds16k_correlate_kernel<true> : lds16k_correlate_kernel<false>;
     GACQ_HIP(ctx, hipFuncSetAttribute((const void*)kern16, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes));
-    hipLaunchKernelGGL(kern16, dim3((unsigned)(8 * groups * ugroup * nchunk)), dim3(kBigThreads), kBigLdsBytes, ctx->stream, X,
+    hipLaunchKernelGGL(kern16, dim3((unsigned)(8 * groups * nchunk)), dim3(kBigThreads), kBigLdsBytes, ctx->stream, X,
                        spectra, d_items, d_fset, twn, rows, nepoch, nitems, F, D, B, pch, nchunk, ugroup, tie_scale, q_out);
     GACQ_HIP(ctx, hipGetLastError());
     return GACQ_OK;

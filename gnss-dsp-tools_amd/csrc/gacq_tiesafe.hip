@@ -8,7 +8,8 @@
 // with its candidate rows; the kernels here then
 //   tie_recheck_kernel   recompute exactly those rows in complex128 -- table-NCO mix, FFT, C_p * conj(.), inverse FFT, |.|/N,
 //                        sum over blocks, (max, first argmax, sum) -- for any FFT length with prime factors in {2, 3, 5, 7, 11, 13, 31} (a
-//                        mixed-radix Stockham transform through a global-memory scratch row, one workgroup per row), and
+//                        mixed-radix Stockham transform through a global-memory scratch row; one workgroup per (row, block), the
+//                        last one to finish a row adds its blocks up in order; N = 4096 on the LDS-resident transform), and
 //   tie_resolve_kernel   redo the strict-'>' scan of the ambiguous pairs on the complex128 values and write their records.
 // Nothing returns to the host: the lists are filled, consumed and reset inside the stream, a launch without ambiguous pairs
 // costs two empty kernels.  The arithmetic is engine 5's (gacq_verify.hip) with another FFT implementation; both are held to
@@ -23,11 +24,11 @@ using namespace gacq;
 
 namespace {
 
-constexpr int kTieThreads = 256;
+constexpr int kTieThreads = 512;      // 8 waves: 2 per SIMD, <= 256 VGPRs each (the radix-31 pass holds 31 complex128 values per lane)
 constexpr int kMaxPasses = 20;
 struct Radices { int count; unsigned char r[kMaxPasses]; };
 
-__device__ __forceinline__ double2 cmul64(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+using gacq::f64::cd;
 
 // W_N^k = exp(-2 pi i k / N), k < N, evaluated with sincospi on the exactly reduced argument
 __global__ void twiddle64_kernel(double2* __restrict__ w, int N) {
@@ -38,28 +39,58 @@ __global__ void twiddle64_kernel(double2* __restrict__ w, int N) {
   w[k] = make_double2(c, s);
 }
 
+__device__ __forceinline__ cd ldc(const double2* p) { const double2 v = *p; return cd{v.x, v.y}; }
+__device__ __forceinline__ void stc(double2* p, cd v) { *p = make_double2(v.x, v.y); }
+
+// 2-, 4- and 8-point DFTs in place, natural order (the powers of two are the bulk of every length)
+template <int R> __device__ __forceinline__ void pow2_dft(cd (&v)[R]) {
+  using namespace gacq::f64;
+  if constexpr (R == 2) {
+    const cd a = v[0] + v[1], b = v[0] - v[1];
+    v[0] = a; v[1] = b;
+  } else if constexpr (R == 4) {
+    dft4<false>(v[0], v[1], v[2], v[3]);
+  } else {
+    cd e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    dft4<false>(e0, e1, e2, e3);
+    dft4<false>(o0, o1, o2, o3);
+    constexpr double h = 0.70710678118654752440;
+    o1 = o1 * cd{h, -h};                      // W8^1
+    o2 = cd{o2.y, -o2.x};                     // W8^2 = -i
+    o3 = o3 * cd{-h, -h};                     // W8^3
+    v[0] = e0 + o0; v[4] = e0 - o0;
+    v[1] = e1 + o1; v[5] = e1 - o1;
+    v[2] = e2 + o2; v[6] = e2 - o2;
+    v[3] = e3 + o3; v[7] = e3 - o3;
+  }
+}
+
 // One radix-R Stockham pass (decimation in frequency, autosort) over the whole row by the whole workgroup:
 //   y[q + s (R p + k)] = W_n^{p k} * sum_j a[q + s (p + m j)] W_R^{j k},   n = R m, p < m, q < s
+// R = 2, 4, 8: butterflies; the odd primes: the R x R sum with table twiddles, one output at a time (the k loop stays rolled).
 template <int R>
 __device__ void stockham_pass(const double2* __restrict__ a, double2* __restrict__ y, const double2* __restrict__ WN, int N, int n, int s) {
+  using namespace gacq::f64;
   const int m = n / R, step_r = N / R, step_n = N / n;
   for (int i = threadIdx.x; i < N / R; i += kTieThreads) {
     const int p = i / s, q = i - p * s;
-    double2 v[R];
+    cd v[R];
 #pragma unroll
-    for (int j = 0; j < R; j++) v[j] = a[q + s * (p + m * j)];
-    constexpr int kUnrollK = R <= 5 ? R : 1;          // the large radices keep the k loop rolled (R x R products otherwise)
-#pragma unroll kUnrollK
-    for (int k = 0; k < R; k++) {
-      double2 acc = v[0];
+    for (int j = 0; j < R; j++) v[j] = ldc(a + q + s * (p + m * j));
+    if constexpr (R == 2 || R == 4 || R == 8) {
+      pow2_dft<R>(v);
+      stc(y + q + s * (R * p), v[0]);
 #pragma unroll
-      for (int j = 1; j < R; j++) {
-        const double2 w = WN[((j * k) % R) * step_r];
-        acc.x += v[j].x * w.x - v[j].y * w.y;
-        acc.y += v[j].x * w.y + v[j].y * w.x;
+      for (int k = 1; k < R; k++) stc(y + q + s * (R * p + k), p ? v[k] * ldc(WN + (int)(((long)p * k) % n) * step_n) : v[k]);
+    } else {
+#pragma unroll 1
+      for (int k = 0; k < R; k++) {
+        cd acc = v[0];
+#pragma unroll
+        for (int j = 1; j < R; j++) acc = acc + v[j] * ldc(WN + ((j * k) % R) * step_r);
+        if (k && p) acc = acc * ldc(WN + (int)(((long)p * k) % n) * step_n);
+        stc(y + q + s * (R * p + k), acc);
       }
-      if (k) acc = cmul64(acc, WN[(int)(((long)p * k) % n) * step_n]);
-      y[q + s * (R * p + k)] = acc;
     }
   }
 }
@@ -76,6 +107,7 @@ __device__ double2* fft_row(double2* a, double2* b, const double2* __restrict__ 
       case 4: stockham_pass<4>(a, b, WN, N, n, s); break;
       case 5: stockham_pass<5>(a, b, WN, N, n, s); break;
       case 7: stockham_pass<7>(a, b, WN, N, n, s); break;
+      case 8: stockham_pass<8>(a, b, WN, N, n, s); break;
       case 11: stockham_pass<11>(a, b, WN, N, n, s); break;
       case 13: stockham_pass<13>(a, b, WN, N, n, s); break;
       default: stockham_pass<31>(a, b, WN, N, n, s); break;
@@ -88,36 +120,89 @@ __device__ double2* fft_row(double2* a, double2* b, const double2* __restrict__ 
   return a;
 }
 
-// One workgroup per listed row: q[k] = sum_b | ifft( C_p * conj(fft(x[b n : b n + N] * nco)) )[k] | in complex128
-// (acquire-gps-l1.py:28-35; |ifft(Y)| = |fft(conj(Y))| / N, so one forward transform routine serves both directions).
-__global__ __launch_bounds__(kTieThreads) void tie_recheck_kernel(TieLists tl, const float2* __restrict__ x, size_t epoch_stride,
+// Workgroup-wide (max, first argmax, sum) of the magnitudes val(i), i < N, visited in ascending order per thread
+template <class F> __device__ __forceinline__ void reduce_row(int N, F val, TieRec* dst) {
+  __shared__ double s_peak[kTieThreads], s_sum[kTieThreads];
+  __shared__ int s_idx[kTieThreads];
+  const int t = threadIdx.x;
+  double peak = -1.0, sum = 0.0;
+  int idx = 0x7fffffff;
+  for (int i = t; i < N; i += blockDim.x) {                           // strict '>' keeps the first maximum
+    const double v = val(i);
+    if (v > peak) { peak = v; idx = i; }
+    sum += v;
+  }
+  s_peak[t] = peak; s_sum[t] = sum; s_idx[t] = idx;
+  __syncthreads();
+  for (int off = blockDim.x / 2; off > 0; off >>= 1) {
+    if (t < off) {
+      const double op = s_peak[t + off];
+      const int oi = s_idx[t + off];
+      if (op > s_peak[t] || (op == s_peak[t] && oi < s_idx[t])) { s_peak[t] = op; s_idx[t] = oi; }
+      s_sum[t] += s_sum[t + off];
+    }
+    __syncthreads();
+  }
+  if (t == 0) { TieRec r; r.peak = s_peak[0]; r.sum = s_sum[0]; r.idx = s_idx[0]; r.pad = 0; *dst = r; }
+  __syncthreads();
+}
+
+// Hand-over between the workgroups that evaluate the B blocks of one row side by side: each stores its per-block magnitudes
+// (plain stores), releases them at agent scope and counts its arrival; the one that finds B - 1 earlier arrivals acquires and
+// adds the B rows up in block order (the same order a single workgroup accumulates them in: identical bits) and reduces.
+// MI355X_MICROARCH.md, inter-workgroup visibility: plain stores -> barrier -> lane-0 release fence -> s_waitcnt vmcnt(0) -> relaxed
+// agent atomic; consumer: agent acquire on one lane -> barrier -> plain loads.
+__device__ __forceinline__ bool arrive_last(unsigned* counter, int B) {
+  __shared__ int s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned earlier = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (int)earlier == B - 1;
+    if (s_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+    }
+  }
+  __syncthreads();
+  return s_last != 0;
+}
+
+// Work item = (listed row, block) when the per-block magnitude rows fit (qb != nullptr: B workgroups share a row, ~1 / B of the
+// latency -- a re-evaluation sits in the stream between two searches), else one listed row with its blocks in sequence.
+//   q[k] = sum_b | ifft( C_p * conj(fft(x[b n : b n + N] * nco)) )[k] |   in complex128   (acquire-gps-l1.py:28-35;
+// |ifft(Y)| = |fft(conj(Y))| / N, so one forward transform routine serves both directions)
+__global__ __launch_bounds__(kTieThreads) void tie_recheck_kernel(TieLists tl, unsigned* __restrict__ done, double* __restrict__ qb,
+                                                                   const float2* __restrict__ x, size_t epoch_stride,
                                                                    const double2* __restrict__ C64, const int* __restrict__ items,
                                                                    const int* __restrict__ fset, const double* __restrict__ freq,
                                                                    const double2* __restrict__ tab64, const double2* __restrict__ WN,
                                                                    char* __restrict__ scratch, int n, int N, int P, int D, int B, Radices rad) {
-  __shared__ double s_peak[kTieThreads], s_sum[kTieThreads];
-  __shared__ int s_idx[kTieThreads];
   const unsigned count = min(tl.c->nrows, (unsigned)tl.cap);
+  const unsigned nwork = qb ? count * (unsigned)B : count;
   char* mine = scratch + (size_t)blockIdx.x * ((size_t)N * 40);
   double2* bufa = reinterpret_cast<double2*>(mine);
   double2* bufb = bufa + N;
-  double* q = reinterpret_cast<double*>(bufb + N);
+  double* qown = reinterpret_cast<double*>(bufb + N);
   const double inv_n = 1.0 / (double)N;
   const int t = threadIdx.x;
-  for (unsigned slot = blockIdx.x; slot < count; slot += gridDim.x) {
+  for (unsigned w = blockIdx.x; w < nwork; w += gridDim.x) {
+    const unsigned slot = qb ? w / (unsigned)B : w;
+    const int b0 = qb ? (int)(w % (unsigned)B) : 0, b1 = qb ? b0 + 1 : B;
     const TieRow row = tl.rows[slot];
     if (row.ep < 0) continue;                                            // voided slot of a pair that did not fit (uniform over the workgroup)
     const long e = row.ep / P;
     const int p = row.ep - (int)e * P;
     const double f = freq[(long)fset[p] * D + row.d];
     const double2* Cp = C64 + (long)items[p] * N;
-    for (int i = t; i < N; i += kTieThreads) q[i] = 0.0;
-    for (int b = 0; b < B; b++) {
+    double* q = qb ? qb + ((size_t)slot * B + b0) * N : qown;
+    for (int b = b0; b < b1; b++) {
       const float2* src = x + e * epoch_stride + (size_t)b * n;
       for (int i = t; i < N; i += kTieThreads) {
         const float2 sv = src[i];
-        const double2 w = tab64[nco_index(f, i)];                     // gnsstools/nco.py:6-10
-        bufa[i] = make_double2((double)sv.x * w.x - (double)sv.y * w.y, (double)sv.x * w.y + (double)sv.y * w.x);
+        const double2 wv = tab64[nco_index(f, i)];                    // gnsstools/nco.py:6-10
+        bufa[i] = make_double2((double)sv.x * wv.x - (double)sv.y * wv.y, (double)sv.x * wv.y + (double)sv.y * wv.x);
       }
       double2* X = fft_row(bufa, bufb, WN, N, rad);
       double2* other = (X == bufa) ? bufb : bufa;
@@ -126,36 +211,27 @@ __global__ __launch_bounds__(kTieThreads) void tie_recheck_kernel(TieLists tl, c
         X[i] = make_double2(cv.x * xv.x + cv.y * xv.y, cv.x * xv.y - cv.y * xv.x);
       }
       double2* Z = fft_row(X, other, WN, N, rad);
-      for (int i = t; i < N; i += kTieThreads) q[i] += hypot(Z[i].x * inv_n, Z[i].y * inv_n);
+      for (int i = t; i < N; i += kTieThreads) {
+        const double m = hypot(Z[i].x * inv_n, Z[i].y * inv_n);
+        q[i] = (b == b0) ? m : q[i] + m;
+      }
       __syncthreads();                                                 // the row buffers are rewritten by the next block's mix
     }
-    double peak = -1.0, sum = 0.0;
-    int idx = 0x7fffffff;
-    for (int i = t; i < N; i += kTieThreads) {                         // ascending i per thread: strict '>' keeps the first maximum
-      const double v = q[i];
-      if (v > peak) { peak = v; idx = i; }
-      sum += v;
+    if (qb) {
+      if (!arrive_last(done + slot, B)) continue;
+      const double* q0 = qb + (size_t)slot * B * N;
+      reduce_row(N, [&](int i) { double v = q0[i]; for (int b = 1; b < B; b++) v += q0[(size_t)b * N + i]; return v; }, tl.recs + slot);
+    } else {
+      reduce_row(N, [&](int i) { return q[i]; }, tl.recs + slot);
     }
-    s_peak[t] = peak; s_sum[t] = sum; s_idx[t] = idx;
-    __syncthreads();
-    for (int off = kTieThreads / 2; off > 0; off >>= 1) {
-      if (t < off) {
-        const double op = s_peak[t + off];
-        const int oi = s_idx[t + off];
-        if (op > s_peak[t] || (op == s_peak[t] && oi < s_idx[t])) { s_peak[t] = op; s_idx[t] = oi; }
-        s_sum[t] += s_sum[t + off];
-      }
-      __syncthreads();
-    }
-    if (t == 0) { TieRec r; r.peak = s_peak[0]; r.sum = s_sum[0]; r.idx = s_idx[0]; r.pad = 0; tl.recs[slot] = r; }
-    __syncthreads();
   }
 }
 
-// N = 4096 (GPS L1 C/A, Xona X1: the headline shape, where a step of 32768 searches has a handful of ambiguous pairs): the same row
-// on the LDS-resident complex128 transform of gacq_fft64.h -- ~10 us per row instead of ~100 us through the global-memory
-// Stockham passes above, so that the re-evaluation stays invisible next to the 5.6 ms search it follows.
-__global__ __launch_bounds__(256, 1) void tie_recheck4k_kernel(TieLists tl, const float2* __restrict__ x, size_t epoch_stride,
+// N = 4096 (GPS L1 C/A, Xona X1: the headline shape, where a step of 32768 searches has a handful of ambiguous pairs): the same work
+// items on the LDS-resident complex128 transform of gacq_fft64.h -- ~10 us per (row, block) instead of ~50 us through the
+// global-memory Stockham passes above, so that the re-evaluation stays invisible next to the 5.6 ms search it follows.
+__global__ __launch_bounds__(256, 1) void tie_recheck4k_kernel(TieLists tl, unsigned* __restrict__ done, double* __restrict__ qb,
+                                                               const float2* __restrict__ x, size_t epoch_stride,
                                                                const double2* __restrict__ C64, const int* __restrict__ items,
                                                                const int* __restrict__ fset, const double* __restrict__ freq,
                                                                const double2* __restrict__ tab64, const double2* __restrict__ WN, int n, int P,
@@ -165,11 +241,14 @@ __global__ __launch_bounds__(256, 1) void tie_recheck4k_kernel(TieLists tl, cons
   __shared__ double s_peak[4], s_sum[4];
   __shared__ int s_idx[4];
   const unsigned count = min(tl.c->nrows, (unsigned)tl.cap);
+  const unsigned nwork = qb ? count * (unsigned)B : count;
   const int t = threadIdx.x;
   const double2 wa2 = WN[t], wb2 = WN[16 * (t & 15)];
   const cd wa = {wa2.x, wa2.y}, wb = {wb2.x, wb2.y};
   const double inv_n = 1.0 / (double)kN;
-  for (unsigned slot = blockIdx.x; slot < count; slot += gridDim.x) {
+  for (unsigned w = blockIdx.x; w < nwork; w += gridDim.x) {
+    const unsigned slot = qb ? w / (unsigned)B : w;
+    const int b0 = qb ? (int)(w % (unsigned)B) : 0, b1 = qb ? b0 + 1 : B;
     const TieRow row = tl.rows[slot];
     if (row.ep < 0) continue;
     const long e = row.ep / P;
@@ -177,17 +256,15 @@ __global__ __launch_bounds__(256, 1) void tie_recheck4k_kernel(TieLists tl, cons
     const double f = freq[(long)fset[p] * D + row.d];
     const double2* cp = C64 + (long)items[p] * kN + t;
     double q[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) q[k] = 0.0;
-    for (int b = 0; b < B; b++) {
+    for (int b = b0; b < b1; b++) {
       const float2* src = x + e * epoch_stride + (size_t)b * n;
       cd v[16];
 #pragma unroll
       for (int j = 0; j < 16; j++) {
         const int i = t + 256 * j;
         const float2 sv = src[i];
-        const double2 w = tab64[nco_index(f, i)];
-        v[j] = cd{(double)sv.x, (double)sv.y} * cd{w.x, w.y};
+        const double2 wv = tab64[nco_index(f, i)];
+        v[j] = cd{(double)sv.x, (double)sv.y} * cd{wv.x, wv.y};
       }
       fft4096<false>(v, lds64, wa, wb, t);
       cd y[16];
@@ -196,8 +273,25 @@ __global__ __launch_bounds__(256, 1) void tie_recheck4k_kernel(TieLists tl, cons
       __syncthreads();
       fft4096<true>(y, lds64, wa, wb, t);
 #pragma unroll
-      for (int k = 0; k < 16; k++) { const cd r = y[rev16(k)]; q[k] += sqrt_pos(r.x * r.x + r.y * r.y) * inv_n; }
+      for (int k = 0; k < 16; k++) {
+        const cd r = y[rev16(k)];
+        const double m = sqrt_pos(r.x * r.x + r.y * r.y) * inv_n;
+        q[k] = (b == b0) ? m : q[k] + m;
+      }
       __syncthreads();
+    }
+    if (qb) {
+      double* mineq = qb + ((size_t)slot * B + b0) * kN;
+#pragma unroll
+      for (int k = 0; k < 16; k++) mineq[t + 256 * k] = q[k];
+      if (!arrive_last(done + slot, B)) continue;
+      const double* q0 = qb + (size_t)slot * B * kN;
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        double v = q0[t + 256 * k];
+        for (int b = 1; b < B; b++) v += q0[(size_t)b * kN + t + 256 * k];
+        q[k] = v;
+      }
     }
     double peak = -1.0, sum = 0.0;
     int idx = 0;
@@ -217,9 +311,9 @@ __global__ __launch_bounds__(256, 1) void tie_recheck4k_kernel(TieLists tl, cons
     if ((t & 63) == 0) { s_peak[t >> 6] = peak; s_idx[t >> 6] = idx; s_sum[t >> 6] = sum; }
     __syncthreads();
     if (t == 0) {
-      for (int w = 1; w < 4; w++) {
-        if (s_peak[w] > peak || (s_peak[w] == peak && s_idx[w] < idx)) { peak = s_peak[w]; idx = s_idx[w]; }
-        sum += s_sum[w];
+      for (int w2 = 1; w2 < 4; w2++) {
+        if (s_peak[w2] > peak || (s_peak[w2] == peak && s_idx[w2] < idx)) { peak = s_peak[w2]; idx = s_idx[w2]; }
+        sum += s_sum[w2];
       }
       TieRec r; r.peak = peak; r.sum = sum; r.idx = idx; r.pad = 0;
       tl.recs[slot] = r;
@@ -265,7 +359,7 @@ __global__ __launch_bounds__(256) void tie_resolve_kernel(TieLists tl, gacq_peak
 
 bool factorise(int N, Radices& rad) {
   rad.count = 0;
-  for (int r : {4, 2, 3, 5, 7, 11, 13, 31}) {
+  for (int r : {8, 4, 2, 3, 5, 7, 11, 13, 31}) {
     while (N % r == 0) {
       if (rad.count == kMaxPasses) return false;
       rad.r[rad.count++] = (unsigned char)r;
@@ -297,7 +391,7 @@ float tie_scale_of(const gacq_ctx* ctx) {
 // layout of ctx->tie: [TieCounters | fp32 guesses (gacq_peak x cap) | TieEp x cap | TieRow x cap | TieRec x cap]
 int tie_lists(gacq_ctx* ctx, long nep, TieLists* out, gacq_peak** guesses) {
   const int cap = tie_capacity(ctx, nep);
-  const size_t bytes = 64 + (size_t)cap * (sizeof(gacq_peak) + sizeof(TieEp) + sizeof(TieRow) + sizeof(TieRec));
+  const size_t bytes = 64 + (size_t)cap * (sizeof(unsigned) * 2 + sizeof(gacq_peak) + sizeof(TieEp) + sizeof(TieRow) + sizeof(TieRec));
   if (cap > ctx->tie_cap || !ctx->tie.p) {
     TieCounters keep{};
     if (ctx->tie.p) {
@@ -307,6 +401,7 @@ int tie_lists(gacq_ctx* ctx, long nep, TieLists* out, gacq_peak** guesses) {
     int rc = ensure(ctx, ctx->tie, bytes);
     if (rc != GACQ_OK) return rc;
     keep.nrows = keep.neps = 0;
+    GACQ_HIP(ctx, hipMemset(ctx->tie.p, 0, ctx->tie.cap));             // the per-row arrival counters start (and are left) at zero
     GACQ_HIP(ctx, hipMemcpy(ctx->tie.p, &keep, sizeof keep, hipMemcpyHostToDevice));
     ctx->tie_cap = cap;
   }
@@ -314,6 +409,8 @@ int tie_lists(gacq_ctx* ctx, long nep, TieLists* out, gacq_peak** guesses) {
   char* base = (char*)ctx->tie.p;
   const int lay = ctx->tie_cap;
   out->c = (TieCounters*)base;
+  out->done = (unsigned*)(base + 64);                                 // [lay] arrival counters, 8-byte stride keeps what follows aligned
+  base += (size_t)lay * sizeof(unsigned) * 2;
   *guesses = (gacq_peak*)(base + 64);
   out->eps = (TieEp*)(base + 64 + (size_t)lay * sizeof(gacq_peak));
   out->rows = (TieRow*)((char*)out->eps + (size_t)lay * sizeof(TieEp));
@@ -361,10 +458,19 @@ int tie_resolve(gacq_sig* sig, const TieLists& tl, const gacq_peak* guesses, con
     wt = ctx->tables.emplace(key, b).first;
   }
   const double2* WN = (const double2*)wt->second.p;
+  // B > 1: the blocks of a listed row are evaluated side by side by B workgroups when their per-block magnitude rows
+  // (capacity x B x N fp64 values) fit into 256 MiB; otherwise one workgroup takes the row's blocks in sequence (same bits)
+  double* qb = nullptr;
+  const size_t qb_bytes = (size_t)tl.cap * B * N * sizeof(double);
+  if (B > 1 && qb_bytes <= ((size_t)256 << 20)) {
+    if ((rc = ensure(ctx, ctx->tie_q, qb_bytes)) != GACQ_OK) return rc;
+    qb = (double*)ctx->tie_q.p;
+  }
   if (N == gacq::f64::kN) {
     GACQ_HIP(ctx, hipFuncSetAttribute((const void*)tie_recheck4k_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, gacq::f64::kLdsBytes));
-    hipLaunchKernelGGL(tie_recheck4k_kernel, dim3(128), dim3(256), gacq::f64::kLdsBytes, ctx->stream, tl, d_x, nsamp, (const double2*)sig->spectra64,
-                       (const int*)ctx->items.p, (const int*)ctx->fset.p, (const double*)ctx->freq.p, tab64, WN, sig->desc.n, P, D, B);
+    hipLaunchKernelGGL(tie_recheck4k_kernel, dim3(128), dim3(256), gacq::f64::kLdsBytes, ctx->stream, tl, tl.done, qb, d_x, nsamp,
+                       (const double2*)sig->spectra64, (const int*)ctx->items.p, (const int*)ctx->fset.p, (const double*)ctx->freq.p, tab64, WN,
+                       sig->desc.n, P, D, B);
     GACQ_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(tie_resolve_kernel, dim3(1), dim3(256), 0, ctx->stream, tl, d_out, guesses, N, sig->desc.metric_mode);
     GACQ_HIP(ctx, hipGetLastError());
@@ -374,9 +480,9 @@ int tie_resolve(gacq_sig* sig, const TieLists& tl, const gacq_peak* guesses, con
   const size_t row_bytes = (size_t)N * 40;
   const int G = (int)std::max<size_t>(4, std::min<size_t>(64, ((size_t)64 << 20) / row_bytes));
   if ((rc = ensure(ctx, ctx->tie_scratch, row_bytes * G)) != GACQ_OK) return rc;
-  hipLaunchKernelGGL(tie_recheck_kernel, dim3((unsigned)G), dim3(kTieThreads), 0, ctx->stream, tl, d_x, nsamp, (const double2*)sig->spectra64,
-                     (const int*)ctx->items.p, (const int*)ctx->fset.p, (const double*)ctx->freq.p, tab64, WN, (char*)ctx->tie_scratch.p,
-                     sig->desc.n, N, P, D, B, rad);
+  hipLaunchKernelGGL(tie_recheck_kernel, dim3((unsigned)G), dim3(kTieThreads), 0, ctx->stream, tl, tl.done, qb, d_x, nsamp,
+                     (const double2*)sig->spectra64, (const int*)ctx->items.p, (const int*)ctx->fset.p, (const double*)ctx->freq.p, tab64, WN,
+                     (char*)ctx->tie_scratch.p, sig->desc.n, N, P, D, B, rad);
   GACQ_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(tie_resolve_kernel, dim3(1), dim3(256), 0, ctx->stream, tl, d_out, guesses, N, sig->desc.metric_mode);
   GACQ_HIP(ctx, hipGetLastError());
