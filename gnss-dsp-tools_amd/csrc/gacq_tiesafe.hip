@@ -72,6 +72,8 @@ template <int R>
 __device__ void stockham_pass(const double2* __restrict__ a, double2* __restrict__ y, const double2* __restrict__ WN, int N, int n, int s) {
   using namespace gacq::f64;
   const int m = n / R, step_r = N / R, step_n = N / n;
+  constexpr int kIter = R <= 8 ? 4 : 1;              // butterflies in flight per lane: their loads overlap (32 VGPRs each at R = 8)
+#pragma unroll kIter
   for (int i = threadIdx.x; i < N / R; i += kTieThreads) {
     const int p = i / s, q = i - p * s;
     cd v[R];
@@ -127,10 +129,24 @@ template <class F> __device__ __forceinline__ void reduce_row(int N, F val, TieR
   const int t = threadIdx.x;
   double peak = -1.0, sum = 0.0;
   int idx = 0x7fffffff;
-  for (int i = t; i < N; i += blockDim.x) {                           // strict '>' keeps the first maximum
-    const double v = val(i);
-    if (v > peak) { peak = v; idx = i; }
-    sum += v;
+  // eight values per lane are fetched before the first compare: the loads behind val() are independent, the strict-'>' scan is not --
+  // taken one at a time, every value costs a full memory round trip on an otherwise idle chip
+  constexpr int kBatch = 8;
+  for (int i0 = t; i0 < N; i0 += kBatch * (int)blockDim.x) {
+    double v[kBatch];
+#pragma unroll
+    for (int u = 0; u < kBatch; u++) {
+      const int i = i0 + u * (int)blockDim.x;
+      v[u] = i < N ? val(i) : -1.0;
+    }
+#pragma unroll
+    for (int u = 0; u < kBatch; u++) {                                 // ascending i: strict '>' keeps the first maximum
+      const int i = i0 + u * (int)blockDim.x;
+      if (i < N) {
+        if (v[u] > peak) { peak = v[u]; idx = i; }
+        sum += v[u];
+      }
+    }
   }
   s_peak[t] = peak; s_sum[t] = sum; s_idx[t] = idx;
   __syncthreads();
@@ -212,7 +228,7 @@ __global__ __launch_bounds__(kTieThreads) void tie_recheck_kernel(TieLists tl, u
       }
       double2* Z = fft_row(X, other, WN, N, rad);
       for (int i = t; i < N; i += kTieThreads) {
-        const double m = hypot(Z[i].x * inv_n, Z[i].y * inv_n);
+        const double m = gacq::f64::sqrt_pos(Z[i].x * Z[i].x + Z[i].y * Z[i].y) * inv_n;
         q[i] = (b == b0) ? m : q[i] + m;
       }
       __syncthreads();                                                 // the row buffers are rewritten by the next block's mix
@@ -319,6 +335,114 @@ __global__ __launch_bounds__(256, 1) void tie_recheck4k_kernel(TieLists tl, unsi
       tl.recs[slot] = r;
     }
     __syncthreads();
+  }
+}
+
+// N = R x 4096, R = 4 or 16 (BeiDou B1I / B2I, GLONASS L1 / L2: 16384; Galileo E1B / E1C: 65536): the row split like engine 4's,
+// n = 4096 n1 + n2, k = k1 + R k2, with the 4096-point transforms on the LDS-resident complex128 transform.  Work item = (listed
+// row, block, k1): one workgroup forms A[k1][n2] = W_N^{n2 k1} sum_n1 x[4096 n1 + n2] W_R^{n1 k1} straight from the samples (mix
+// included), transforms it, multiplies by conj(C_p[k1 + R k2]), transforms again (|ifft(Y)| = |fft(conj Y)| / N; the second
+// transform decimates in time, so its inner transforms run over the same k1 rows) and stores W_N^{k1 n2} T_k1[n2]; the last of the
+// R workgroups of a (row, block) to arrive does the outer DFT-R and the magnitudes, the last block of a row the ordered sum and
+// the reduction.  Two global round trips per block instead of ten Stockham passes, R-fold parallel: ~25 us per listed row where
+// the generic kernel needs ~150 us per block.
+template <int R>
+__global__ __launch_bounds__(256, 1) void tie_recheck_split_kernel(TieLists tl, unsigned* __restrict__ done, unsigned* __restrict__ done2,
+                                                                   double* __restrict__ qb, double2* __restrict__ zs,
+                                                                   const float2* __restrict__ x, size_t epoch_stride,
+                                                                   const double2* __restrict__ C64, const int* __restrict__ items,
+                                                                   const int* __restrict__ fset, const double* __restrict__ freq,
+                                                                   const double2* __restrict__ tab64, const double2* __restrict__ WN, int n, int P,
+                                                                   int D, int B) {
+  using namespace gacq::f64;
+  constexpr int M = kN, N = R * kN;
+  extern __shared__ __attribute__((aligned(16))) double lds64[];
+  const unsigned count = min(tl.c->nrows, (unsigned)tl.cap);
+  const unsigned nwork = count * (unsigned)B * (unsigned)R;
+  const int t = threadIdx.x;
+  const cd wa = ldc(WN + t * R), wb = ldc(WN + 16 * (t & 15) * R);      // W_4096^t, W_256^(t & 15)
+  const double inv_n = 1.0 / (double)N;
+  for (unsigned w = blockIdx.x; w < nwork; w += gridDim.x) {
+    const int k1 = (int)(w % (unsigned)R);
+    const unsigned sb = w / (unsigned)R;                                 // (slot, block)
+    const unsigned slot = sb / (unsigned)B;
+    const int b = (int)(sb % (unsigned)B);
+    const TieRow row = tl.rows[slot];
+    if (row.ep < 0) continue;
+    const long e = row.ep / P;
+    const int p = row.ep - (int)e * P;
+    const double f = freq[(long)fset[p] * D + row.d];
+    const double2* Cp = C64 + (long)items[p] * N;
+    const float2* src = x + e * epoch_stride + (size_t)b * n;
+    cd v[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) v[j] = cd{0.0, 0.0};
+    for (int n1 = 0; n1 < R; n1++) {
+      // the 16 sample loads and the 16 table gathers of one n1 are independent: issued together, one round trip each
+      float2 sv[16];
+      double2 wv[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const int i = M * n1 + t + 256 * j;
+        sv[j] = src[i];
+        wv[j] = tab64[nco_index(f, i)];                                // gnsstools/nco.py:6-10
+      }
+      const cd wr = ldc(WN + ((n1 * k1) % R) * M);                     // W_R^{n1 k1}
+#pragma unroll
+      for (int j = 0; j < 16; j++) v[j] = v[j] + (cd{(double)sv[j].x, (double)sv[j].y} * cd{wv[j].x, wv[j].y}) * wr;
+    }
+    {
+      cd tw[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) tw[j] = ldc(WN + (t + 256 * j) * k1);   // W_N^{n2 k1}  (n2 k1 < N)
+#pragma unroll
+      for (int j = 0; j < 16; j++) v[j] = v[j] * tw[j];
+    }
+    fft4096<false>(v, lds64, wa, wb, t);
+    cd y[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) y[j] = ldc(Cp + k1 + R * (t + 256 * j));      // register rev16(j) holds k2 = t + 256 j: X[k1 + R k2]
+#pragma unroll
+    for (int j = 0; j < 16; j++) y[j] = conj(y[j]) * v[rev16(j)];              // conj(C_p * conj(X))
+    __syncthreads();
+    fft4096<false>(y, lds64, wa, wb, t);
+    double2* zrow = zs + ((size_t)sb * R + k1) * M;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const int n2 = t + 256 * j;
+      stc(zrow + n2, y[rev16(j)] * ldc(WN + n2 * k1));                 // W_N^{k1 n2} T_k1[n2]
+    }
+    if (!arrive_last(done2 + sb, R)) continue;
+    // outer DFT-R over k1 for every n2, magnitudes of this block's row
+    const double2* z0 = zs + (size_t)sb * R * M;
+    double* q = qb + (size_t)sb * N;
+    constexpr int JB = R == 4 ? 4 : 1;                                 // columns per batch: 16 loads in flight either way
+    for (int j0 = 0; j0 < 16; j0 += JB) {
+      cd z[JB][R];
+#pragma unroll
+      for (int jj = 0; jj < JB; jj++)
+#pragma unroll
+        for (int kk = 0; kk < R; kk++) z[jj][kk] = ldc(z0 + (size_t)kk * M + t + 256 * (j0 + jj));
+#pragma unroll
+      for (int jj = 0; jj < JB; jj++) {
+        const int n2 = t + 256 * (j0 + jj);
+        if constexpr (R == 4) {
+          dft4<false>(z[jj][0], z[jj][1], z[jj][2], z[jj][3]);
+#pragma unroll
+          for (int n1 = 0; n1 < 4; n1++) q[M * n1 + n2] = sqrt_pos(z[jj][n1].x * z[jj][n1].x + z[jj][n1].y * z[jj][n1].y) * inv_n;
+        } else {
+          dft16<false>(z[jj]);
+#pragma unroll
+          for (int n1 = 0; n1 < 16; n1++) {
+            const cd r = z[jj][rev16(n1)];
+            q[M * n1 + n2] = sqrt_pos(r.x * r.x + r.y * r.y) * inv_n;
+          }
+        }
+      }
+    }
+    if (!arrive_last(done + slot, B)) continue;
+    const double* q0 = qb + (size_t)slot * B * N;
+    reduce_row(N, [&](int i) { double a = q0[i]; for (int bb = 1; bb < B; bb++) a += q0[(size_t)bb * N + i]; return a; }, tl.recs + slot);
   }
 }
 
@@ -465,6 +589,28 @@ int tie_resolve(gacq_sig* sig, const TieLists& tl, const gacq_peak* guesses, con
   if (B > 1 && qb_bytes <= ((size_t)256 << 20)) {
     if ((rc = ensure(ctx, ctx->tie_q, qb_bytes)) != GACQ_OK) return rc;
     qb = (double*)ctx->tie_q.p;
+  }
+  const int Rs = (N == 4 * gacq::f64::kN) ? 4 : ((N == 16 * gacq::f64::kN) ? 16 : 0);
+  const size_t split_bytes = (size_t)tl.cap * B * ((size_t)N * (sizeof(double) + sizeof(double2)) + 64);
+  if (Rs && split_bytes <= ((size_t)768 << 20)) {
+    // [per-(row, block) arrival counters | per-block magnitude rows | twiddled inner transforms]
+    const size_t cnt_bytes = (((size_t)tl.cap * B * sizeof(unsigned)) + 255) & ~(size_t)255;
+    const size_t q_bytes = (size_t)tl.cap * B * N * sizeof(double);
+    const bool fresh = ctx->tie_split.cap < split_bytes + cnt_bytes;
+    if ((rc = ensure(ctx, ctx->tie_split, split_bytes + cnt_bytes)) != GACQ_OK) return rc;
+    if (fresh) GACQ_HIP(ctx, hipMemsetAsync(ctx->tie_split.p, 0, cnt_bytes, ctx->stream));      // the kernels leave the counters at zero
+    unsigned* done2 = (unsigned*)ctx->tie_split.p;
+    double* q2 = (double*)((char*)ctx->tie_split.p + cnt_bytes);
+    double2* zs = (double2*)((char*)q2 + q_bytes);
+    auto kern = Rs == 4 ? tie_recheck_split_kernel<4> : tie_recheck_split_kernel<16>;
+    GACQ_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, gacq::f64::kLdsBytes));
+    hipLaunchKernelGGL(kern, dim3(256), dim3(256), gacq::f64::kLdsBytes, ctx->stream, tl, tl.done, done2, q2, zs, d_x, nsamp,
+                       (const double2*)sig->spectra64, (const int*)ctx->items.p, (const int*)ctx->fset.p, (const double*)ctx->freq.p, tab64, WN,
+                       sig->desc.n, P, D, B);
+    GACQ_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(tie_resolve_kernel, dim3(1), dim3(256), 0, ctx->stream, tl, d_out, guesses, N, sig->desc.metric_mode);
+    GACQ_HIP(ctx, hipGetLastError());
+    return GACQ_OK;
   }
   if (N == gacq::f64::kN) {
     GACQ_HIP(ctx, hipFuncSetAttribute((const void*)tie_recheck4k_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, gacq::f64::kLdsBytes));
