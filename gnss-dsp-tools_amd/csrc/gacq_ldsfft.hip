@@ -1247,16 +1247,18 @@ int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const i
     int rcb = twiddle_cache(ctx, "W16384_lo", kBig, 1024, &twn);
     if (rcb != GACQ_OK) return rcb;
     // One 1024-thread workgroup per CU, 32 per XCD.  Workgroup = (one item, a group of G of the XCD's units): the item's code
-    // spectrum is read once per workgroup.  G as large as leaves >= ~8 workgroups per CU on an XCD (fine enough that the last
-    // round leaves few CUs idle), at most 8, evened out so that the groups of an XCD have the same size where possible.
-    // B1I (63 items, 200 units, B = 10): 25 units per XCD -> G = 5, 5 x 63 = 315 workgroups of 50 rows per XCD.
+    // spectrum is read once per workgroup, so G is as large as still leaves ~2 rounds of workgroups per XCD (>= 60; at most 32
+    // units), evened out so that the groups of an XCD have the same size where possible.  B1I (63 items, 200 units, B = 10):
+    // 25 units per XCD -> G = 25, 63 workgroups of 250 rows per XCD.  Measured (profiles/r04_16k_unit_group_sweep.log): HBM
+    // traffic per launch 2.07 GB (round 3, unit-major) -> 1.07 GB (G = 5) -> 0.89 (9) -> 0.78 (13) -> 0.59 GB (25) = 2.2 x the
+    // compulsory bytes, kernel time unchanged within 2 % (3.37-3.45 ms in the four-signal step): HBM was never what paced it.
     const long units = (long)nepoch * D;
     int pch = 1;
     if (ctx->opt[GACQ_OPT_LDS_PCH] >= 1) pch = (int)ctx->opt[GACQ_OPT_LDS_PCH];
     pch = std::min(pch, nitems);
     const int nchunk = (nitems + pch - 1) / pch;
     const long units8 = (units + 7) / 8;                                 // units per XCD
-    long g0 = std::max<long>(1, std::min<long>(8, units8 * nchunk / 256));
+    long g0 = std::max<long>(1, std::min<long>(32, units8 * nchunk / 60));
     int ugroup = (int)((units8 + ((units8 + g0 - 1) / g0) - 1) / ((units8 + g0 - 1) / g0));
     if (ctx->opt[GACQ_OPT_LDS_UGROUP] >= 1) ugroup = (int)std::min<long>(ctx->opt[GACQ_OPT_LDS_UGROUP], units8);
     const long groups = (units8 + ugroup - 1) / ugroup;

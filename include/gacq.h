@@ -118,7 +118,7 @@ int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes);
                                 /*     code-spectrum row fetched serves that many correlation rows                           */
 #define GACQ_OPT_FE_GENERIC 8    /* [0] front-end: 1 = run the any-length mix + FIR kernels even for the reference's 161-tap filter     */
                                 /*     (the specialised kernels produce the same bits; this is the A/B and test switch)              */
-#define GACQ_OPT_LDS_UGROUP 9    /* [0 = auto, <= 8] N = 16384 correlate kernel: (epoch, Doppler) units a workgroup walks with one item's  */
+#define GACQ_OPT_LDS_UGROUP 9    /* [0 = auto, <= 64] N = 16384 correlate kernel: (epoch, Doppler) units a workgroup walks with one item's  */
                                 /*     code spectrum held in registers (round 4: item-major order; the spectrum is fetched once per group)  */
 #define GACQ_OPT_SEARCH1 10       /* [0] N = 4096, B = 1, one carrier, small batches (<= 4096 rows): the whole search -- mix, forward        */
                                 /*     transform, correlation, Doppler scan -- in ONE kernel launch.  Off by default: measured slower      */
