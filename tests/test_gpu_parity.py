@@ -539,6 +539,28 @@ def test_bench_measures_hbm_traffic_live_with_pmc_child_runs():
     assert rr["kernel"] == "fused4k_c128_kernel" and rr["peak"] == 78.6 and 0.05 < rr["frac"] < 1.0 and rr["avg_kernel_ms"] <= ref["ms_per_step"], rr
     assert ref["value"] > 1.5e11 and ref["f32_same_loop"]["seconds_timed"] >= 1.0, ref
     assert abs(ref["f32_over_f64"] - ref["f32_same_loop"]["value"] / ref["value"]) < 1e-9
+    # round 4: the rows either side of the FFT search, the live stream ceilings and the tie-safe counters are in the driver-visible line
+    nr = j["next_rows"]
+    assert set(nr) == {"frontend", "longcode_l2cl", "longcode_glonass_p", "tracking_epl"}, nr
+    assert 0.0 < nr["frontend"]["frac_hbm_8TBps"] < 1.0 and 0.0 < nr["frontend"]["frac_fp32_vector_peak"] < 1.0 and nr["frontend"]["calls_timed"] >= 3
+    assert nr["longcode_l2cl"]["k_found"] == nr["longcode_l2cl"]["k_injected"] and nr["longcode_glonass_p"]["k_found"] == nr["longcode_glonass_p"]["k_injected"]
+    assert 0.0 < nr["tracking_epl"]["us_resident_block"] < nr["tracking_epl"]["us_host_block"] < 500.0
+    assert j["tie_safe"]["enabled"] is True and j["tie_safe"]["kept_fp32"] == 0, j["tie_safe"]
+    for c in others:
+        if c["bound"] == "hbm":
+            sc = c["stream_ceiling"]
+            assert sc["measured_in_this_run"] is True and 2000.0 < sc["GBps"] < 8000.0 and (sc.get("exceeded_by_kernel") or 0.0 < sc["frac"] <= 1.0), sc
+
+
+def test_stream_probe_measures_plausible_hbm_rates(engine):
+    """gacq_stream_probe: a tuned fill / read / copy kernel on this device (what bench.py holds the HBM-bound kernels against): between a
+    quarter of and the full 8 TB/s of the data sheet, read >= fill (stores are the slower direction on this part), and bad arguments rejected."""
+    from gnss_dsp_tools_amd import _native as nat
+    r = {k: engine.stream_probe(k, 1 << 30, 4) for k in ("fill", "read", "copy")}
+    assert all(2000.0 < v < 8000.0 for v in r.values()), r
+    assert r["read"] > r["fill"] * 0.95, r
+    with pytest.raises(nat.GacqError):
+        engine.stream_probe("fill", 1000, 4)
 
 
 def test_bench_rank_slice_projection_mode():
