@@ -663,15 +663,24 @@ def make_timed(run_steps, dev, use_dist):
             torch.cuda.synchronize(dev)
 
     def timed(k):
-        sync_dev()
-        if use_dist:
-            dist.barrier()
-        t0 = time.perf_counter()
-        out = run_steps(k)
-        sync_dev()
-        if use_dist:
-            dist.barrier()
-        dt = time.perf_counter() - t0
+        # the interpreter's cyclic collector is run BEFORE the region and held off inside it: a full collection of this process (tens
+        # of thousands of tracked objects after the imports) takes ~35 ms and otherwise lands in whichever region the allocation count
+        # happens to cross its threshold in (tools/exp_cfg4_steps.py: one 38.8 ms step among 160 of 3.2 ms)
+        import gc
+        gc.collect()
+        gc.disable()
+        try:
+            sync_dev()
+            if use_dist:
+                dist.barrier()
+            t0 = time.perf_counter()
+            out = run_steps(k)
+            sync_dev()
+            if use_dist:
+                dist.barrier()
+            dt = time.perf_counter() - t0
+        finally:
+            gc.enable()
         if use_dist:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
