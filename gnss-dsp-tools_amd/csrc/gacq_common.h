@@ -90,6 +90,16 @@ struct gacq_ctx {
   // last grid uploaded to freq/fset/items (skip the H2D + sync when a call repeats it, as batched loops do)
   std::vector<double> up_freq;
   std::vector<int> up_fset, up_items, up_d0;
+  // ... and the grids before it, with their device buffers: callers that alternate between a few grids -- several signals per step
+  // (BASELINE configs 4 and 5), a rank's Doppler slice and the full grid of the tie-safe merge -- find theirs again instead of paying
+  // an upload and a stream synchronisation per call (round 4; most recently displaced first, at most kGridSlots)
+  struct GridSlot {
+    std::vector<double> freq;
+    std::vector<int> fset, items;
+    gacq::DevBuf dfreq, dfset, ditems;
+  };
+  static constexpr int kGridSlots = 7;
+  std::vector<GridSlot> grid_slots;
   std::vector<float> up_taps;
   // correlator calls repeat their (code, PRN list) every millisecond: the device chip-table pointers of the last call are kept
   std::string tr_code;

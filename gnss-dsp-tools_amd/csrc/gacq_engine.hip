@@ -525,6 +525,7 @@ void gacq_destroy(gacq_ctx* ctx) {
   if (ctx->pin_peaks.p) (void)hipHostFree(ctx->pin_peaks.p);
   if (ctx->bar_x.p) (void)hipFree(ctx->bar_x.p);
   if (ctx->bar_s.p) (void)hipFree(ctx->bar_s.p);
+  for (auto& sl : ctx->grid_slots) for (DevBuf* b : {&sl.dfreq, &sl.dfset, &sl.ditems}) if (b->p) (void)hipFree(b->p);
   for (auto& kv : ctx->tables) if (kv.second.p) (void)hipFree(kv.second.p);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -795,6 +796,29 @@ int upload_grid(gacq_sig* sig, int nepoch, const int* items, int nitems, const d
     return set_error(ctx, GACQ_ERR_UNSUPPORTED, "%d epochs x %d items x %d Doppler bins exceeds the 2^31 rows one call can index", nepoch, P, D);
   if (!nco_range_ok(max_f, N))
     return set_error(ctx, GACQ_ERR_UNSUPPORTED, "NCO frequency %.3g cycles/sample x %d samples exceeds the 32-bit phase-index range", max_f, N);
+  const std::vector<int> items_key(items, items + P);
+  if (!(g.freq == ctx->up_freq && g.fset == ctx->up_fset && items_key == ctx->up_items)) {
+    // not the current grid: one of the earlier ones?  Its device buffers trade places with the current ones -- no upload, no
+    // synchronisation; kernels still in flight keep reading the buffers they were given (nothing is freed or rewritten here)
+    auto swap_in = [&](gacq_ctx::GridSlot& sl) {
+      std::swap(sl.freq, ctx->up_freq); std::swap(sl.fset, ctx->up_fset); std::swap(sl.items, ctx->up_items);
+      std::swap(sl.dfreq, ctx->freq); std::swap(sl.dfset, ctx->fset); std::swap(sl.ditems, ctx->items);
+    };
+    size_t hit = ctx->grid_slots.size();
+    for (size_t k = 0; k < ctx->grid_slots.size(); k++)
+      if (ctx->grid_slots[k].freq == g.freq && ctx->grid_slots[k].fset == g.fset && ctx->grid_slots[k].items == items_key) { hit = k; break; }
+    if (hit < ctx->grid_slots.size()) {
+      swap_in(ctx->grid_slots[hit]);
+      std::rotate(ctx->grid_slots.begin(), ctx->grid_slots.begin() + hit, ctx->grid_slots.begin() + hit + 1);      // the displaced grid: most recent
+    } else if (!ctx->up_freq.empty()) {
+      // a new grid: the current one moves into the slots (the oldest slot's buffers are recycled for the upload below, which is
+      // ordered behind every kernel that may still read them: same stream)
+      if ((int)ctx->grid_slots.size() < gacq_ctx::kGridSlots) ctx->grid_slots.emplace(ctx->grid_slots.begin());
+      else std::rotate(ctx->grid_slots.begin(), ctx->grid_slots.end() - 1, ctx->grid_slots.end());
+      swap_in(ctx->grid_slots.front());
+      ctx->up_freq.clear();            // whatever came back (empty, or the oldest grid) is about to be overwritten
+    }
+  }
   const void* before[3] = {ctx->freq.p, ctx->fset.p, ctx->items.p};
   if ((rc = ensure(ctx, ctx->freq, sizeof(double) * g.freq.size())) != GACQ_OK) return rc;
   if ((rc = ensure(ctx, ctx->fset, sizeof(int) * P)) != GACQ_OK) return rc;

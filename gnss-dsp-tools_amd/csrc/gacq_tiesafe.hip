@@ -525,8 +525,11 @@ int tie_lists(gacq_ctx* ctx, long nep, TieLists* out, gacq_peak** guesses) {
     int rc = ensure(ctx, ctx->tie, bytes);
     if (rc != GACQ_OK) return rc;
     keep.nrows = keep.neps = 0;
-    GACQ_HIP(ctx, hipMemset(ctx->tie.p, 0, ctx->tie.cap));             // the per-row arrival counters start (and are left) at zero
-    GACQ_HIP(ctx, hipMemcpy(ctx->tie.p, &keep, sizeof keep, hipMemcpyHostToDevice));
+    // on the ctx stream (a non-blocking stream is not ordered against the null stream a plain hipMemset runs on), then waited for:
+    // `keep` lives on this frame
+    GACQ_HIP(ctx, hipMemsetAsync(ctx->tie.p, 0, ctx->tie.cap, ctx->stream));      // the per-row arrival counters start (and are left) at zero
+    GACQ_HIP(ctx, hipMemcpyAsync(ctx->tie.p, &keep, sizeof keep, hipMemcpyHostToDevice, ctx->stream));
+    GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->tie_cap = cap;
   }
   // the lists are always laid out for the allocated capacity; a smaller request only lowers the fill limit
