@@ -160,7 +160,7 @@ class Engine:
     def stream_probe(self, kind, nbytes=2 << 30, reps=10):
         """gacq_stream_probe: GB/s a tuned streaming kernel reaches on this device; kind "fill", "read" or "copy" (read + write bytes)."""
         v = ctypes.c_double()
-        nat.check(nat.lib.gacq_stream_probe(self._ctx, {"fill": 0, "read": 1, "copy": 2}[kind], int(nbytes), int(reps), ctypes.byref(v)), self._ctx)
+        nat.check(nat.lib.gacq_stream_probe(self._ctx, {"fill": 0, "read": 1, "copy": 2, "fill_read": 3, "fill_plain": 4, "read_plain": 5, "fill_read_plain": 6}[kind], int(nbytes), int(reps), ctypes.byref(v)), self._ctx)
         return v.value
 
     def set_profiling(self, on):

@@ -12,21 +12,26 @@ namespace {
 typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int kU = 8;
 
+template <bool NT = true>
 __global__ __launch_bounds__(256) void stream_fill_kernel(f4* __restrict__ p, size_t ntiles, float v) {
   for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     f4* dst = p + tile * (256 * kU) + threadIdx.x;
 #pragma unroll
-    for (int u = 0; u < kU; u++) __builtin_nontemporal_store(f4{v, v, v, v}, dst + 256 * u);
+    for (int u = 0; u < kU; u++) {
+      if (NT) __builtin_nontemporal_store(f4{v, v, v, v}, dst + 256 * u);
+      else dst[256 * u] = f4{v, v, v, v};
+    }
   }
 }
 
+template <bool NT = true>
 __global__ __launch_bounds__(256) void stream_read_kernel(const f4* __restrict__ p, size_t ntiles, float* __restrict__ sink) {
   f4 acc = {0.f, 0.f, 0.f, 0.f};
   for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const f4* src = p + tile * (256 * kU) + threadIdx.x;
     f4 v[kU];
 #pragma unroll
-    for (int u = 0; u < kU; u++) v[u] = __builtin_nontemporal_load(src + 256 * u);
+    for (int u = 0; u < kU; u++) v[u] = NT ? __builtin_nontemporal_load(src + 256 * u) : src[256 * u];
 #pragma unroll
     for (int u = 0; u < kU; u++) acc += v[u];
   }
@@ -48,8 +53,10 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(const f4* __restrict__
 }  // namespace
 
 extern "C" int gacq_stream_probe(gacq_ctx* ctx, int kind, size_t bytes, int reps, double* gbytes_per_s) {
-  if (!ctx || !gbytes_per_s || kind < 0 || kind > 2 || reps <= 0 || reps > 1000 || bytes < ((size_t)1 << 20) || bytes > ((size_t)16 << 30))
-    return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_stream_probe: kind 0..2, 1 MiB <= bytes <= 16 GiB, 1 <= reps <= 1000");
+  const bool plain = kind >= 4;          // 4..6: kinds 0, 1, 3 with default-policy accesses instead of non-temporal ones
+  if (plain) kind = kind > 6 ? -1 : (kind == 6 ? 3 : kind - 4);
+  if (!ctx || !gbytes_per_s || kind < 0 || kind > 3 || reps <= 0 || reps > 1000 || bytes < ((size_t)1 << 20) || bytes > ((size_t)16 << 30))
+    return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_stream_probe: kind 0..3, 1 MiB <= bytes <= 16 GiB, 1 <= reps <= 1000");
   GACQ_DEVICE(ctx);
   const size_t tile_bytes = (size_t)256 * kU * 16;
   const size_t ntiles = bytes / tile_bytes;
@@ -75,18 +82,25 @@ extern "C" int gacq_stream_probe(gacq_ctx* ctx, int kind, size_t bytes, int reps
   const dim3 grid((unsigned)std::min<size_t>(ntiles, (size_t)cus * 8)), block(256);
   hipStream_t st = ctx->stream;
   auto launch = [&]() {
-    if (kind == 0) hipLaunchKernelGGL(stream_fill_kernel, grid, block, 0, st, (f4*)a, ntiles, 1.0f);
-    else if (kind == 1) hipLaunchKernelGGL(stream_read_kernel, grid, block, 0, st, (const f4*)a, ntiles, sink);
-    else hipLaunchKernelGGL(stream_copy_kernel, grid, block, 0, st, (const f4*)a, (f4*)b, ntiles);
+    if (kind == 3 || kind == 0) {      // 3: write then read back -- what a consumer gets of data a producer has just written
+      if (plain) hipLaunchKernelGGL(stream_fill_kernel<false>, grid, block, 0, st, (f4*)a, ntiles, 1.0f);
+      else hipLaunchKernelGGL(stream_fill_kernel<true>, grid, block, 0, st, (f4*)a, ntiles, 1.0f);
+    }
+    if (kind == 3 || kind == 1) {
+      if (plain) hipLaunchKernelGGL(stream_read_kernel<false>, grid, block, 0, st, (const f4*)a, ntiles, sink);
+      else hipLaunchKernelGGL(stream_read_kernel<true>, grid, block, 0, st, (const f4*)a, ntiles, sink);
+    }
+    if (kind <= 1 || kind == 3) return;
+    hipLaunchKernelGGL(stream_copy_kernel, grid, block, 0, st, (const f4*)a, (f4*)b, ntiles);
   };
-  hipLaunchKernelGGL(stream_fill_kernel, grid, block, 0, st, (f4*)a, ntiles, 1.0f);      // defined contents for the read / copy probes
+  hipLaunchKernelGGL(stream_fill_kernel<true>, grid, block, 0, st, (f4*)a, ntiles, 1.0f);      // defined contents for the read / copy probes
   for (int w = 0; w < 2; w++) launch();
   if (hipEventRecord(e0, st) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "gacq_stream_probe: event record failed");
   for (int r = 0; r < reps && rc == GACQ_OK; r++) launch();
   float ms = 0.f;
   if (rc == GACQ_OK && (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || hipGetLastError() != hipSuccess))
     rc = set_error(ctx, GACQ_ERR_HIP, "gacq_stream_probe: timing failed");
-  if (rc == GACQ_OK) *gbytes_per_s = (kind == 2 ? 2.0 : 1.0) * (double)(ntiles * tile_bytes) * reps / ((double)ms * 1e-3) / 1e9;
+  if (rc == GACQ_OK) *gbytes_per_s = (kind >= 2 ? 2.0 : 1.0) * (double)(ntiles * tile_bytes) * reps / ((double)ms * 1e-3) / 1e9;
   cleanup();
   return rc;
 }

@@ -296,7 +296,7 @@ int gacq_reset_stage_times(gacq_ctx* ctx);
 const char* gacq_stage_name(int stage);
 
 /* What this device's HBM delivers to a tuned streaming kernel (eight 16-byte non-temporal accesses in flight per lane): kind 0 = fill
- * (stores), 1 = read, 2 = copy (read + write bytes counted); `bytes` per launch, `reps` timed launches after two warm-up launches,
+ * (stores), 1 = read, 2 = copy (read + write bytes counted), 3 = fill followed by a read of the same buffer (both counted), 4 / 5 / 6 = kinds 0 / 1 / 3 with default-policy instead of non-temporal accesses; `bytes` per launch, `reps` timed launches after two warm-up launches,
  * HIP events on the ctx stream.  The yardstick bench.py holds the HBM-bound kernels against next to the 8 TB/s of the data sheet
  * (roofline.stream_ceiling), measured in the run that reports it.  Synchronous; allocates and frees its own buffers. */
 int gacq_stream_probe(gacq_ctx* ctx, int kind, size_t bytes, int reps, double* gbytes_per_s);

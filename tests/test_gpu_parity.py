@@ -552,6 +552,38 @@ def test_bench_measures_hbm_traffic_live_with_pmc_child_runs():
             assert sc["measured_in_this_run"] is True and 2000.0 < sc["GBps"] < 8000.0 and (sc.get("exceeded_by_kernel") or 0.0 < sc["frac"] <= 1.0), sc
 
 
+def test_alternating_between_more_grids_than_the_cache_holds(engine):
+    """The context keeps the device buffers of the last eight (frequency grid, item list) pairs, so that callers alternating between a few
+    grids -- several signals per step, a rank's slice and the full grid of the tie-safe merge -- pay no upload / synchronisation per call.
+    Ten different grids in rotation (more than the cache holds: hits, swaps and evictions all occur), three rounds, asynchronously on one
+    stream: every result equals the one a fresh context computes for that grid alone."""
+    import torch
+    from gnss_dsp_tools_amd import acquire, signals, synth
+    sig = signals.get("gps-l1")
+    xs = synth.make_epochs(sig, 1, 4711, synth.default_sats([3, 11, 19, 28]), 2, nsamp=4096)
+    xd = torch.from_numpy(xs).cuda()
+    grids = [(list(range(1 + k, 9 + k)), acquire.doppler_grid([-2000.0 + 100.0 * k, 2000.0, 250.0 + 10.0 * k])) for k in range(10)]
+    want = []
+    for items, dop in grids:
+        e = acquire.Engine(0)
+        try:
+            e.use_torch_stream()
+            r = e.search_batch_dev(sig, xd, items, dop, 1)
+            torch.cuda.synchronize()
+            want.append(r.cpu().numpy().tobytes())
+        finally:
+            e.close()
+    engine.use_torch_stream()
+    outs = []
+    for rnd in range(3):
+        order = range(10) if rnd != 1 else [3, 3, 9, 0, 5, 1, 8, 2, 7, 4, 6, 0]
+        for k in order:
+            outs.append((k, engine.search_batch_dev(sig, xd, grids[k][0], grids[k][1], 1)))      # no synchronisation in between
+    torch.cuda.synchronize()
+    for k, r in outs:
+        assert r.cpu().numpy().tobytes() == want[k], k
+
+
 def test_stream_probe_measures_plausible_hbm_rates(engine):
     """gacq_stream_probe: a tuned fill / read / copy kernel on this device (what bench.py holds the HBM-bound kernels against): between a
     quarter of and the full 8 TB/s of the data sheet, read >= fill (stores are the slower direction on this part), and bad arguments rejected."""

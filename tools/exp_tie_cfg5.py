@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Each signal of BASELINE config 5 searched alone, tie-safe locations on and then off on the same engine (third repetition timed, search +
+synchronise): shows which signal of the synthetic workload has ambiguous pairs and what their complex128 re-evaluation costs."""
 import sys, time, json
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import torch, numpy as np
 import bench
 from gnss_dsp_tools_amd import acquire
