@@ -359,6 +359,29 @@ def test_c_abi_rejects_bad_arguments_with_codes_not_crashes(engine):
     assert call(dp=np.array([1e30, 0.0, 1.0])) < 0
     assert call(dp=np.array([0.0, float("nan"), 1.0])) < 0
     assert call(dp=np.array([0.0, float("inf"), 1.0])) < 0
+    # round-4 entry points: NULL device pointers, bad kinds and counts come back as codes as well
+    import torch
+    xd = torch.from_numpy(x).cuda()
+    q = np.zeros(4)
+    ph = np.zeros(4)
+    ip, dp_ = items.ctypes.data_as(nat.c_int_p), dop.ctypes.data_as(nat.c_double_p)
+    assert lib.gacq_longcode_search_dev(engine._ctx, None, 4096, 4.096e6, b"gps.l2cl", 1, 0.0, ph.ctypes.data_as(nat.c_double_p), 4, 1, 4096,
+                                        q.ctypes.data_as(nat.c_double_p)) < 0
+    assert lib.gacq_longcode_search_dev(engine._ctx, ctypes.c_void_p(xd.data_ptr()), 4096, 4.096e6, b"gps.nope", 1, 0.0,
+                                        ph.ctypes.data_as(nat.c_double_p), 4, 1, 4096, q.ctypes.data_as(nat.c_double_p)) < 0
+    assert lib.gacq_correlate_batch_dev(engine._ctx, None, 4096, b"gps.ca", 0, ip, dp_, dp_, dp_, 3, q.ctypes.data_as(nat.c_double_p)) < 0
+    assert lib.gacq_correlate_batch_dev(engine._ctx, ctypes.c_void_p(xd.data_ptr()), 4096, b"gps.ca", 9, ip, dp_, dp_, dp_, 3,
+                                        q.ctypes.data_as(nat.c_double_p)) < 0
+    assert lib.gacq_mix_int8_dev(engine._ctx, None, 4096, 4.096e6, 0.0, ctypes.c_void_p(xd.data_ptr())) < 0
+    pk = torch.zeros((2, 1, 3, 2), dtype=torch.float64, device="cuda")
+    d0 = np.array([0, 2], dtype=np.int32)
+    args = (s._h, ctypes.c_void_p(xd.data_ptr()), 4096, 1, ip, 3, dp_, 3, None, 1)
+    assert lib.gacq_merge_peaks_tiesafe_dev(*args, None, 2, d0.ctypes.data_as(nat.c_int_p), ctypes.c_void_p(pk[0].data_ptr())) < 0
+    assert lib.gacq_merge_peaks_tiesafe_dev(*args, ctypes.c_void_p(pk.data_ptr()), 0, d0.ctypes.data_as(nat.c_int_p), ctypes.c_void_p(pk[0].data_ptr())) < 0
+    assert lib.gacq_merge_peaks_tiesafe_dev(*args, ctypes.c_void_p(pk.data_ptr()), 2, d0.ctypes.data_as(nat.c_int_p), ctypes.c_void_p(pk[0].data_ptr())) == 0
+    v = ctypes.c_double()
+    assert lib.gacq_stream_probe(engine._ctx, 9, 1 << 24, 2, ctypes.byref(v)) < 0 and lib.gacq_stream_probe(engine._ctx, 0, 1 << 24, 0, ctypes.byref(v)) < 0
+    assert lib.gacq_get_tie_stats(engine._ctx, None) < 0 and lib.gacq_get_tie_stats(None, (ctypes.c_longlong * 4)()) < 0
     # the context still works and returns the same answer
     assert call() == 0
     assert [(r.metric, r.code_chips, r.doppler_hz) for r in res] == good
