@@ -585,25 +585,31 @@ int tie_resolve(gacq_sig* sig, const TieLists& tl, const gacq_peak* guesses, con
     wt = ctx->tables.emplace(key, b).first;
   }
   const double2* WN = (const double2*)wt->second.p;
+  const int Rs = (N == 4 * gacq::f64::kN) ? 4 : ((N == 16 * gacq::f64::kN) ? 16 : 0);
+  const size_t split_bytes = (size_t)tl.cap * B * ((size_t)N * (sizeof(double) + sizeof(double2)) + 64);
   // B > 1: the blocks of a listed row are evaluated side by side by B workgroups when their per-block magnitude rows
   // (capacity x B x N fp64 values) fit into 256 MiB; otherwise one workgroup takes the row's blocks in sequence (same bits)
   double* qb = nullptr;
   const size_t qb_bytes = (size_t)tl.cap * B * N * sizeof(double);
-  if (B > 1 && qb_bytes <= ((size_t)256 << 20)) {
+  if (B > 1 && qb_bytes <= ((size_t)256 << 20) && !(Rs && split_bytes <= ((size_t)768 << 20))) {
     if ((rc = ensure(ctx, ctx->tie_q, qb_bytes)) != GACQ_OK) return rc;
     qb = (double*)ctx->tie_q.p;
+    // the per-row arrival counters are left at zero by the kernel; cleared per launch all the same (see above)
+    GACQ_HIP(ctx, hipMemsetAsync(tl.done, 0, sizeof(unsigned) * (size_t)tl.cap, ctx->stream));
   }
-  const int Rs = (N == 4 * gacq::f64::kN) ? 4 : ((N == 16 * gacq::f64::kN) ? 16 : 0);
-  const size_t split_bytes = (size_t)tl.cap * B * ((size_t)N * (sizeof(double) + sizeof(double2)) + 64);
   if (Rs && split_bytes <= ((size_t)768 << 20)) {
-    // [per-(row, block) arrival counters | per-block magnitude rows | twiddled inner transforms]
-    const size_t cnt_bytes = (((size_t)tl.cap * B * sizeof(unsigned)) + 255) & ~(size_t)255;
+    // per-(row, block) arrival counters in a buffer of their own (inside the data buffer their place would move with the capacity
+    // and land on stale row data).  The kernels leave them at zero; they are cleared per launch all the same (a few KB): a faulted
+    // or aborted launch must not leave the next one waiting on stale counts
+    const size_t cnt_bytes = (size_t)tl.cap * B * sizeof(unsigned);
+    if ((rc = ensure(ctx, ctx->tie_done2, cnt_bytes)) != GACQ_OK) return rc;
+    GACQ_HIP(ctx, hipMemsetAsync(ctx->tie_done2.p, 0, cnt_bytes, ctx->stream));
+    GACQ_HIP(ctx, hipMemsetAsync(tl.done, 0, sizeof(unsigned) * (size_t)tl.cap, ctx->stream));
+    // [per-block magnitude rows | twiddled inner transforms]
     const size_t q_bytes = (size_t)tl.cap * B * N * sizeof(double);
-    const bool fresh = ctx->tie_split.cap < split_bytes + cnt_bytes;
-    if ((rc = ensure(ctx, ctx->tie_split, split_bytes + cnt_bytes)) != GACQ_OK) return rc;
-    if (fresh) GACQ_HIP(ctx, hipMemsetAsync(ctx->tie_split.p, 0, cnt_bytes, ctx->stream));      // the kernels leave the counters at zero
-    unsigned* done2 = (unsigned*)ctx->tie_split.p;
-    double* q2 = (double*)((char*)ctx->tie_split.p + cnt_bytes);
+    if ((rc = ensure(ctx, ctx->tie_split, split_bytes)) != GACQ_OK) return rc;
+    unsigned* done2 = (unsigned*)ctx->tie_done2.p;
+    double* q2 = (double*)ctx->tie_split.p;
     double2* zs = (double2*)((char*)q2 + q_bytes);
     auto kern = Rs == 4 ? tie_recheck_split_kernel<4> : tie_recheck_split_kernel<16>;
     GACQ_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, gacq::f64::kLdsBytes));

@@ -169,6 +169,34 @@ def test_doppler_slices_and_device_groups_merge_to_the_unsliced_records(fresh, n
     assert res == want
 
 
+def test_reevaluation_buffers_survive_changing_capacities(fresh):
+    """One context, searches whose re-evaluation lists have different capacities and block counts in turn (the scratch rows, per-block
+    magnitude rows and arrival counters are laid out per call): every row re-evaluated (eps = 1) on the split-LDS kernel (N = 16384, 65536),
+    the LDS kernel (4096, B > 1) and the generic kernel (61380), small call, larger call, small call again -- always engine 5's answer."""
+    import torch
+    from gnss_dsp_tools_amd import acquire, signals, synth
+    fresh.use_torch_stream()
+    fresh.set_option("tie_eps_ppb", 1000000000)
+    plan = [("beidou-b1i", [1, 2], [-500.0, 500.0, 250.0], 2, 1), ("beidou-b1i", list(range(1, 9)), [-1000.0, 1000.0, 250.0], 3, 2),
+            ("galileo-e1b", [4, 5, 6], [0.0, 500.0, 125.0], 1, 1), ("beidou-b1i", [1, 2], [-500.0, 500.0, 250.0], 2, 1),
+            ("gps-l1", [1, 2, 3], [-1000.0, 1000.0, 250.0], 3, 2), ("gps-l1", list(range(1, 17)), [-1000.0, 1000.0, 250.0], 2, 3),
+            ("gps-l5i", [1, 2], [0.0, 400.0, 200.0], 1, 1), ("glonass-l1", [-1, 0, 3], [-500.0, 500.0, 250.0], 2, 2)]
+    for name, items, ds, B, E in plan:
+        sig = signals.get(name)
+        dop = acquire.doppler_grid(ds)
+        xs = synth.make_epochs(sig, B, 606, synth.default_sats(items), E, nsamp=sig.samples_needed(B))
+        xd = torch.from_numpy(xs).cuda()
+        fresh.set_option("tie_cap", E * len(items) * len(dop))
+        fresh.set_engine(0)
+        got = _peaks(fresh.search_batch_dev(sig, xd, items, dop, B))
+        fresh.set_engine(5)
+        ref = _peaks(fresh.search_batch_dev(sig, xd, items, dop, B))
+        np.testing.assert_array_equal(got["idx"], ref["idx"], err_msg=name)
+        np.testing.assert_array_equal(got["d_index"], ref["d_index"])
+        np.testing.assert_allclose(got["metric"], ref["metric"], rtol=1e-10)
+    assert fresh.tie_stats()["kept_fp32"] == 0
+
+
 def test_option_ranges_are_validated(fresh):
     """gacq_set_option rejects values outside an option's range instead of storing them."""
     from gnss_dsp_tools_amd import _native as nat
