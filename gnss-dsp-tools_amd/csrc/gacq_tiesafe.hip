@@ -344,8 +344,9 @@ __global__ __launch_bounds__(256, 1) void tie_recheck4k_kernel(TieLists tl, unsi
 // included), transforms it, multiplies by conj(C_p[k1 + R k2]), transforms again (|ifft(Y)| = |fft(conj Y)| / N; the second
 // transform decimates in time, so its inner transforms run over the same k1 rows) and stores W_N^{k1 n2} T_k1[n2]; the last of the
 // R workgroups of a (row, block) to arrive does the outer DFT-R and the magnitudes, the last block of a row the ordered sum and
-// the reduction.  Two global round trips per block instead of ten Stockham passes, R-fold parallel: ~25 us per listed row where
-// the generic kernel needs ~150 us per block.
+// the reduction.  Two global round trips per block instead of ten Stockham passes, R-fold parallel.  Measured: two GLONASS rows of ten
+// blocks (80 work items) in 0.18 ms on an otherwise idle chip (profiles/r04_tie_recheck_kernel_times.log); four dependent phases of
+// complex128 work at idle clocks plus two agent-scope hand-overs per row are what is left.
 template <int R>
 __global__ __launch_bounds__(256, 1) void tie_recheck_split_kernel(TieLists tl, unsigned* __restrict__ done, unsigned* __restrict__ done2,
                                                                    double* __restrict__ qb, double2* __restrict__ zs,
