@@ -29,6 +29,11 @@ def one_round(i):
         xs = synth.make_epochs(sig, B, 100 + i, synth.default_sats(items), 3, nsamp=sig.samples_needed(B))
         eng = acquire.Engine(0, workspace_bytes=(1 << 20) if i % 3 == 0 else None)
         try:
+            if i % 2 == 0:
+                # tie-safe re-evaluation buffers (lists, complex128 spectra, row scratch, per-block rows, counters) come and go with the
+                # context too: eps = 2e-2 makes many pairs ambiguous, every fifth round re-evaluates every row
+                eng.set_option("tie_eps_ppb", 1000000000 if i % 10 == 0 else 20000000)
+                eng.set_option("tie_cap", 4096)
             eng.search_all(sig, xs[0], items, ds, ms)
             eng.search_batch_host(sig, xs, items, acquire.doppler_grid(ds), B)
             if i % 4 == 0:
