@@ -670,6 +670,7 @@ def make_timed(run_steps, dev, use_dist):
         gc.collect()
         gc.disable()
         try:
+            run_steps(8)                 # untimed: the collection above idled the GPU for tens of ms, long enough for its clocks to drop
             sync_dev()
             if use_dist:
                 dist.barrier()
