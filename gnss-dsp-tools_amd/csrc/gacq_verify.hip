@@ -198,7 +198,8 @@ __global__ __launch_bounds__(kBlock, 2) void fused4k_c128_kernel(const float2* _
       r.peak = peak; r.sum = sum; r.idx = idx; r.pad = 0;
       rows[(e * P + p) * (long)D + d] = r;
     }
-    __syncthreads();      // the reduction scratch is rewritten by the next item
+    // no barrier here: the scratch is rewritten only after the next item's transform, whose first exchange barrier thread 0 reaches
+    // after it has finished reading it
   }
 }
 
