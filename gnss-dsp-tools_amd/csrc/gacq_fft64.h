@@ -132,6 +132,17 @@ __device__ __forceinline__ void make_powers(cd (&pw)[15], cd w1) {
 // values).  lds: kLdsBytes.  The caller puts a barrier between two transforms that use the same LDS buffer.
 // TAB2: the pass-2 powers (already conjugated for INV) come from an LDS table laid out [k - 1][lane class], tb2 already
 // offset by the lane's class t & 15 -- one 16-byte read per product instead of 14 complex products per row to rebuild them.
+// One LDS read per instruction where the including unit asks for it (#define GACQ_F64_UNPAIR before the include): paired into
+// ds_read2st64_b64 by the compiler the reads run at half rate (MI355X guide, LDS table; GACQ_UNPAIR in gacq_cplx.h).  Same-box A/B on the
+// fused search kernel: 13.80 -> 13.60 ms per 1024-epoch step; unpairing the writes as well costs 3 %.  NOT for the re-evaluation
+// kernels of gacq_tiesafe.hip: they live on 256 VGPRs + 256 AGPRs + scratch, and with the separators in place this toolchain's
+// VGPR-to-AGPR spilling produced wrong rows in tie_recheck4k_kernel (right again with -mllvm -amdgpu-spill-vgpr-to-agpr=0 or with two
+// workgroups per CU, i.e. no AGPR spills) -- their speed does not matter, so they keep the compiler's pairing.
+#if defined(GACQ_F64_UNPAIR) && !defined(GACQ_LDS_PAIRED)
+#define F64_UR() asm volatile("" ::: "memory")
+#else
+#define F64_UR() do {} while (0)
+#endif
 template <bool INV, bool TAB2 = false>
 __device__ __forceinline__ void fft4096(cd (&v)[16], double* lds, cd wa, cd wb, int t, const cd* tb2 = nullptr) {
   double* lre = lds;
@@ -145,7 +156,7 @@ __device__ __forceinline__ void fft4096(cd (&v)[16], double* lds, cd wa, cd wb, 
     for (int k = 0; k < 16; k++) { lre[wbase + 16 * k] = v[rev16(k)].x; lim[wbase + 16 * k] = v[rev16(k)].y; }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 16; j++) { v[j].x = lre[t + 256 * j]; v[j].y = lim[t + 256 * j]; }
+    for (int j = 0; j < 16; j++) { v[j].x = lre[t + 256 * j]; F64_UR(); v[j].y = lim[t + 256 * j]; F64_UR(); }
   }
   dft16<INV>(v);
   if (TAB2) {
@@ -161,7 +172,7 @@ __device__ __forceinline__ void fft4096(cd (&v)[16], double* lds, cd wa, cd wb, 
     for (int k = 0; k < 16; k++) { lre[wbase + 16 * k] = v[rev16(k)].x; lim[wbase + 16 * k] = v[rev16(k)].y; }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 16; j++) { v[j].x = lre[t + kPitch * j]; v[j].y = lim[t + kPitch * j]; }
+    for (int j = 0; j < 16; j++) { v[j].x = lre[t + kPitch * j]; F64_UR(); v[j].y = lim[t + kPitch * j]; F64_UR(); }
   }
   dft16<INV>(v);
 }

@@ -97,6 +97,9 @@ __device__ __forceinline__ void wave_first_max(const float (&m)[kR], unsigned ba
 
 // Length-4096 transform of the 16 values per lane. In: v[j] = x[t + 256 j]; out: v[rev16(k2)] = X[t + 256 k2].
 // wa = W_4096^t, wb = W_256^(t & 15) (forward values; conjugated here when INV).
+__device__ __forceinline__ v2 lds_ld1(const v2& x) { const v2 r = x; GACQ_UNPAIR(); return r; }
+#define LDS_LD(x) lds_ld1(x)
+#define LDS_ST1(dst, val) do { (dst) = (val); GACQ_UNPAIR(); } while (0)
 // PRE: bit 0 = the pass-1 powers (W_4096^t)^k, bit 1 = the pass-2 powers (W_256^(t&15))^k come precomputed in *pa / *pb (already
 // conjugated for an inverse transform) instead of being rebuilt from wa / wb by 14 complex products per pass.
 // bit 2 = the pass-2 powers are read from an LDS table (tb2[16 (k - 1)], tb2 already offset by the lane's class t & 15).
@@ -114,12 +117,12 @@ __device__ __forceinline__ void fft4096(v2 (&v)[kR], v2* lds, v2 wa, v2 wb, cons
     for (int k = 0; k < kR; k++) lds[wbase + 16 * k] = v[rev16(k)];
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < kR; j++) v[j] = lds[t + 256 * j];
+    for (int j = 0; j < kR; j++) v[j] = LDS_LD(lds[t + 256 * j]);
   }
   dft16<INV>(v);
   if (PRE & 4) {
 #pragma unroll
-    for (int k = 1; k < kR; k++) v[rev16(k)] = cmul(v[rev16(k)], tb2[16 * (k - 1)]);
+    for (int k = 1; k < kR; k++) v[rev16(k)] = cmul(v[rev16(k)], LDS_LD(tb2[16 * (k - 1)]));
   } else if (PRE & 2) apply_table(v, *pb);
   else apply_powers(v, wb);
   __syncthreads();   // all exchange-1 reads done before the buffer is reused
@@ -129,7 +132,7 @@ __device__ __forceinline__ void fft4096(v2 (&v)[kR], v2* lds, v2 wa, v2 wb, cons
     for (int k = 0; k < kR; k++) lds[wbase + 16 * k] = v[rev16(k)];
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < kR; j++) v[j] = lds[t + kPitch * j];
+    for (int j = 0; j < kR; j++) v[j] = LDS_LD(lds[t + kPitch * j]);
   }
   dft16<INV>(v);
 }
@@ -299,26 +302,26 @@ __device__ __forceinline__ void fft16k_fwd(v2 (&v)[kR], v2* lds, const Tw16k& tw
   dft16<false>(v);
   apply_powers(v, tw.w0);
 #pragma unroll
-  for (int ka = 0; ka < kR; ka++) lds[ka * kRegion + t] = v[rev16(ka)];            // exchange 0: output ka -> wave ka
+  for (int ka = 0; ka < kR; ka++) LDS_ST1(lds[ka * kRegion + t], v[rev16(ka)]);           // exchange 0: output ka -> wave ka
   lds_barrier();
   GACQ_SETPRIO(GACQ_QF);
 #pragma unroll
-  for (int j = 0; j < kR; j++) v[j] = reg[l + 64 * j];
+  for (int j = 0; j < kR; j++) v[j] = LDS_LD(reg[l + 64 * j]);
   dft16<false>(v);
   apply_powers(v, tw.w1);
 #pragma unroll
-  for (int k0 = 0; k0 < kR; k0++) reg[66 * k0 + l] = v[rev16(k0)];                 // transpose 1, element (k0, l) at 66 k0 + l
+  for (int k0 = 0; k0 < kR; k0++) LDS_ST1(reg[66 * k0 + l], v[rev16(k0)]);                // transpose 1, element (k0, l) at 66 k0 + l
 #pragma unroll
-  for (int lh = 0; lh < kR; lh++) v[lh] = reg[66 * (l & 15) + (l >> 4) + 4 * lh];  // lane (k0 = l & 15, l_lo = l >> 4)
+  for (int lh = 0; lh < kR; lh++) v[lh] = LDS_LD(reg[66 * (l & 15) + (l >> 4) + 4 * lh]);  // lane (k0 = l & 15, l_lo = l >> 4)
   GACQ_SETPRIO(GACQ_QT1);
   dft16<false>(v);
   apply_powers(v, tw.w2);
 #pragma unroll
-  for (int k1 = 0; k1 < kR; k1++) reg[256 * (l >> 4) + (l & 15) + 16 * k1] = v[rev16(k1)];   // transpose 2, (k0, l_lo, k1) at 256 l_lo + 16 k1 + k0
+  for (int k1 = 0; k1 < kR; k1++) LDS_ST1(reg[256 * (l >> 4) + (l & 15) + 16 * k1], v[rev16(k1)]);   // transpose 2, (k0, l_lo, k1) at 256 l_lo + 16 k1 + k0
 #pragma unroll
   for (int lo = 0; lo < 4; lo++) {
 #pragma unroll
-    for (int kh = 0; kh < 4; kh++) v[kh + 4 * lo] = reg[l + 256 * lo + 64 * kh];     // lane mu = k0 + 16 k1_lo, k1 = k1_lo + 4 kh
+    for (int kh = 0; kh < 4; kh++) v[kh + 4 * lo] = LDS_LD(reg[l + 256 * lo + 64 * kh]);     // lane mu = k0 + 16 k1_lo, k1 = k1_lo + 4 kh
   }
   GACQ_SETPRIO(GACQ_QT2);
 #pragma unroll
@@ -334,28 +337,28 @@ __device__ __forceinline__ void ifft16k_private(v2 (&v)[kR], v2* reg, const Tw16
 #pragma unroll
   for (int lo = 0; lo < 4; lo++) {
 #pragma unroll
-    for (int kh = 0; kh < 4; kh++) reg[64 * (l >> 4) + (l & 15) + 256 * kh + 16 * lo] = v[kh + 4 * lo];   // (k0, l_lo, k1) at 64 k1 + 16 l_lo + k0
+    for (int kh = 0; kh < 4; kh++) LDS_ST1(reg[64 * (l >> 4) + (l & 15) + 256 * kh + 16 * lo], v[kh + 4 * lo]);   // (k0, l_lo, k1) at 64 k1 + 16 l_lo + k0
   }
 #pragma unroll
-  for (int k1 = 0; k1 < kR; k1++) v[k1] = reg[l + 64 * k1];                         // lane (k0 = l & 15, l_lo = l >> 4)
+  for (int k1 = 0; k1 < kR; k1++) v[k1] = LDS_LD(reg[l + 64 * k1]);                         // lane (k0 = l & 15, l_lo = l >> 4)
   GACQ_SETPRIO(GACQ_P3);
   apply_powers_nat(v, tw.w2);
   dft16<true>(v);                                                                   // over k1 -> l_hi
 #pragma unroll
-  for (int lh = 0; lh < kR; lh++) reg[65 * (l & 15) + (l >> 4) + 4 * lh] = v[rev16(lh)];   // element (k0, l = l_lo + 4 l_hi) at 65 k0 + l
+  for (int lh = 0; lh < kR; lh++) LDS_ST1(reg[65 * (l & 15) + (l >> 4) + 4 * lh], v[rev16(lh)]);   // element (k0, l = l_lo + 4 l_hi) at 65 k0 + l
 #pragma unroll
-  for (int k0 = 0; k0 < kR; k0++) v[k0] = reg[l + 65 * k0];
+  for (int k0 = 0; k0 < kR; k0++) v[k0] = LDS_LD(reg[l + 65 * k0]);
   GACQ_SETPRIO(GACQ_P4);
   apply_powers_nat(v, tw.w1);
   dft16<true>(v);                                                                   // over k0 -> j'
 #pragma unroll
-  for (int j = 0; j < kR; j++) reg[l + 64 * j] = v[rev16(j)];
+  for (int j = 0; j < kR; j++) LDS_ST1(reg[l + 64 * j], v[rev16(j)]);
 }
 // cross-wave part: gather the 16 partial transforms of n = t (mod 1024) ...
 __device__ __forceinline__ void ifft16k_gather(v2 (&v)[kR], const v2* lds) {
   const int t = threadIdx.x;
 #pragma unroll
-  for (int ka = 0; ka < kR; ka++) v[ka] = lds[ka * kRegion + t];
+  for (int ka = 0; ka < kR; ka++) v[ka] = LDS_LD(lds[ka * kRegion + t]);
 }
 // ... and combine them: v[rev16(j)] = N y[t + 1024 j]
 __device__ __forceinline__ void ifft16k_final(v2 (&v)[kR], const Tw16k& tw) {

@@ -6,6 +6,7 @@
 // when an fp32 engine and the oracle disagree on a near-tied peak, engine 5 says which side the rounding fell on.  Slow by
 // design (twice the bytes, a quarter of the flops/s); selected only by gacq_set_engine(ctx, 5), never by auto.
 #include "gacq_common.h"
+#define GACQ_F64_UNPAIR 1      // fused4k_c128_kernel: no AGPR spills (244 VGPRs), see gacq_fft64.h
 #include "gacq_fft64.h"
 
 #include <cmath>
