@@ -95,11 +95,14 @@ __device__ __forceinline__ void wave_first_max(const float (&m)[kR], unsigned ba
   }
 }
 
-// Length-4096 transform of the 16 values per lane. In: v[j] = x[t + 256 j]; out: v[rev16(k2)] = X[t + 256 k2].
-// wa = W_4096^t, wb = W_256^(t & 15) (forward values; conjugated here when INV).
+// LDS accesses of the exchanges, one per instruction (GACQ_UNPAIR, gacq_cplx.h): LDS_LD for every read; LDS_ST1 for the writes of the
+// 16384-point transforms (the 4096-point ones are faster with their writes left to the compiler's ds_write2_b64 pairing)
 __device__ __forceinline__ v2 lds_ld1(const v2& x) { const v2 r = x; GACQ_UNPAIR(); return r; }
 #define LDS_LD(x) lds_ld1(x)
 #define LDS_ST1(dst, val) do { (dst) = (val); GACQ_UNPAIR(); } while (0)
+
+// Length-4096 transform of the 16 values per lane. In: v[j] = x[t + 256 j]; out: v[rev16(k2)] = X[t + 256 k2].
+// wa = W_4096^t, wb = W_256^(t & 15) (forward values; conjugated here when INV).
 // PRE: bit 0 = the pass-1 powers (W_4096^t)^k, bit 1 = the pass-2 powers (W_256^(t&15))^k come precomputed in *pa / *pb (already
 // conjugated for an inverse transform) instead of being rebuilt from wa / wb by 14 complex products per pass.
 // bit 2 = the pass-2 powers are read from an LDS table (tb2[16 (k - 1)], tb2 already offset by the lane's class t & 15).
