@@ -246,10 +246,11 @@ __device__ __forceinline__ void fill_pass_twiddles(v2* __restrict__ twp, const f
 }
 
 // One radix-R pass, in place: every thread pulls its butterflies' inputs into registers (one LDS read per instruction, GACQ_UNPAIR in
-// gacq_cplx.h: config 4 3.17 -> 3.09 ms per step), the workgroup synchronises, then the
+// gacq_cplx.h: config 4 3.17 -> 3.09 ms per step; not in the one-Doppler-bin instantiations, which then spill two registers), the
+// workgroup synchronises, then the
 // outputs overwrite the same buffer (autosort order).  One buffer instead of a ping-pong pair keeps the workgroup at
 // 2 M complex of LDS (row + twiddles) so five of them fit a CU.  LAST writes the row to global memory instead.
-template <int R, bool LAST, int M, int NT>
+template <int R, bool LAST, int M, int NT, bool UNPAIR = true>
 __device__ __forceinline__ void stockham_pass(v2* __restrict__ buf, float2* __restrict__ gz, const v2* __restrict__ twp, int Ns, int tid,
                                               bool live GACQ_MARK_ARG) {
   constexpr int nb = M / R;
@@ -262,7 +263,7 @@ __device__ __forceinline__ void stockham_pass(v2* __restrict__ buf, float2* __re
       const int k = j % Ns;
       v2 wv[R];
 #pragma unroll
-      for (int t = 0; t < R; t++) { x[it][t] = buf[j + t * nb]; GACQ_UNPAIR(); if (t) { wv[t] = twp[(t - 1) * Ns + k]; GACQ_UNPAIR(); } }      // conj(W_{Ns R}^{k t})
+      for (int t = 0; t < R; t++) { x[it][t] = buf[j + t * nb]; if (UNPAIR) GACQ_UNPAIR(); if (t) { wv[t] = twp[(t - 1) * Ns + k]; if (UNPAIR) GACQ_UNPAIR(); } }      // conj(W_{Ns R}^{k t})
 #pragma unroll
       for (int t = 1; t < R; t++) x[it][t] = cmul(x[it][t], wv[t]);
       SmallDft<R, true>::run(x[it]);
@@ -383,16 +384,16 @@ __global__ __launch_bounds__(NT * TEAMS, (DT == 1 ? 5 : (DT == 2 && R0 * R1 * R2
       GACQ_MARK(0);                                // (wait for C, X) C conj(X), DFT-R0, LDS writes
       __syncthreads();
       GACQ_MARK(1);
-      stockham_pass<R1, false, M, NT>(buf0, nullptr, tw1, R0, j, live GACQ_MARK_PASS(2));
+      stockham_pass<R1, false, M, NT, (DT > 1)>(buf0, nullptr, tw1, R0, j, live GACQ_MARK_PASS(2));
       GACQ_MARK(4);                                // pass-2 outputs written to LDS
       __syncthreads();
       GACQ_MARK(5);
       if (R3 > 1) {
-        stockham_pass<R2, false, M, NT>(buf0, nullptr, tw2, R0 * R1, j, live GACQ_MARK_PASS(10));
+        stockham_pass<R2, false, M, NT, (DT > 1)>(buf0, nullptr, tw2, R0 * R1, j, live GACQ_MARK_PASS(10));
         __syncthreads();
-        stockham_pass<(R3 > 1 ? R3 : 2), true, M, NT>(buf0, gz, tw3, R0 * R1 * R2, j, live GACQ_MARK_PASS(12));
+        stockham_pass<(R3 > 1 ? R3 : 2), true, M, NT, (DT > 1)>(buf0, gz, tw3, R0 * R1 * R2, j, live GACQ_MARK_PASS(12));
       } else {
-        stockham_pass<R2, true, M, NT>(buf0, gz, tw2, R0 * R1, j, live GACQ_MARK_PASS(6));
+        stockham_pass<R2, true, M, NT, (DT > 1)>(buf0, gz, tw2, R0 * R1, j, live GACQ_MARK_PASS(6));
       }
       GACQ_MARK(8);                                // last pass: row stored to global memory
       __syncthreads();                             // buf0 is rewritten by the next row's first pass
