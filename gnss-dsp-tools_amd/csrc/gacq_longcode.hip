@@ -5,6 +5,7 @@
 // with w the table NCO restarted per block.  x*w does not depend on k, so it is formed once (longcode_mix_kernel) and every
 // candidate is a +-1 weighted sum over it (longcode_dot_kernel, fp64 accumulation, code indices in fp64 like numpy's).
 #include "gacq_common.h"
+#include "gacq_fft64.h"
 
 #include <cmath>
 #include <cstring>
@@ -28,38 +29,61 @@ __global__ __launch_bounds__(kLcBlock) void longcode_mix_kernel(const float2* __
   xw[g] = make_float2(s.x * w.x - s.y * w.y, s.x * w.y + s.y * w.x);
 }
 
-// partial[(k*B + b)*chunks + c] = sum over the chunk's samples of +-xw
-__global__ __launch_bounds__(kLcBlock) void longcode_dot_kernel(const float2* __restrict__ xw, const uint8_t* __restrict__ chips, long L,
+// partial[(k*B + b)*chunks + c] = sum over the chunk's samples of +-xw.  Workgroup = (chunk of 4096 samples, block, group of kc <= kLcKc
+// candidates): a thread keeps its 16 samples (as fp64 pairs) and their incr*i products in registers and runs every candidate of the
+// group over them -- the samples cross L2 once per group instead of once per candidate, the per-sample product is formed once, and the
+// candidates share one barrier.  Per candidate and sample what is left is the index of the reference (floor(ph + incr*i) in fp64, np.mod
+// wrap, gnsstools/gps/l2cl.py:57-61), one byte of code, a sign flip and two fp64 additions; the wave sums run on DPP (gacq_fft64.h).
+// Round 4: GLONASS P (1000 x 5 x 65536) 0.80 -> see profiles/r04_longcode_dot_kernel.log.
+constexpr int kLcKc = 8;
+#ifndef GACQ_LC_MINWG
+#define GACQ_LC_MINWG 1024      // workgroups below which the candidate group is halved (L2CL, 75 candidates: 79.7 us per call at 1024, 84 at 512 or 2048, 93 at 4096)
+#endif
+__global__ __launch_bounds__(kLcBlock) void longcode_dot_kernel(const float2* __restrict__ xw, const uint8_t* __restrict__ chips, int L,
                                                                  const double* __restrict__ phase0, double incr, long n, int B,
-                                                                 int chunks, double2* __restrict__ partial) {
-  __shared__ double s_re[kLcBlock / 64], s_im[kLcBlock / 64];
-  const long blk = blockIdx.x;
-  const int c = (int)(blk % chunks);
-  const long kb = blk / chunks;                   // k*B + b
-  const int b = (int)(kb % B);
-  const double ph = phase0[kb];
+                                                                 int chunks, int K, int kc, double2* __restrict__ partial) {
+  __shared__ double s_re[kLcKc][kLcBlock / 64], s_im[kLcKc][kLcBlock / 64];
+  unsigned blk = blockIdx.x;
+  const int c = (int)(blk % (unsigned)chunks);
+  blk /= (unsigned)chunks;
+  const int b = (int)(blk % (unsigned)B);
+  const int k0 = (int)(blk / (unsigned)B) * kc;
+  const int nk = min(kc, K - k0);
   const float2* src = xw + (long)b * n;
-  double ar = 0.0, ai = 0.0;
   const long i0 = (long)c * kLcChunk + threadIdx.x;
-#pragma unroll 4
+  double vx[kLcPer], vy[kLcPer], prod[kLcPer];
+#pragma unroll
   for (int j = 0; j < kLcPer; j++) {
     const long i = i0 + (long)j * kLcBlock;
-    if (i < n) {
-      // idx = floor((chips % L) + frac + incr*i) mod L, fp64 as numpy does it (gnsstools/gps/l2cl.py:57-61)
-      long idx = (long)floor(ph + __dmul_rn(incr, (double)i));
-      if (idx >= L) { idx -= L; if (idx >= L) idx %= L; }
-      else if (idx < 0) { idx %= L; if (idx < 0) idx += L; }      // np.mod is floored: a negative start phase wraps upwards
-      const float2 v = src[i];
-      if (chips[idx]) { ar -= (double)v.x; ai -= (double)v.y; } else { ar += (double)v.x; ai += (double)v.y; }
-    }
+    const float2 v = (i < n) ? src[i] : make_float2(0.f, 0.f);       // a sample past the block adds +-0
+    vx[j] = (double)v.x;
+    vy[j] = (double)v.y;
+    prod[j] = __dmul_rn(incr, (double)(i < n ? i : 0));
   }
+  for (int kk = 0; kk < nk; kk++) {
+    const double ph = phase0[(long)(k0 + kk) * B + b];
+    double ar = 0.0, ai = 0.0;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { ar += __shfl_down(ar, off); ai += __shfl_down(ai, off); }
-  if ((threadIdx.x & 63) == 0) { s_re[threadIdx.x >> 6] = ar; s_im[threadIdx.x >> 6] = ai; }
+    for (int j = 0; j < kLcPer; j++) {
+      // idx = floor((chips % L) + frac + incr*i) mod L, fp64 as numpy does it; |ph + incr*i| < 2^31 for every code length in the table.
+      // (A branch-free reduction -- conditional -L, conditional +L, rare cases redone -- lets the compiler batch the 16 byte loads, needs
+      // 130+ registers for that and is 12 % slower: 268 against 238 us for the GLONASS P shape.)
+      int idx = (int)floor(ph + prod[j]);
+      if (idx >= L) { idx -= L; if (idx >= L) idx %= L; }
+      else if (idx < 0) { idx %= L; if (idx < 0) idx += L; }          // np.mod is floored: a negative start phase wraps upwards
+      const unsigned long long flip = (unsigned long long)chips[idx] << 63;       // chip 1 -> -x
+      ar += __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, vx[j]) ^ flip);
+      ai += __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, vy[j]) ^ flip);
+    }
+    ar = gacq::f64::wave_add_f64(ar);
+    ai = gacq::f64::wave_add_f64(ai);
+    if ((threadIdx.x & 63) == 0) { s_re[kk][threadIdx.x >> 6] = ar; s_im[kk][threadIdx.x >> 6] = ai; }
+  }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < kLcBlock / 64; w++) { ar += s_re[w]; ai += s_im[w]; }
-    partial[blk] = make_double2(ar, ai);
+  if ((int)threadIdx.x < nk) {
+    double ar = s_re[threadIdx.x][0], ai = s_im[threadIdx.x][0];
+    for (int w = 1; w < kLcBlock / 64; w++) { ar += s_re[threadIdx.x][w]; ai += s_im[threadIdx.x][w]; }
+    partial[((long)(k0 + (int)threadIdx.x) * B + b) * chunks + c] = make_double2(ar, ai);
   }
 }
 
@@ -139,8 +163,13 @@ static int longcode_run(gacq_ctx* ctx, const float* x_iq, const int8_t* iq_int8,
   hipLaunchKernelGGL(longcode_mix_kernel, dim3((unsigned)((total + kLcBlock - 1) / kLcBlock)), dim3(kLcBlock), 0, st,
                      d_x ? d_x : (const float2*)ctx->xstage.p, (float2*)ctx->fe_a.p, (long)n, blocks, f, (const float2*)ctx->tab.p);
   GACQ_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(longcode_dot_kernel, dim3((unsigned)npart), dim3(kLcBlock), 0, st, (const float2*)ctx->fe_a.p, d_chips, L,
-                     (const double*)d_phase, incr, (long)n, blocks, chunks, d_partial);
+  // candidates per workgroup: as many as leave a few workgroups per CU (the samples then cross L2 once per group)
+  int kc = kLcKc;
+  while (kc > 1 && (long)((K + kc - 1) / kc) * blocks * chunks < GACQ_LC_MINWG) kc >>= 1;
+  const long ngroups = (K + kc - 1) / kc;
+  if (L >= (1L << 30)) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "long-code search: code length %ld too large", L);
+  hipLaunchKernelGGL(longcode_dot_kernel, dim3((unsigned)(ngroups * blocks * chunks)), dim3(kLcBlock), 0, st, (const float2*)ctx->fe_a.p, d_chips,
+                     (int)L, (const double*)d_phase, incr, (long)n, blocks, chunks, K, kc, d_partial);
   GACQ_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(longcode_finish_kernel, dim3((unsigned)((K + 127) / 128)), dim3(128), 0, st, (const double2*)d_partial, d_q, K, blocks,
                      chunks);

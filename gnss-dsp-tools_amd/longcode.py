@@ -60,23 +60,50 @@ def _run(engine, x, fs, code, prn, carrier_hz, phase0, blocks, n, coffset=None):
 
 
 def _best(q):
-    """strict '>' scan from (0, 0): first maximum wins, all-zero keeps the initial ints (acquire-gps-l2cl.py:20,27-29)."""
-    m_metric, m_k = 0, 0
-    for k, v in enumerate(q):
-        if v > m_metric:
-            m_metric, m_k = v, k
-    return m_metric, m_k
+    """strict '>' scan from (0, 0): first maximum wins, all-zero keeps the initial ints (acquire-gps-l2cl.py:20,27-29).
+    np.argmax returns the first maximum, which is what the scan keeps; a NaN in q (never greater than anything) takes the scan itself."""
+    q = np.asarray(q)
+    if q.size == 0:
+        return 0, 0
+    if np.isnan(q).any():
+        m_metric, m_k = 0, 0
+        for k, v in enumerate(q):
+            if v > m_metric:
+                m_metric, m_k = v, k
+        return m_metric, m_k
+    k = int(np.argmax(q))
+    return (q[k], k) if q[k] > 0 else (0, 0)
+
+
+def l2cl_start_phases(l2cm_code_phase, blocks):
+    """chips = (k + block) * 10230 + l2cm_code_phase (acquire-gps-l2cl.py:24); start phase (chips % code_length) + frac with frac = 0
+    (gps/l2cl.py:59).  Formed for all (k, block) at once: the same operations in the same order per element as the reference's scalar
+    loop (integer product, one addition, np.mod = Python's floored %), so the values are bit for bit the loop's
+    (tests/test_longcode.py::test_start_phase_tables_equal_the_scalar_loops)."""
+    kb = np.arange(75, dtype=np.int64)[:, None] + np.arange(max(blocks, 0), dtype=np.int64)[None, :]
+    chips = kb * 10230 + l2cm_code_phase
+    return np.ascontiguousarray(np.mod(chips, L2CL_LENGTH) + 0, dtype=np.float64)
 
 
 def search_l2cl(x, prn, doppler, l2cm_code_phase, ms, fs, engine=None, coffset=None):
     blocks = ms // 20
     n = int(fs * 0.020)
-    phase0 = np.empty((75, max(blocks, 0)), dtype=np.float64)
-    for k in range(75):
-        for block in range(blocks):
-            chips = (k + block) * 10230 + l2cm_code_phase            # acquire-gps-l2cl.py:24
-            phase0[k, block] = (chips % L2CL_LENGTH) + 0             # (chips % code_length) + frac   gps/l2cl.py:59
+    phase0 = l2cl_start_phases(l2cm_code_phase, blocks)
     return _best(_run(engine, x, fs, "gps.l2cl", prn, doppler, phase0, blocks, n, coffset))
+
+
+def glonass_p_start_phases(ca_code_phase, blocks, n, incr):
+    """cp = 5110 k + 10 ca_code_phase, then cp += n * incr block after block (acquire-glonass-l1-p.py:24-31; p.code(0, cp, incr, n):
+    chips = 0, frac = cp): one column of the (k, block) table per block, every element going through the scalar loop's sequence of
+    fp64 additions."""
+    phase0 = np.empty((1000, max(blocks, 0)), dtype=np.float64)
+    cp = 5110 * np.arange(1000, dtype=np.int64) + 10 * ca_code_phase
+    cp = cp.astype(np.float64) if cp.dtype != np.float64 else cp
+    step = n * incr
+    for block in range(blocks):
+        phase0[:, block] = (0 % P_LENGTH) + cp
+        cp = cp + step
+    return phase0
 
 
 def search_glonass_p(x, chan, doppler, ca_code_phase, ms, fs, band="l1", engine=None, coffset=None):
@@ -84,10 +111,5 @@ def search_glonass_p(x, chan, doppler, ca_code_phase, ms, fs, band="l1", engine=
     blocks = ms // 4
     n = int(fs * 0.004)
     incr = 5110000.0 / fs
-    phase0 = np.empty((1000, max(blocks, 0)), dtype=np.float64)
-    for k in range(1000):
-        cp = 5110 * k + 10 * ca_code_phase
-        for block in range(blocks):
-            phase0[k, block] = (0 % P_LENGTH) + cp                   # p.code(0, cp, incr, n): chips = 0, frac = cp
-            cp += n * incr
+    phase0 = glonass_p_start_phases(ca_code_phase, blocks, n, incr)
     return _best(_run(engine, x, fs, "glonass.p", 0, spacing * chan + doppler, phase0, blocks, n, coffset))

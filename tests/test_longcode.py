@@ -122,3 +122,44 @@ def test_gpu_device_resident_chain_equals_the_host_buffer_entry_points(engine):
     assert got == want and got[1] == case["k"]
     with pytest.raises(ValueError):
         longcode.search_l2cl(x_dev[:1000], item, dop, cp, ms, g["fs"], engine=engine)
+
+
+def test_start_phase_tables_equal_the_scalar_loops():
+    """The (candidate, block) start-phase tables are formed with array operations; they must be bit for bit what the reference's scalar
+    loops produce (acquire-gps-l2cl.py:22-26, acquire-glonass-l1-p.py:24-31), for integer and fractional code phases alike."""
+    from gnss_dsp_tools_amd import longcode
+    rng = np.random.default_rng(11)
+    for l2cm in [0, 5, 10229, 3.25, 1234.5678, float(rng.uniform(0, 10230)), -3.5, np.float64(77.125)]:
+        for blocks in [0, 1, 5, 75]:
+            want = np.empty((75, blocks))
+            for k in range(75):
+                for block in range(blocks):
+                    chips = (k + block) * 10230 + l2cm
+                    want[k, block] = (chips % longcode.L2CL_LENGTH) + 0
+            assert longcode.l2cl_start_phases(l2cm, blocks).tobytes() == want.tobytes(), (l2cm, blocks)
+    for ca in [0, 17, 510.25, float(rng.uniform(0, 511)), np.float64(3.0625), -2.5]:
+        for blocks, n, fs in [(5, 65536, 16384000.0), (0, 65536, 16384000.0), (3, 40000, 1e7), (7, 65472, 16368000.0)]:
+            incr = 5110000.0 / fs
+            want = np.empty((1000, blocks))
+            for k in range(1000):
+                cp = 5110 * k + 10 * ca
+                for block in range(blocks):
+                    want[k, block] = (0 % longcode.P_LENGTH) + cp
+                    cp += n * incr
+            assert longcode.glonass_p_start_phases(ca, blocks, n, incr).tobytes() == want.tobytes(), (ca, blocks)
+
+
+def test_best_candidate_scan_equals_the_strict_greater_loop():
+    from gnss_dsp_tools_amd import longcode
+    rng = np.random.default_rng(12)
+
+    def loop(q):
+        m, k0 = 0, 0
+        for k, v in enumerate(q):
+            if v > m:
+                m, k0 = v, k
+        return m, k0
+    for q in [rng.normal(size=1000), -np.abs(rng.normal(size=10)), np.zeros(5), np.array([1.0, 3.0, 3.0, 2.0]),
+              np.array([np.nan, 1.0, np.nan, 2.0]), np.array([])]:
+        got, want = longcode._best(q), loop(q)
+        assert got[1] == want[1] and got[0] == want[0], (q, got, want)
