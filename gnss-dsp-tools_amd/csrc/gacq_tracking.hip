@@ -11,6 +11,7 @@
 // floor(cp0 + incr*i) mod L.  The two differ only when the accumulated rounding (~1e-11 chips over a block) straddles a chip
 // boundary, i.e. with probability ~1e-8 per correlator call; tests/test_tracking.py holds the result to 1e-5 of the reference.
 #include "gacq_common.h"
+#include "gacq_fft64.h"
 
 #include <algorithm>
 #include <cmath>
@@ -69,8 +70,8 @@ __global__ __launch_bounds__(kTrBlock) void correlate_partial_kernel(const float
       ai += (double)(v.y * w);
     }
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { ar += __shfl_down(ar, off); ai += __shfl_down(ai, off); }
+  ar = gacq::f64::wave_add_f64(ar);                   // DPP: the ds_bpermute chain of a __shfl_down tree is a tenth of this kernel's time
+  ai = gacq::f64::wave_add_f64(ai);
   if ((threadIdx.x & 63) == 0) { s_re[threadIdx.x >> 6] = ar; s_im[threadIdx.x >> 6] = ai; }
   __syncthreads();
   if (threadIdx.x == 0) {
