@@ -141,6 +141,11 @@ static int longcode_run(gacq_ctx* ctx, const float* x_iq, const int8_t* iq_int8,
   if (rc != GACQ_OK) return rc;
   const double chip_rate = gacq_code_chip_rate(code);
   const double incr = chip_rate / fs;                                   // l2cl.chip_rate/fs  (acquire-gps-l2cl.py:19)
+  // the kernel forms floor(phase + incr * i) as a 32-bit integer: start phases as the reference builds them are below two code periods
+  const double reach = 2147483000.0 - incr * (double)n;
+  for (size_t i = 0; i < (size_t)K * blocks; i++)
+    if (!(std::fabs(phase0[i]) < reach))
+      return set_error(ctx, GACQ_ERR_BAD_ARG, "long-code search: start phase %g of candidate %zu is not finite or beyond +-2^31 chips", phase0[i], i / blocks);
   const long total = (long)n * blocks;
   const int chunks = (n + kLcChunk - 1) / kLcChunk;
   const size_t npart = (size_t)K * blocks * chunks;

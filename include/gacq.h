@@ -252,7 +252,8 @@ int gacq_frontend_dev(gacq_ctx* ctx, const void* d_iq_int8, size_t nsamp_in, dou
  * acquire-glonass-l1-p.py / -l2-p.py:15-33.  For candidate k:
  *   q[k] = sum_block | sum_i x[n*block+i] * code[floor(phase0[k*blocks+block] + (chip_rate/fs)*i) mod L] * nco[i] |
  * x_iq: host complex64 at the file rate fs (after the carrier-offset wipe-off); carrier_hz = Doppler (+ FDMA channel bias);
- * phase0: the caller's (chips % L) + frac per (k, block), in chips.  Synchronous; q_out[K] in fp64.
+ * phase0: the caller's (chips % L) + frac per (k, block), in chips -- finite and within +-2^31 chips (anything else is
+ * GACQ_ERR_BAD_ARG; the reference's expressions stay below two code periods).  Synchronous; q_out[K] in fp64.
  * ------------------------------------------------------------------------------------------- */
 int gacq_longcode_search(gacq_ctx* ctx, const float* x_iq, size_t nsamp, double fs, const char* code, int prn,
                          double carrier_hz, const double* phase0, int K, int blocks, int n, double* q_out);

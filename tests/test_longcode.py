@@ -163,3 +163,19 @@ def test_best_candidate_scan_equals_the_strict_greater_loop():
               np.array([np.nan, 1.0, np.nan, 2.0]), np.array([])]:
         got, want = longcode._best(q), loop(q)
         assert got[1] == want[1] and got[0] == want[0], (q, got, want)
+
+
+@pytest.mark.gpu
+def test_gpu_start_phase_out_of_range_is_rejected(engine):
+    """The kernel forms floor(phase + incr * i) as a 32-bit integer; a start phase that is not finite or beyond +-2^31 chips (nothing the
+    reference's callers produce) is an argument error, not an out-of-bounds code index."""
+    from gnss_dsp_tools_amd import longcode
+    n, blocks = 8192, 2
+    x = np.zeros(n * blocks, dtype=np.complex64)
+    for bad in (np.inf, np.nan, 3.0e9, -3.0e9):
+        ph = np.zeros((5, blocks))
+        ph[3, 1] = bad
+        with pytest.raises(Exception) as err:
+            longcode._run(engine, x, 4096000.0, "gps.l2cl", 1, 0.0, ph, blocks, n)
+        assert "start phase" in str(err.value)
+    assert longcode._run(engine, x, 4096000.0, "gps.l2cl", 1, 0.0, np.full((5, blocks), 2.0e9), blocks, n).shape == (5,)
