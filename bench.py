@@ -75,7 +75,7 @@ def engine_kind(N):
     if N in (4096, 16384):
         return "lds"                 # whole transform in one workgroup's registers + LDS
     if N % 31 == 0:
-        return "split31"             # outer DFT-31 + Stockham inner transforms, one Z' round trip through HBM
+        return "split31"             # prime-factor form 31 x 11 x Nb x 9 (gacq_pfa.hip), one Z' round trip through HBM
     return "split_lds"               # outer DFT-R + 4096-point LDS inner transforms, one Z' round trip through HBM
 
 
@@ -913,9 +913,9 @@ def run(args, env):
     work_launch = dk["work_per_step"] / dk["launches_per_step"]
     kernel_name = {("lds", "lds_correlate", 4096): "lds_correlate_kernel", ("lds", "lds_correlate", 16384): "lds16k_correlate_kernel / lds16k_fused_kernel",
                    ("lds", "mix_nco", 4096): "lds_forward_kernel", ("lds", "mix_nco", 16384): "lds16k_forward_kernel",
-                   ("split31", "lds_correlate"): "split_inner_corr_kernel", ("split_lds", "lds_correlate"): "lds_inner_correlate_kernel",
-                   ("split31", "mag_peak"): "split_outer_inverse_kernel<31>", ("split_lds", "mag_peak"): "split_outer_inverse_kernel",
-                   ("split31", "mix_nco"): "split_outer_forward_kernel<31> + rocFFT inner", ("split_lds", "mix_nco"): "split_outer_forward_kernel + lds_inner_forward_kernel"}
+                   ("split31", "lds_correlate"): "pfa_inner_corr_kernel", ("split_lds", "lds_correlate"): "lds_inner_correlate_kernel",
+                   ("split31", "mag_peak"): "pfa_outer_inverse_kernel", ("split_lds", "mag_peak"): "split_outer_inverse_kernel",
+                   ("split31", "mix_nco"): "pfa_outer_forward_kernel + pfa_inner_forward_kernel", ("split_lds", "mix_nco"): "split_outer_forward_kernel + lds_inner_forward_kernel"}
     kname = kernel_name.get((dj["engine"], dstage, dj["N"])) or kernel_name.get((dj["engine"], dstage)) or dstage
     if dj["engine"] == "lds" and dstage == "lds_correlate":
         kname = {(4096, True): "lds_fused4k_kernel", (4096, False): "lds_correlate_kernel", (16384, True): "lds16k_fused_kernel",

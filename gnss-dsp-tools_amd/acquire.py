@@ -88,7 +88,7 @@ class AcqSignal:
 
     def nco_indices(self, kernel, doppler, bias_hz=0.0):
         """Test hook (gacq_debug_nco_indices): the table-NCO index vector of one (doppler, bias) row as the forward kernel
-        `kernel` (1 mix_nco, 2 LDS forward, 3 split outer forward, 4 fused 16K) computes it on the device; int32 [N]."""
+        `kernel` (1 mix_nco, 2 LDS forward, 3 split outer forward, 4 fused 16K, 5 prime-factor outer forward) computes it on the device; int32 [N]."""
         out = np.empty(self.sig.nfft, dtype=np.int32)
         nat.check(nat.lib.gacq_debug_nco_indices(self._h, int(kernel), float(doppler), float(bias_hz), out.ctypes.data_as(nat.c_int_p)),
                   self.engine._ctx)

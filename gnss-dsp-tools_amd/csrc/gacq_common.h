@@ -77,7 +77,7 @@ struct gacq_ctx {
   gacq::DevBuf tab, xstage, X, Y, rows, freq, fset, items, out_peaks, d0, partial, fe_a, fe_b, fe_taps, chunk_peaks, arrivals;
   gacq::DevBuf tie, tie_scratch, tie_q, tie_split, tie_done2;   // tie-safe re-evaluation: counters + lists, complex128 row scratch, per-block magnitude rows
   int tie_cap = 0;                     // list capacity the `tie` buffer was laid out for
-  long opt[GACQ_NOPTS] = {1, 1, -1, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 1, 8000, 0, 1};   // gacq_set_option values (defaults documented in include/gacq.h)
+  long opt[GACQ_NOPTS] = {1, 1, -1, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 1, 8000, 0, 1, 0};   // gacq_set_option values (defaults documented in include/gacq.h)
   gacq::DevBuf pin_x, pin_peaks;       // pinned host staging for the host-buffer entry point (gacq_search)
   gacq::DevBuf bar_x;                  // fine-grained device memory the host writes directly through the PCIe BAR (small gacq_search inputs)
   gacq::DevBuf bar_s;                  // the same for the correlator specs of gacq_correlate_batch_dev
@@ -116,6 +116,7 @@ struct gacq_sig {
   int N = 0;                 // FFT length: n or 2n
   float2* spectra = nullptr; // [nprn][N] code spectra C_p = fft(replica), complex64, natural order
   float2* spectra_r31 = nullptr;   // same in the radix-31 engine's [k1][k2] order (only when split_supported(N))
+  float2* spectra_pfa = nullptr;   // same in the prime-factor engine's order (only when pfa_supported(N))
   float2* spectra_split = nullptr; // split engine with LDS inner transforms: R lane-pair rows per item (N = R*4096)
   float2* spectra_lds = nullptr;   // same in the LDS engine's lane-pair layout (only when lds_supported(N))
   double2* spectra64 = nullptr;    // complex128 code spectra of the verification engine (engine 5), built on first use
@@ -172,26 +173,37 @@ int split_debug_nco(gacq_ctx* ctx, int N, int n, const double* d_freq, int* d_id
 // front-end carrier wipe-off alone (gacq_frontend.hip): int8 I/Q on the device -> complex64, fixed-point table NCO
 int frontend_mix(gacq_ctx* ctx, const void* d_iq_int8, long n, double fs_in, double carrier_offset_hz, float2* d_out);
 
-// split engines (gacq_split.hip): N = R*M, hand-written outer DFT-R, inner length-M transforms (rocFFT, Stockham LDS or the 4096 kernels)
+// split engines (gacq_split.hip): N = R*M, hand-written outer DFT-R, inner length-M transforms (rocFFT or the 4096 kernels)
 bool split_supported(int N);
 // outer DFT-31 (+NCO mix when mix) + twiddle, then the inner forward transforms; X in [k1][k2] order
 // inner == false: outer stage only (the caller runs the inner transforms itself)
 int split_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, long rows, int n, int N, const double* d_freq, int FD, int B,
                 const float2* tab, float2* X, bool mix, bool inner = true);
 int split_radix(int N);
-bool split_inner_fused_supported(int N);
-int split_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* C, const int* d_items, const int* d_fset, long g0, long ng,
-                          int P, int F, int D, int B, int N, float2* Z, int Mp = 0);
-// row pitch (complex elements) of the Z' buffer between the fused inner kernel and the outer inverse kernel of engine 3; 0 = none
-int split_row_pitch(int N);
 // inner stages of the split engine on the LDS FFT kernels (M = 4096)
 int lds_inner_forward(gacq_ctx* ctx, float2* rows, long nrows, bool conj);
 int lds_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const int* d_items, const int* d_fset, long g0,
                         long ng, int P, int F, int D, int B, int R, int N, float2* Z);
 // inner inverse transforms on Y (in place), then twiddle + inverse DFT-31 + |.|/N + sum over B + reduce -> rows[g0..g0+ng)
 // inner == false: Y already holds the twiddled inner inverse transforms (LDS inner path)
-int split_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng, int B, int N, float* q_out, float tie_scale,
-                       bool inner = true, bool twiddle_only = false, int Mp = 0);
+int split_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng, int B, int N, float* q_out, float tie_scale, bool inner = true);
+
+// partial[(g, chunk)] -> rows[g0 + g] (tie-tag aware): the last step of every split engine's outer inverse stage
+int split_combine(gacq_ctx* ctx, const RowRec* partial, RowRec* rows, long g0, long ng, int chunks, float tie_scale);
+
+// prime-factor form of the radix-31 engine (gacq_pfa.hip): N = 61380 / 30690 as the twiddle-free 4-D transform 31 x 11 x Nb x 9
+bool pfa_supported(int N);
+int pfa_row_pitch(int N);                        // pitch (complex elements) of a Z' row: 9 segments of whole 128-byte lines
+// rotated gather of x (+ NCO mix) + DFT-31, then the in-place inner transforms; X rows in the engine's own spectrum order
+int pfa_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, long rows, int n, int N, const double* d_freq, int FD, int B, const float2* tab,
+                float2* X, bool mix);
+// K2 + inner inverse transforms -> Z' (rows pfa_row_pitch apart)
+int pfa_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* C, const int* d_items, const int* d_fset, long g0, long ng, int P, int F,
+                        int D, int B, int N, float2* Z);
+// inverse DFT-31 (packed math or matrix pipe, GACQ_OPT_SPLIT_MFMA) + |.|/N + sum over B + reduce -> rows[g0..g0+ng)
+// need_sum: the row sum feeds the max/mean metric (acquire-gps-l1.py:35); raw-metric signals skip it (RowRec::sum = 0)
+int pfa_inverse_reduce(gacq_ctx* ctx, const float2* Z, RowRec* rows, long g0, long ng, int B, int N, float* q_out, float tie_scale, bool need_sum);
+int pfa_debug_nco(gacq_ctx* ctx, int N, int n, const double* d_freq, int* d_idx);
 
 // tie-safe re-evaluation (gacq_tiesafe.hip)
 bool tie_supported(int N);                       // prime factors of N in {2, 3, 5, 7, 11, 13, 31}: every FFT length of the reference's scripts

@@ -357,7 +357,7 @@ template <bool INV> struct OuterDft<40, INV> {
   template <class Sink> static __device__ __forceinline__ void run(v2 (&x)[40], Sink&& sink) { dft_ra5<8, INV>(x, sink); }
 };
 
-// In-place small DFTs in natural order, the butterflies of the Stockham inner transforms (radices 2, 3, 4, 5, 9, 11)
+// In-place small DFTs in natural order, the butterflies of the prime-factor engine's inner passes (radices 2, 4, 5, 9, 11 and their coprime products)
 template <int R, bool INV> struct SmallDft {
   static __device__ __forceinline__ void run(v2 (&x)[R]) {            // odd primes through the symmetric form
     v2 y[R];
@@ -391,7 +391,7 @@ template <bool INV> struct SmallDft<9, INV> {                          // 9 = 3 
 // Coprime composites by the prime-factor (Good-Thomas) mapping: R = N1 N2 with gcd 1,
 //   input  n = (N2 n1 + N1 n2) mod R,   output k = (A k1 + Bk k2) mod R,  A = N2 (N2^-1 mod N1), Bk = N1 (N1^-1 mod N2)
 // so that W_R^{nk} = W_N1^{n1 k1} W_N2^{n2 k2}: two layers of small DFTs and no twiddle factors at all (a register
-// permutation at compile time).  10 = 2 x 5, 12 = 3 x 4, 15 = 3 x 5 give 1980 = 11 * 12 * 15 and 990 = 11 * 9 * 10 in three passes.
+// permutation at compile time).  10 = 2 x 5 and 20 = 4 x 5 are the middle dimensions of the prime-factor engine (gacq_pfa.hip): 990 = 11 * 10 * 9, 1980 = 11 * 20 * 9.
 template <int N1, int N2, int A, int Bk, bool INV> struct PfaDft {
   static constexpr int R = N1 * N2;
   static __device__ __forceinline__ void run(v2 (&x)[R]) {
@@ -414,8 +414,7 @@ template <int N1, int N2, int A, int Bk, bool INV> struct PfaDft {
   }
 };
 template <bool INV> struct SmallDft<10, INV> : PfaDft<2, 5, 5, 6, INV> {};      // 5^-1 mod 2 = 1, 2^-1 mod 5 = 3
-template <bool INV> struct SmallDft<12, INV> : PfaDft<3, 4, 4, 9, INV> {};      // 4^-1 mod 3 = 1, 3^-1 mod 4 = 3
-template <bool INV> struct SmallDft<15, INV> : PfaDft<3, 5, 10, 6, INV> {};     // 5^-1 mod 3 = 2, 3^-1 mod 5 = 2
+template <bool INV> struct SmallDft<20, INV> : PfaDft<4, 5, 5, 16, INV> {};     // 5^-1 mod 4 = 1, 4^-1 mod 5 = 4
 
 // w^k for k = 0..43 from base-4 digits: w^k = p[k & 3] * q[k >> 2], p[a] = w^a, q[b] = w^(4b); multiplication depth <= 5
 struct TwPow {

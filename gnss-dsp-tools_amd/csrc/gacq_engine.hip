@@ -558,11 +558,10 @@ int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes) {
 int gacq_set_option(gacq_ctx* ctx, int option, long value) {
   if (!ctx || option < 0 || option >= GACQ_NOPTS) return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_set_option: unknown option %d", option);
   // accepted range per option (GACQ_OPT_* order): switches 0/1(/2), counts bounded by what the kernels' index arithmetic carries
-  static const long kMax[GACQ_NOPTS] = {1, 1, 1000, 4096, 4096, 4, 2, 3, 1, 64, 1, 1, 1, 1, 1000000000L, 1L << 24, 1};
+  static const long kMax[GACQ_NOPTS] = {1, 1, 1000, 4096, 4096, 4, 2, 3, 1, 64, 1, 1, 1, 1, 1000000000L, 1L << 24, 1, 1};
   const long lo = (option == GACQ_OPT_LDS_VARIANT) ? -1 : 0;
   if (value < lo || value > kMax[option])
     return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_set_option: value %ld out of range [%ld, %ld] for option %d", value, lo, kMax[option], option);
-  if (option == GACQ_OPT_SPLIT_TEAMS && value == 3) return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_set_option: split_teams must be 0, 1, 2 or 4");
   ctx->opt[option] = value;
   return GACQ_OK;
 }
@@ -656,6 +655,11 @@ static int build_signal(gacq_ctx* ctx, const gacq_sigdesc* desc, const std::vect
       if (rc == GACQ_OK) rc = split_forward(ctx, tmp, 0, nprn, s->N, s->N, nullptr, 1, 1, nullptr, s->spectra_split, false, false);
       if (rc == GACQ_OK) rc = lds_inner_forward(ctx, s->spectra_split, (long)nprn * split_radix(s->N), false);
     }
+    if (rc == GACQ_OK && pfa_supported(s->N)) {
+      // prime-factor engine: the spectrum order is whatever its forward kernels produce -- run the replicas through them
+      if (hipMalloc((void**)&s->spectra_pfa, bytes) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "hipMalloc for prime-factor spectra failed");
+      if (rc == GACQ_OK) rc = pfa_forward(ctx, tmp, 0, nprn, s->N, s->N, nullptr, 1, 1, nullptr, s->spectra_pfa, false);
+    }
     if (rc == GACQ_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "split-engine code spectrum failed");
     if (tmp) (void)hipFree(tmp);
   }
@@ -664,7 +668,7 @@ static int build_signal(gacq_ctx* ctx, const gacq_sigdesc* desc, const std::vect
     else rc = lds_prepare_spectra(ctx, s->spectra, s->spectra_lds, nprn, s->N);
   }
   if (rc == GACQ_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "code spectrum FFT failed");
-  if (rc != GACQ_OK) { (void)hipFree(s->spectra); if (s->spectra_lds) (void)hipFree(s->spectra_lds); if (s->spectra_r31) (void)hipFree(s->spectra_r31); if (s->spectra_split) (void)hipFree(s->spectra_split); delete s; return rc; }
+  if (rc != GACQ_OK) { (void)hipFree(s->spectra); if (s->spectra_lds) (void)hipFree(s->spectra_lds); if (s->spectra_r31) (void)hipFree(s->spectra_r31); if (s->spectra_pfa) (void)hipFree(s->spectra_pfa); if (s->spectra_split) (void)hipFree(s->spectra_split); delete s; return rc; }
   *out = s;
   return GACQ_OK;
 }
@@ -710,6 +714,7 @@ void gacq_signal_destroy(gacq_sig* sig) {
   if (sig->spectra) (void)hipFree(sig->spectra);
   if (sig->spectra_lds) (void)hipFree(sig->spectra_lds);
   if (sig->spectra_r31) (void)hipFree(sig->spectra_r31);
+  if (sig->spectra_pfa) (void)hipFree(sig->spectra_pfa);
   if (sig->spectra_split) (void)hipFree(sig->spectra_split);
   if (sig->spectra64) (void)hipFree(sig->spectra64);
   delete sig;
@@ -860,6 +865,9 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
   if (ctx->engine == 4 && !split_lds_ok)
     return set_error(ctx, GACQ_ERR_UNSUPPORTED, "engine 4 (split with LDS inner transforms) does not support N=%d", N);
   const bool use_split = use_split_lds || (ctx->engine == 3) || (ctx->engine == 0 && split_supported(N));
+  // N = 31 * 1980 / 31 * 990: the twiddle-free prime-factor form (gacq_pfa.hip) unless the caller asks for the Cooley-Tukey forms
+  // form with rocFFT inner transforms (GACQ_OPT_FUSED_INNER 0: other arithmetic, the cross-check)
+  const bool use_pfa = use_split && !use_split_lds && pfa_supported(N) && ctx->opt[GACQ_OPT_FUSED_INNER] != 0;
   if (ctx->engine == 3 && !split_supported(N))
     return set_error(ctx, GACQ_ERR_UNSUPPORTED, "engine 3 (split with rocFFT inner transforms) does not support N=%d", N);
 
@@ -919,7 +927,12 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
       stage_end(ctx);
       if (rc != GACQ_OK) return rc;
     } else {
-      if (use_split) {
+      if (use_pfa) {
+        stage_begin(ctx, 0);
+        rc = pfa_forward(ctx, xe, nsamp, rows_x, n, N, (const double*)ctx->freq.p, F * D, B, (const float2*)ctx->tab.p, X, true);
+        stage_end(ctx);
+        if (rc != GACQ_OK) return rc;
+      } else if (use_split) {
         stage_begin(ctx, 0);
         rc = split_forward(ctx, xe, nsamp, rows_x, n, N, (const double*)ctx->freq.p, F * D, B, (const float2*)ctx->tab.p, X, true,
                          !use_split_lds);
@@ -939,10 +952,10 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
       }
       // correlation workspace: chunks of whole (e,p,d) groups, B rows each
       const long groups = (long)ne * P * D;
-      const bool fused_r31 = use_split && split_inner_fused_supported(N) && ctx->opt[GACQ_OPT_FUSED_INNER];
-      const int zpitch = fused_r31 ? split_row_pitch(N) : 0;       // engine 3: Z' rows padded to whole 128-byte lines
+      const int zpitch = use_pfa ? pfa_row_pitch(N) : 0;       // prime-factor engine: Z' rows are whole reader workgroups of 128-byte lines
       const size_t group_bytes = sizeof(float2) * (size_t)B * (zpitch ? (size_t)zpitch * R : (size_t)N);
       long gc = (long)std::max<size_t>(1, std::min<size_t>((size_t)groups, ctx->ws_limit / group_bytes));
+      gc = (groups + (groups + gc - 1) / gc - 1) / ((groups + gc - 1) / gc);       // equal passes instead of full ones and a sliver
       if ((rc = ensure(ctx, ctx->Y, group_bytes * gc)) != GACQ_OK) return rc;
       float2* Y = (float2*)ctx->Y.p;
       for (long g0 = 0; g0 < groups; g0 += gc) {
@@ -959,14 +972,13 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
           if (rc != GACQ_OK) return rc;
           continue;
         }
-        if (fused_r31) {
+        if (use_pfa) {
           stage_begin(ctx, 6);
-          rc = split_inner_correlate(ctx, X, sig->spectra_r31, (const int*)ctx->items.p, (const int*)ctx->fset.p, g0, ng, P, F, D, B, N,
-                                     Y, zpitch);                                // K2 + inner inverse FFTs (Stockham in LDS)
+          rc = pfa_inner_correlate(ctx, X, sig->spectra_pfa, (const int*)ctx->items.p, (const int*)ctx->fset.p, g0, ng, P, F, D, B, N, Y);   // K2 + inner inverse transforms, in place in LDS
           stage_end(ctx);
           if (rc != GACQ_OK) return rc;
           stage_begin(ctx, 4);
-          rc = split_inverse_reduce(ctx, Y, rows, g0, ng, B, N, d_qrow, tscale, false, true, zpitch);   // twiddle + outer DFT-31 + |.| + reduce
+          rc = pfa_inverse_reduce(ctx, Y, rows, g0, ng, B, N, d_qrow, tscale, ds.metric_mode != 0);                 // inverse DFT-31 + |.| + reduce
           stage_end(ctx);
           if (rc != GACQ_OK) return rc;
           continue;
@@ -1293,7 +1305,8 @@ int gacq_debug_nco_indices(gacq_sig* sig, int kernel, double doppler, double bia
     case 2: rc = lds_debug_nco(ctx, N, n, (const double*)ctx->freq.p, false, d_idx); break;
     case 3: rc = split_debug_nco(ctx, N, n, (const double*)ctx->freq.p, d_idx); break;
     case 4: rc = lds_debug_nco(ctx, N, n, (const double*)ctx->freq.p, true, d_idx); break;
-    default: rc = set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_debug_nco_indices: kernel must be 1..4");
+    case 5: rc = pfa_debug_nco(ctx, N, n, (const double*)ctx->freq.p, d_idx); break;
+    default: rc = set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_debug_nco_indices: kernel must be 1..5");
   }
   if (rc != GACQ_OK) return rc;
   GACQ_HIP(ctx, hipMemcpyAsync(idx_out, d_idx, sizeof(int) * (size_t)N, hipMemcpyDeviceToHost, ctx->stream));

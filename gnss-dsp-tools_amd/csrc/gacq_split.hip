@@ -10,10 +10,12 @@
 //   inverse : inner inverse transforms of length M, batch R*rows
 //             split_outer_inverse_kernel (twiddle + inverse DFT-R + |.|/N + sum over blocks + max/argmax/sum)  outer + K3
 //
-// R = 31, M = 1980 / 990 (N = 61380 / 30690: the 10.23 Mcps family, acquire-gps-l5i.py:19-24 and 18 more scripts, and
+// R = 31, any 13-smooth M >= 64 (N = 61380 / 30690: the 10.23 Mcps family, acquire-gps-l5i.py:19-24 and 18 more scripts, and
 //   E6, acquire-galileo-e6b.py:19-24).  rocFFT has no radix-31 butterfly and falls back to Bluestein for these lengths
 //   (three transforms of twice the size per FFT); M = 4*5*9*11 is native to it.  The DFT-31 uses the conjugate symmetry
-//   of W_31 (gacq_cplx.h: dft_prime), a quarter of the 31 x 31 complex products.
+//   of W_31 (gacq_cplx.h: dft_prime), a quarter of the 31 x 31 complex products.  For the two lengths the reference uses, auto
+//   runs the twiddle-free prime-factor form of gacq_pfa.hip instead (since round 5); this Cooley-Tukey form with rocFFT inner
+//   transforms stays as the independent cross-check (GACQ_OPT_FUSED_INNER 0) and for other multiples of 31.
 // R = 4 / 16 / 20 / 40, M = 4096 (N = 16384 / 65536 / 81920 / 163840: B1I, GLONASS, E1B/E1C, L1C, B1C, L2CM): the inner transforms are single-kernel and the
 //   magnitude/reduce stage is fused into the outer inverse DFT, so the correlation workspace is read once less.
 #include "gacq_common.h"
@@ -97,7 +99,7 @@ __device__ __forceinline__ v2 ld_stream(const float2* p) {
 // and the 3-waves-per-SIMD register budget let a third wave hide the R strided loads of the other two.
 template <int R, bool TW, bool B1>
 __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_inverse_kernel(
-    const float2* __restrict__ Z, RowRec* __restrict__ partial, const float2* __restrict__ tw, int M, int Mp, int B, int chunks, float inv_n,
+    const float2* __restrict__ Z, RowRec* __restrict__ partial, const float2* __restrict__ tw, int M, int B, int chunks, float inv_n,
     float* __restrict__ q_out, int paired, float tie_scale) {
   __shared__ float s_peak[kBlock / 64], s_second[kBlock / 64];
   __shared__ int s_idx[kBlock / 64];
@@ -118,9 +120,9 @@ __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_i
     // loads first, asm afterwards: the machine scheduler does not move loads across inline asm
     v2 v[R];
     {
-      const float2* src = Z + (g * B) * (long)(R * Mp) + pos;     // rows are Mp apart (128-byte aligned pitch)
+      const float2* src = Z + (g * B) * (long)(R * M) + pos;
 #pragma unroll
-      for (int k1 = 0; k1 < R; k1++) v[k1] = ld_stream<kNT>(src + (long)k1 * Mp);
+      for (int k1 = 0; k1 < R; k1++) v[k1] = ld_stream<kNT>(src + (long)k1 * M);
     }
     TwPow tp;
     if (TW) {
@@ -162,9 +164,9 @@ __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_i
     for (int k = 0; k < R; k++) q[k] = 0.f;
     for (int b = 0; b < B; b++) {
       if (b > 0) {
-        const float2* src = Z + (g * B + b) * (long)(R * Mp) + pos;
+        const float2* src = Z + (g * B + b) * (long)(R * M) + pos;
 #pragma unroll
-        for (int k1 = 0; k1 < R; k1++) v[k1] = ld_stream<kNT>(src + (long)k1 * Mp);
+        for (int k1 = 0; k1 < R; k1++) v[k1] = ld_stream<kNT>(src + (long)k1 * M);
       }
       if (TW) {
 #pragma unroll
@@ -207,207 +209,6 @@ __global__ __launch_bounds__(kBlock, (B1 && R >= 31) ? 3 : 1) void split_outer_i
   }
 }
 
-// Phase timing (diagnostic builds only, -DGACQ_PHASE_TIMING; tools/phase_timing.sh): thread 0 of every workgroup accumulates the
-// shader-clock cycles between marks and adds them to gacq_phase_cycles[] once at the end (read back with
-// gacq_debug_phase_cycles).  Never defined in the product build.
-#ifdef GACQ_PHASE_TIMING
-__device__ unsigned long long gacq_phase_cycles[32];
-struct PhaseAcc { unsigned long long t[16]; };
-#define GACQ_MARK(i)                                                                              \
-  do {                                                                                            \
-    const unsigned long long now_ = __builtin_readcyclecounter();                                 \
-    acc_.t[i] += now_ - mark_;                                                                    \
-    mark_ = now_;                                                                                 \
-  } while (0)
-#define GACQ_MARK_ARG , unsigned long long& mark_, PhaseAcc& acc_, int mark_base_
-#define GACQ_MARK_PASS(b) , mark_, acc_, b
-#else
-#define GACQ_MARK(i) do { } while (0)
-#define GACQ_MARK_ARG
-#define GACQ_MARK_PASS(b)
-#endif
-
-// ---- inner inverse transforms fused with the conj-multiply (engine 3, M = 1980 / 990) ---------------------------------
-// Z[ry][n2] = IFFT_M( C_p[k1][.] * conj(X[e,f,d,b][k1][.]) )[n2]  (unnormalised), one workgroup per (group, block, k1) row.
-// Stockham autosort in LDS (one buffer, see stockham_pass), mixed radices R0*R1*R2*R3 = M; the first pass reads the two spectra from global
-// memory and multiplies them (K2), so the product never exists in HBM; the last pass writes the row.  Thread j of a
-// radix-R pass with Ns = product of the previous radices:  k = j mod Ns; inputs in[j + t M/R] * W_{Ns R}^{-k t};
-// R-point DFT; outputs out[(j div Ns) Ns R + k + t Ns].
-// Twiddles of the pass with (Ns, R) live in their own LDS table twp[(t-1) Ns + k] = conj(W_{Ns R}^{k t}), k < Ns: consecutive
-// lanes read consecutive words (indexing one shared W_M table by k t M/(Ns R) put up to 32 lanes on one bank).
-template <int R, int NT>
-__device__ __forceinline__ void fill_pass_twiddles(v2* __restrict__ twp, const float2* __restrict__ twm_g, int Ns, int M) {
-  const int step = M / (Ns * R);
-  for (int q = threadIdx.x; q < (R - 1) * Ns; q += NT) {
-    const int t = q / Ns + 1, k = q - (t - 1) * Ns;
-    const float2 w = twm_g[k * t * step];          // k t step < M
-    twp[q] = v2{w.x, -w.y};
-  }
-}
-
-// One radix-R pass, in place: every thread pulls its butterflies' inputs into registers (one LDS read per instruction, GACQ_UNPAIR in
-// gacq_cplx.h: config 4 3.17 -> 3.09 ms per step; not in the one-Doppler-bin instantiations, which then spill two registers), the
-// workgroup synchronises, then the
-// outputs overwrite the same buffer (autosort order).  One buffer instead of a ping-pong pair keeps the workgroup at
-// 2 M complex of LDS (row + twiddles) so five of them fit a CU.  LAST writes the row to global memory instead.
-template <int R, bool LAST, int M, int NT, bool UNPAIR = true>
-__device__ __forceinline__ void stockham_pass(v2* __restrict__ buf, float2* __restrict__ gz, const v2* __restrict__ twp, int Ns, int tid,
-                                              bool live GACQ_MARK_ARG) {
-  constexpr int nb = M / R;
-  constexpr int iters = (nb + NT - 1) / NT;
-  v2 x[iters][R];
-#pragma unroll
-  for (int it = 0; it < iters; it++) {
-    const int j = tid + it * NT;
-    if (j < nb && live) {
-      const int k = j % Ns;
-      v2 wv[R];
-#pragma unroll
-      for (int t = 0; t < R; t++) { x[it][t] = buf[j + t * nb]; if (UNPAIR) GACQ_UNPAIR(); if (t) { wv[t] = twp[(t - 1) * Ns + k]; if (UNPAIR) GACQ_UNPAIR(); } }      // conj(W_{Ns R}^{k t})
-#pragma unroll
-      for (int t = 1; t < R; t++) x[it][t] = cmul(x[it][t], wv[t]);
-      SmallDft<R, true>::run(x[it]);
-    }
-  }
-  GACQ_MARK(mark_base_);                           // LDS reads, twiddle products, R-point DFT
-  if (!LAST) __syncthreads();                      // all inputs are in registers
-  GACQ_MARK(mark_base_ + 1);
-#pragma unroll
-  for (int it = 0; it < iters; it++) {
-    const int j = tid + it * NT;
-    if (j < nb && live) {
-      const int k = j % Ns;
-      const int j0 = (j / Ns) * Ns * R + k;
-#pragma unroll
-      for (int t = 0; t < R; t++) {
-        if (LAST) gz[j0 + t * Ns] = make_float2(x[it][t].x, x[it][t].y);
-        else buf[j0 + t * Ns] = x[it][t];
-      }
-    }
-  }
-}
-
-// Workgroup = (k1, chunk of pch consecutive (epoch, item) pairs, Doppler bin, block).  TEAMS teams of NT threads (whole waves)
-// share one set of per-pass twiddle tables in LDS and work on TEAMS consecutive items at a time, each team in its own row buffer;
-// a team keeps the first-pass operands of X[e,f,d,b][k1][.] in registers while its items change (reloaded only when the row
-// pointer changes, i.e. across an epoch or frequency-set boundary).  One team per workgroup (31.6 KB for M = 1980) lets five
-// workgroups = 15 waves share a CU, and the kernel waits on LDS round trips and barriers two thirds of the time; four teams
-// amortise the 15.7 KB of tables over four rows (79 KB per workgroup, two workgroups = 24 waves per CU, the register limit).
-// Consecutive workgroups share k1 and the item chunk, so the pch code-spectrum rows they read stay in every XCD's L2.
-// [g0, g0+ng) is the range of (e,p,d) groups whose Z rows exist in this workspace pass; anything outside is skipped (the team
-// idles through the barriers).
-// R3 == 1: three passes (R0, R1, R2).  NT threads per team, chosen close to the butterflies per pass:
-//   M = 1980 = 11 * 12 * 15: 180, 165, 132 butterflies -> 192 threads;   M = 990 = 11 * 9 * 10: 90, 110, 99 -> 128 threads.
-// Three passes instead of four (11 * 9 * 5 * 4|2) mean one LDS exchange, one twiddle stage and two barriers less per row; the
-// composite radices 10, 12 and 15 are coprime products (PfaDft), so they cost no internal twiddles either.
-// DT consecutive Doppler bins per workgroup: the first-pass operands of DT rows X[e,f,d..d+DT-1,b][k1][.] stay in registers and
-// every code-spectrum row fetched for an item serves DT correlation rows.  Phase timing (profiles/r02_stockham_phase_timing*.log)
-// shows a row spending 44 % of its time waiting for the 16 KB of C it reads and 20 % issuing the 16 KB of Z' it writes -- the
-// CU's memory pipeline, not arithmetic or LDS, paces this kernel -- so halving the C traffic per row is what pays.
-template <int R0, int R1, int R2, int R3, int NT, int TEAMS, int DT>
-__global__ __launch_bounds__(NT * TEAMS, (DT == 1 ? 5 : (DT == 2 && R0 * R1 * R2 * R3 == 990 ? 4 : 3))) void split_inner_corr_kernel(const float2* __restrict__ X, const float2* __restrict__ C,
-                                                                   float2* __restrict__ Z, const int* __restrict__ items,
-                                                                   const int* __restrict__ fset, const float2* __restrict__ twm_g,
-                                                                   long g0, long ng, long ep_first, int nblk_ep, int pch, int P, int F,
-                                                                   int D, int B, int R, int Mp) {
-  constexpr int M = R0 * R1 * R2 * R3;
-  constexpr int nb0 = M / R0;
-  static_assert(nb0 <= NT, "first pass: one radix-R0 butterfly per thread");
-  static_assert(NT % 64 == 0, "teams are whole waves");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int team = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / NT));      // wave-uniform: keeps the row pointers in SGPRs
-  const int j = (int)threadIdx.x - team * NT;
-  v2* buf0 = reinterpret_cast<v2*>(smem) + team * M;
-  v2* tw1 = reinterpret_cast<v2*>(smem) + TEAMS * M;        // per-pass twiddle tables, M - R0 entries in all
-  v2* tw2 = tw1 + (R1 - 1) * R0;
-  v2* tw3 = tw2 + (R2 - 1) * R0 * R1;
-  fill_pass_twiddles<R1, NT * TEAMS>(tw1, twm_g, R0, M);
-  fill_pass_twiddles<R2, NT * TEAMS>(tw2, twm_g, R0 * R1, M);
-  if (R3 > 1) fill_pass_twiddles<R3, NT * TEAMS>(tw3, twm_g, R0 * R1 * R2, M);
-  unsigned blk = blockIdx.x;                       // 32-bit index math: 64-bit divisions cost ~100 scalar ops each
-  const int b = (int)(blk % (unsigned)B);
-  blk /= (unsigned)B;
-  const int DG = (D + DT - 1) / DT;                // Doppler groups
-  const int d0 = (int)(blk % (unsigned)DG) * DT;
-  blk /= (unsigned)DG;
-  const unsigned epc = blk % (unsigned)nblk_ep;
-  const int k1 = (int)(blk / (unsigned)nblk_ep);
-  const bool act = j < nb0;
-  const float2* have[DT];
-  float2 xv[DT][R0];
-#pragma unroll
-  for (int dd = 0; dd < DT; dd++) have[dd] = nullptr;
-  const unsigned ep0 = (unsigned)ep_first + epc * (unsigned)pch;       // E * P < 2^31 (checked by the launcher)
-#ifdef GACQ_PHASE_TIMING
-  PhaseAcc acc_;
-#pragma unroll
-  for (int i = 0; i < 16; i++) acc_.t[i] = 0;
-  unsigned long long mark_ = __builtin_readcyclecounter();
-#endif
-  for (int i0 = 0; i0 < pch; i0 += TEAMS) {
-    const unsigned ep = ep0 + (unsigned)(i0 + team);
-    const unsigned e = ep / (unsigned)P;
-    const int p = (int)(ep - e * (unsigned)P);
-    const bool item_ok = i0 + team < pch;
-    float2 cv[R0];
-    bool have_c = false;
-#pragma unroll
-    for (int dd = 0; dd < DT; dd++) {
-      const int d = d0 + dd;
-      const long g = (long)ep * D + d;
-      const bool live = item_ok && d < D && g >= g0 && g < g0 + ng;       // uniform over the team
-      float2* gz = nullptr;
-      if (live) {
-        const float2* gx = X + (((((long)e * F + fset[p]) * D + d) * (long)B + b) * R + k1) * (long)M;
-        gz = Z + (((g - g0) * B + b) * R + k1) * (long)Mp;
-        if (act) {
-          if (!have_c) {
-            const float2* gc = C + ((long)items[p] * R + k1) * (long)M;
-#pragma unroll
-            for (int t = 0; t < R0; t++) cv[t] = gc[j + t * nb0];
-          }
-          if (gx != have[dd]) {
-#pragma unroll
-            for (int t = 0; t < R0; t++) xv[dd][t] = gx[j + t * nb0];
-          }
-          v2 x[R0];
-#pragma unroll
-          for (int t = 0; t < R0; t++)
-            x[t] = v2{cv[t].x * xv[dd][t].x + cv[t].y * xv[dd][t].y, cv[t].y * xv[dd][t].x - cv[t].x * xv[dd][t].y};      // C * conj(X)   acquire-gps-l1.py:32
-          SmallDft<R0, true>::run(x);
-#pragma unroll
-          for (int t = 0; t < R0; t++) buf0[j * R0 + t] = x[t];                                             // Ns = 1: k = 0, no twiddles
-        }
-        have_c = true;
-        have[dd] = gx;
-      }
-      GACQ_MARK(0);                                // (wait for C, X) C conj(X), DFT-R0, LDS writes
-      __syncthreads();
-      GACQ_MARK(1);
-      stockham_pass<R1, false, M, NT, (DT > 1)>(buf0, nullptr, tw1, R0, j, live GACQ_MARK_PASS(2));
-      GACQ_MARK(4);                                // pass-2 outputs written to LDS
-      __syncthreads();
-      GACQ_MARK(5);
-      if (R3 > 1) {
-        stockham_pass<R2, false, M, NT, (DT > 1)>(buf0, nullptr, tw2, R0 * R1, j, live GACQ_MARK_PASS(10));
-        __syncthreads();
-        stockham_pass<(R3 > 1 ? R3 : 2), true, M, NT, (DT > 1)>(buf0, gz, tw3, R0 * R1 * R2, j, live GACQ_MARK_PASS(12));
-      } else {
-        stockham_pass<R2, true, M, NT, (DT > 1)>(buf0, gz, tw2, R0 * R1, j, live GACQ_MARK_PASS(6));
-      }
-      GACQ_MARK(8);                                // last pass: row stored to global memory
-      __syncthreads();                             // buf0 is rewritten by the next row's first pass
-      GACQ_MARK(9);
-    }
-  }
-#ifdef GACQ_PHASE_TIMING
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int i = 0; i < 16; i++) if (acc_.t[i]) atomicAdd(&gacq_phase_cycles[i], acc_.t[i]);
-  }
-#endif
-}
-
 // partial[(g, chunk)] -> rows[g0 + g]
 __global__ void split_combine_kernel(const RowRec* __restrict__ partial, RowRec* __restrict__ rows, long g0, long ng, int chunks, float tie_scale) {
   const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -445,110 +246,26 @@ int launch_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, long rows, int 
 }
 
 template <int R>
-int launch_inverse(gacq_ctx* ctx, const float2* Z, RowRec* partial, const float2* tw, int M, int Mp, int B, long ng, float inv_n,
+int launch_inverse(gacq_ctx* ctx, const float2* Z, RowRec* partial, const float2* tw, int M, int B, long ng, float inv_n,
                    float* q_out, bool twiddle, int paired, float tie_scale) {
   const int chunks = (M + kBlock - 1) / kBlock;
   const dim3 grid((unsigned)(ng * chunks));
   const bool b1 = (B == 1) && !q_out;
   if (twiddle && b1)
-    hipLaunchKernelGGL((split_outer_inverse_kernel<R, true, true>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, Mp, B, chunks, inv_n, q_out, paired, tie_scale);
+    hipLaunchKernelGGL((split_outer_inverse_kernel<R, true, true>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, B, chunks, inv_n, q_out, paired, tie_scale);
   else if (twiddle)
-    hipLaunchKernelGGL((split_outer_inverse_kernel<R, true, false>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, Mp, B, chunks, inv_n, q_out, paired, tie_scale);
+    hipLaunchKernelGGL((split_outer_inverse_kernel<R, true, false>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, B, chunks, inv_n, q_out, paired, tie_scale);
   else if (b1)
-    hipLaunchKernelGGL((split_outer_inverse_kernel<R, false, true>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, Mp, B, chunks, inv_n, q_out, paired, tie_scale);
+    hipLaunchKernelGGL((split_outer_inverse_kernel<R, false, true>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, B, chunks, inv_n, q_out, paired, tie_scale);
   else
-    hipLaunchKernelGGL((split_outer_inverse_kernel<R, false, false>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, Mp, B, chunks, inv_n, q_out, paired, tie_scale);
+    hipLaunchKernelGGL((split_outer_inverse_kernel<R, false, false>), grid, dim3(kBlock), 0, ctx->stream, Z, partial, tw, M, B, chunks, inv_n, q_out, paired, tie_scale);
   GACQ_HIP(ctx, hipGetLastError());
   return GACQ_OK;
-}
-
-int inner_twiddles(gacq_ctx* ctx, int M, const float2** out) {          // W_M^k, k < M
-  return twiddle_cache(ctx, "WM_" + std::to_string(M), M, M, out);
 }
 
 }  // namespace
 
 namespace gacq {
-
-bool split_inner_fused_supported(int N) { return N == 61380 || N == 30690; }
-
-#ifdef GACQ_PHASE_TIMING
-extern "C" int gacq_debug_phase_cycles(unsigned long long* out32, int reset) {
-  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(gacq_phase_cycles), sizeof(unsigned long long) * 32) != hipSuccess) return GACQ_ERR_HIP;
-  if (reset) {
-    unsigned long long z[32] = {0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(gacq_phase_cycles), z, sizeof z) != hipSuccess) return GACQ_ERR_HIP;
-  }
-  return GACQ_OK;
-}
-#endif
-
-// K2 + inner inverse transforms in one kernel (no Y round trip); Z gets the unnormalised, untwiddled inner IFFTs
-int split_row_pitch(int N) {
-  if (!split_inner_fused_supported(N)) return 0;
-  return (N / 31 + 15) & ~15;                      // 1980 -> 1984, 990 -> 992 complex: rows of Z' start on 128-byte lines
-}
-
-int split_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* C, const int* d_items, const int* d_fset, long g0, long ng,
-                          int P, int F, int D, int B, int N, float2* Z, int Mp) {
-  const int R = 31, M = N / R;
-  if (Mp < M) Mp = M;
-  const float2* twm;
-  int rc = inner_twiddles(ctx, M, &twm);
-  if (rc != GACQ_OK) return rc;
-  // (epoch, item) rows touched by this pass, cut into chunks of pch per workgroup; >= ~2048 workgroups, <= 8 items each
-  const long ep_first = g0 / D, ep_last = (g0 + ng - 1) / D;
-  const long nep = ep_last - ep_first + 1;
-  int pch = (int)std::max<long>(1, std::min<long>(8, nep * D * B * R / 2048));
-  if (ctx->opt[GACQ_OPT_SPLIT_PCH] >= 1) pch = (int)ctx->opt[GACQ_OPT_SPLIT_PCH];
-  int teams = 1;      // measured (profiles/r02_stockham_teams_sweep.log): 2 or 4 rows per workgroup are 5-10 % slower despite 24 instead of 15 waves per CU
-  if (ctx->opt[GACQ_OPT_SPLIT_TEAMS] >= 1) teams = (int)ctx->opt[GACQ_OPT_SPLIT_TEAMS];
-  if (teams != 1 && teams != 2 && teams != 4) return set_error(ctx, GACQ_ERR_BAD_ARG, "split engine: teams per workgroup must be 1, 2 or 4");
-  pch = (pch + teams - 1) / teams * teams;
-  const int nblk_ep = (int)((nep + pch - 1) / pch);
-  int dt = (teams == 1 && D >= 8) ? (M == 1980 ? 3 : 2) : 1;       // Doppler bins per workgroup (profiles/r02_stockham_doppler_tile_sweep.log)
-  if (ctx->opt[GACQ_OPT_SPLIT_DT] >= 1) dt = (int)ctx->opt[GACQ_OPT_SPLIT_DT];
-  if (dt < 1 || dt > 3) return set_error(ctx, GACQ_ERR_BAD_ARG, "split engine: Doppler bins per workgroup must be 1, 2 or 3");
-  const int DG = (D + dt - 1) / dt;
-  const dim3 grid((unsigned)((long)R * nblk_ep * DG * B));
-  const size_t smem = sizeof(float2) * ((size_t)teams * M + (size_t)M);
-  {
-    // teams = 4 with M = 1980 asks for 79 KB of dynamic LDS: fine on gfx950 (160 KB), not on a 64 KB part -- say so instead of
-    // failing inside hipFuncSetAttribute with a generic HIP error
-    int max_lds = 0;
-    if (hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device) == hipSuccess && max_lds > 0 && smem > (size_t)max_lds)
-      return set_error(ctx, GACQ_ERR_UNSUPPORTED, "split engine: %d team(s) of M=%d need %zu bytes of LDS per workgroup, the device allows %d",
-                       teams, M, smem, max_lds);
-  }
-#define GACQ_LAUNCH_INNER(KERN, NT)                                                                                                 \
-  do {                                                                                                                              \
-    GACQ_HIP(ctx, hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                   \
-    hipLaunchKernelGGL(KERN, grid, dim3((NT) * teams), smem, ctx->stream, X, C, Z, d_items, d_fset, twm, g0, ng, ep_first, nblk_ep, pch, P, F, D, \
-                       B, R, Mp);                                                                                                   \
-  } while (0)
-#define GACQ_LAUNCH_DT(R1_, R2_, NT_, TEAMS_)                                                                                        \
-  do {                                                                                                                              \
-    if (dt == 3) GACQ_LAUNCH_INNER((split_inner_corr_kernel<11, R1_, R2_, 1, NT_, TEAMS_, 3>), NT_);                                \
-    else if (dt == 2) GACQ_LAUNCH_INNER((split_inner_corr_kernel<11, R1_, R2_, 1, NT_, TEAMS_, 2>), NT_);                           \
-    else GACQ_LAUNCH_INNER((split_inner_corr_kernel<11, R1_, R2_, 1, NT_, TEAMS_, 1>), NT_);                                        \
-  } while (0)
-  if (teams != 1 && dt != 1) return set_error(ctx, GACQ_ERR_BAD_ARG, "split engine: teams > 1 and Doppler tiles > 1 are not combined");
-  if (M == 1980) {
-    if (teams == 4) GACQ_LAUNCH_INNER((split_inner_corr_kernel<11, 12, 15, 1, 192, 4, 1>), 192);
-    else if (teams == 2) GACQ_LAUNCH_INNER((split_inner_corr_kernel<11, 12, 15, 1, 192, 2, 1>), 192);
-    else GACQ_LAUNCH_DT(12, 15, 192, 1);
-  } else if (M == 990) {
-    if (teams == 4) GACQ_LAUNCH_INNER((split_inner_corr_kernel<11, 9, 10, 1, 128, 4, 1>), 128);
-    else if (teams == 2) GACQ_LAUNCH_INNER((split_inner_corr_kernel<11, 9, 10, 1, 128, 2, 1>), 128);
-    else GACQ_LAUNCH_DT(9, 10, 128, 1);
-  } else {
-    return set_error(ctx, GACQ_ERR_UNSUPPORTED, "fused inner transforms: M=%d not supported", M);
-  }
-#undef GACQ_LAUNCH_DT
-#undef GACQ_LAUNCH_INNER
-  GACQ_HIP(ctx, hipGetLastError());
-  return GACQ_OK;
-}
 
 int split_radix(int N) {
   if (N > 0 && N % 31 == 0 && smooth(N / 31) && N / 31 >= 64) return 31;
@@ -605,34 +322,33 @@ int split_debug_nco(gacq_ctx* ctx, int N, int n, const double* d_freq, int* d_id
   return GACQ_OK;
 }
 
-int split_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng, int B, int N, float* q_out, float tie_scale, bool inner,
-                         bool twiddle_only, int Mp) {
+int split_inverse_reduce(gacq_ctx* ctx, float2* Y, RowRec* rows, long g0, long ng, int B, int N, float* q_out, float tie_scale, bool inner) {
   const int R = split_radix(N);
   if (!R) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "split engine: N=%d not supported", N);
   const int M = N / R;
-  if (Mp <= 0) Mp = M;
   // Y written by lds_inner_correlate_kernel (inner == false, M == 4096): rows in the lane-pair layout
-  const int paired = (!inner && !twiddle_only && M == 4096) ? 1 : 0;
-  if (Mp != M && !twiddle_only) return set_error(ctx, GACQ_ERR_BAD_ARG, "split engine: padded rows need the fused inner kernel");
+  const int paired = (!inner && M == 4096) ? 1 : 0;
   const float2* tw;
   int rc = base_twiddles(ctx, N, M, &tw);
   if (rc != GACQ_OK) return rc;
   const int chunks = (M + kBlock - 1) / kBlock;
-  if (inner && !twiddle_only && (rc = fft_exec(ctx, M, ng * B * R, true, Y)) != GACQ_OK) return rc;
-  if (twiddle_only) inner = true;              // Y holds untwiddled inner IFFTs: the outer kernel applies W_N^{-n2 k1}
+  if (inner && (rc = fft_exec(ctx, M, ng * B * R, true, Y)) != GACQ_OK) return rc;
   if ((rc = ensure(ctx, ctx->partial, sizeof(RowRec) * (size_t)ng * chunks)) != GACQ_OK) return rc;
   RowRec* partial = (RowRec*)ctx->partial.p;
   const float inv_n = 1.0f / (float)N;
   switch (R) {
-    case 31: rc = launch_inverse<31>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner, paired, tie_scale); break;
-    case 40: rc = launch_inverse<40>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner, paired, tie_scale); break;
-    case 20: rc = launch_inverse<20>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner, paired, tie_scale); break;
-    case 16: rc = launch_inverse<16>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner, paired, tie_scale); break;
-    default: rc = launch_inverse<4>(ctx, Y, partial, tw, M, Mp, B, ng, inv_n, q_out, inner, paired, tie_scale); break;
+    case 31: rc = launch_inverse<31>(ctx, Y, partial, tw, M, B, ng, inv_n, q_out, inner, paired, tie_scale); break;
+    case 40: rc = launch_inverse<40>(ctx, Y, partial, tw, M, B, ng, inv_n, q_out, inner, paired, tie_scale); break;
+    case 20: rc = launch_inverse<20>(ctx, Y, partial, tw, M, B, ng, inv_n, q_out, inner, paired, tie_scale); break;
+    case 16: rc = launch_inverse<16>(ctx, Y, partial, tw, M, B, ng, inv_n, q_out, inner, paired, tie_scale); break;
+    default: rc = launch_inverse<4>(ctx, Y, partial, tw, M, B, ng, inv_n, q_out, inner, paired, tie_scale); break;
   }
   if (rc != GACQ_OK) return rc;
-  hipLaunchKernelGGL(split_combine_kernel, dim3((unsigned)((ng + 127) / 128)), dim3(128), 0, ctx->stream, (const RowRec*)partial, rows,
-                     g0, ng, chunks, tie_scale);
+  return split_combine(ctx, partial, rows, g0, ng, chunks, tie_scale);
+}
+
+int split_combine(gacq_ctx* ctx, const RowRec* partial, RowRec* rows, long g0, long ng, int chunks, float tie_scale) {
+  hipLaunchKernelGGL(split_combine_kernel, dim3((unsigned)((ng + 127) / 128)), dim3(128), 0, ctx->stream, partial, rows, g0, ng, chunks, tie_scale);
   GACQ_HIP(ctx, hipGetLastError());
   return GACQ_OK;
 }

@@ -94,7 +94,7 @@ int gacq_set_stream(gacq_ctx* ctx, void* hip_stream);
  * entered a stream context; needed so that work is ordered with collectives issued on that stream. */
 int gacq_use_null_stream(gacq_ctx* ctx);
 /* Engine selection: 0 = auto, 1 = rocFFT pipeline (any N), 2 = LDS-resident FFT kernels (N = 4096, 16384),
- * 3 = split engine, outer radix 31/16/4 + rocFFT inner transforms (N = 61380, 30690, 65536, 16384),
+ * 3 = split engine, outer radix 31/16/4: prime-factor form for N = 61380 / 30690, rocFFT inner transforms otherwise (65536, 16384, ...),
  * 4 = split engine with the inner transforms on the LDS FFT kernels (N = 65536, 16384),
  * 5 = complex128 verification pipeline (any N): the rocFFT pipeline with every value in fp64 on the device, as the reference
  *     computes (numpy complex128); agrees with it to ~1e-12 and is what a near-tie disagreement of an fp32 engine is bisected
@@ -106,16 +106,18 @@ int gacq_set_engine(gacq_ctx* ctx, int engine);
 int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes);
 /* Tuning switches of the launch path.  They are ctx state set through this call; nothing in the library reads the
  * environment.  Defaults in brackets. */
-#define GACQ_OPT_FUSED_INNER 0  /* [1] engine 3: conj-multiply fused into the Stockham inner inverse transforms         */
+#define GACQ_OPT_FUSED_INNER 0  /* [1] engine 3, N = 61380 / 30690: 1 = prime-factor form (no twiddles at any level, conj-multiply fused into the */
+                                /*     in-place inner inverse transforms; gacq_pfa.hip); 0 = Cooley-Tukey form with rocFFT inner transforms    */
+                                /*     (other arithmetic: the cross-check)                                                                     */
 #define GACQ_OPT_FUSED_16K 1    /* [1] N = 16384 with one carrier per item: forward + correlate in one kernel           */
 #define GACQ_OPT_LDS_VARIANT 2  /* retired (round 3): the build carries one instantiation of lds_correlate_kernel; accepted, ignored   */
 #define GACQ_OPT_LDS_PCH 3      /* [0 = auto] items per workgroup of the LDS correlate kernels                          */
 #define GACQ_OPT_SPLIT_PCH 4    /* [0 = auto] (epoch, item) rows per workgroup of the split engines' inner kernels      */
-#define GACQ_OPT_SPLIT_TEAMS 5  /* [0 = auto] rows (teams of waves) per workgroup of the Stockham inner kernel: 1, 2 or 4  */
+#define GACQ_OPT_SPLIT_TEAMS 5  /* retired (round 5): belonged to the Stockham inner kernel the prime-factor engine replaced; accepted, ignored */
 #define GACQ_OPT_FUSED_4K 6     /* [1] N = 4096, B = 1, one carrier, >= 1024 (epoch, Doppler) units: forward + correlate in  */
                                 /*     one kernel (no forward-spectra buffer); 2 = also for small batches                    */
-#define GACQ_OPT_SPLIT_DT 7      /* [0 = auto] Doppler bins per workgroup of the Stockham inner kernel (1, 2 or 3): every      */
-                                /*     code-spectrum row fetched serves that many correlation rows                           */
+#define GACQ_OPT_SPLIT_DT 7      /* [0 = auto] Doppler bins per workgroup of the prime-factor engine's inner kernel (1, 2 or 3): every   */
+                                /*     code-spectrum row fetched serves that many correlation rows                                         */
 #define GACQ_OPT_FE_GENERIC 8    /* [0] front-end: 1 = run the any-length mix + FIR kernels even for the reference's 161-tap filter     */
                                 /*     (the specialised kernels produce the same bits; this is the A/B and test switch)              */
 #define GACQ_OPT_LDS_UGROUP 9    /* [0 = auto, <= 64] N = 16384 correlate kernel: (epoch, Doppler) units a workgroup walks with one item's  */
@@ -138,7 +140,11 @@ int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes);
                                 /*     answer and are counted in gacq_get_tie_stats()[2]                                                    */
 #define GACQ_OPT_FUSED_C128 16     /* [1] engine 5, N = 4096, B = 1, one carrier: the whole complex128 search row in one workgroup (one kernel     */
                                 /*     instead of the five-stage rocFFT double-precision pipeline); 0 = always the pipeline                  */
-#define GACQ_NOPTS 17
+#define GACQ_OPT_SPLIT_MFMA 17     /* [0] prime-factor engine: the inverse DFT-31 of the outer stage as two real 16 x 16 matrices on the       */
+                                /*     matrix pipe (v_mfma_f32_16x16x4_f32, exact fp32) instead of packed math on the VALU.  Off: measured     */
+                                /*     12-18 % slower -- the stage is paced by its load stream, not by arithmetic                             */
+                                /*     (profiles/r05_engine3_prime_factor_vs_cooley_tukey_ab.log)                                             */
+#define GACQ_NOPTS 18
 int gacq_set_option(gacq_ctx* ctx, int option, long value);
 int gacq_get_option(gacq_ctx* ctx, int option, long* value);
 
@@ -311,7 +317,7 @@ int gacq_debug_row(gacq_sig* sig, const float* x_iq, size_t nsamp, int item, dou
  * table lookup (the kernels are instantiated in a dump mode that stores the index instead of using it).  Index work is
  * bit-exact against the reference; a wrong index moves the metric by less than the 1e-5 tolerance, so it gets its own check.
  * kernel: 1 mix_nco_kernel (rocFFT pipeline), 2 lds_forward_kernel / lds16k_forward_kernel, 3 split_outer_forward_kernel,
- *         4 lds16k_fused_kernel.  GACQ_ERR_UNSUPPORTED when that kernel does not serve the signal's N. */
+ *         4 lds16k_fused_kernel, 5 pfa_outer_forward_kernel.  GACQ_ERR_UNSUPPORTED when that kernel does not serve the signal's N. */
 int gacq_debug_nco_indices(gacq_sig* sig, int kernel, double doppler, double bias_hz, int* idx_out);
 
 #ifdef __cplusplus

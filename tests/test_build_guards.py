@@ -49,7 +49,8 @@ def test_kernels_with_lds_separators_use_no_accumulator_registers_and_hot_kernel
     with_agprs = sorted(k for k, m in kernels.items() if m["agpr_count"])
     assert with_agprs and all("tie_recheck" in k for k in with_agprs), with_agprs
     for fragment in ("lds_fused4k_kernelILi4ELb1ELb0", "lds16k_correlate_kernelILb0", "fused4k_c128_kernel", "lds_inner_correlate_kernel",
-                     "lds_correlate_kernelILi2E", "split_inner_corr_kernelILi11ELi12ELi15ELi1ELi192ELi1ELi2E"):
+                     "lds_correlate_kernelILi2E", "pfa_inner_corr_kernelILi1980ELi3E", "pfa_inner_corr_kernelILi990ELi2E",
+                     "pfa_outer_inverse_kernelILi1980ELi0E", "pfa_outer_inverse_kernelILi990ELi2E", "pfa_outer_inverse_mfma_kernelILi1980ELi0E"):
         hit = [k for k in kernels if fragment in k]
         assert hit, fragment
         for k in hit:

@@ -638,17 +638,27 @@ R31_CASES = ["cfg4_l5i_subset", "l5q_subset", "cfg4_b2ad_b80", "gal_e6b", "gal_e
              "xona_x5p", "bds_b2ap", "bds_b2bq", "gal_e5ai", "gal_e5aq", "gal_e5bi", "gal_e6c", "glo_l3ocp"]
 
 
+# engine 3 at N = 61380 / 30690: the prime-factor form with the DFT-31 on the VALU (default) / on the matrix pipe, and the
+# Cooley-Tukey form with rocFFT inner transforms (GACQ_OPT_FUSED_INNER 0) -- next to the rocFFT pipeline four different arithmetic paths
+R31_FORMS = {"rocfft-pipeline": (1, 1, 0), "pfa-valu": (3, 1, 0), "pfa-mfma": (3, 1, 1), "ct-rocfft": (3, 0, 0)}
+
+
 @pytest.mark.parametrize("cid", R31_CASES)
-@pytest.mark.parametrize("eng", [1, 3])
-def test_radix31_split_and_rocfft_match_reference_golden(engine, golden_cases, cid, eng):
-    """N = 61380 / 30690: rocFFT (Bluestein) pipeline (1) and the radix-31 split engine (3) separately."""
+@pytest.mark.parametrize("form", sorted(R31_FORMS))
+def test_radix31_split_and_rocfft_match_reference_golden(engine, golden_cases, cid, form):
+    """N = 61380 / 30690: rocFFT (Bluestein) pipeline (1) and every form of the radix-31 split engine (3) separately."""
     case = golden_cases[cid]
     x = case_iq(case)
+    eng, fused, mfma = R31_FORMS[form]
     engine.set_engine(eng)
+    engine.set_option("fused_inner", fused)
+    engine.set_option("split_mfma", mfma)
     try:
         got = engine.search_all(case["script"], x, case["items"], case["doppler_search"], case["ms"])
     finally:
         engine.set_engine(0)
+        engine.set_option("fused_inner", 1)
+        engine.set_option("split_mfma", 0)
     _assert_results(got, case["results"], case)
 
 
@@ -659,22 +669,26 @@ def test_radix31_rows_match_oracle(engine):
     for name, prn, dop, B in [("gps-l5i", 7, 1600.0, 2), ("xona-x5p", 0, -400.0, 3), ("galileo-e6c", 4, 200.0, 1)]:
         sig = signals.get(name)
         x = synth.make_iq(sig, B, 4711, [(prn, 0.3, dop - 63.0, 1201)])
-        engine.set_engine(3)
-        try:
-            q = engine.debug_row(sig, x, prn, dop, B)
-        finally:
-            engine.set_engine(0)
         want = acq_oracle.search_row(x.astype(np.complex128), codes_oracle.chips(sig.code, prn), dop, B, fs=sig.fs, n=sig.n,
                                      pad=sig.pad, boc=sig.boc)
-        assert int(np.argmax(q)) == int(np.argmax(want)), name
-        err = np.max(np.abs(q.astype(np.float64) - want)) / np.max(want)
-        assert err < 5e-6, (name, err)
-        assert np.sum(q.astype(np.float64)) == pytest.approx(np.sum(want), rel=1e-5)
+        for mfma in (0, 1):                          # the lag labels of both inverse outer kernels of the prime-factor form
+            engine.set_engine(3)
+            engine.set_option("split_mfma", mfma)
+            try:
+                q = engine.debug_row(sig, x, prn, dop, B)
+            finally:
+                engine.set_engine(0)
+                engine.set_option("split_mfma", 0)
+            assert int(np.argmax(q)) == int(np.argmax(want)), (name, mfma)
+            err = np.max(np.abs(q.astype(np.float64) - want)) / np.max(want)
+            assert err < 5e-6, (name, mfma, err)
+            assert np.sum(q.astype(np.float64)) == pytest.approx(np.sum(want), rel=1e-5)
 
 
 def test_radix31_code_spectrum_is_a_permutation_of_the_natural_one(engine):
-    """Engine 3 stores spectra as [k1][k2] with k = k1 + 31 k2; searching with engines 1 and 3 on noise-only input must
-    locate identically (near ties included) -- a wrong permutation or twiddle would scramble the correlation."""
+    """Engine 3 stores spectra in its own order (the prime-factor maps of gacq_pfa.hip, or [k1][k2] with k = k1 + 31 k2 for the
+    Cooley-Tukey form); searching with engines 1 and 3 on noise-only input must locate identically (near ties included) -- a wrong
+    index map would scramble the correlation."""
     from gnss_dsp_tools_amd import signals, synth
     sig = signals.get("gps-l5i")
     x = synth.make_iq(sig, 1, 2024, [])
@@ -865,8 +879,8 @@ def test_epoch_chunking_with_small_workspace():
 
 @pytest.mark.parametrize("name,items,B", [("gps-l5i", [7, 8, 9], 1), ("galileo-e6b", [2, 3, 4], 2)])
 @pytest.mark.parametrize("dt", [1, 2, 3])
-def test_stockham_doppler_tiles_with_group_chunks_not_aligned_to_the_tile(engine, name, items, B, dt):
-    """GACQ_OPT_SPLIT_DT: a workgroup of the Stockham inner kernel serves dt consecutive Doppler bins.  13 bins (not a multiple of 2
+def test_inner_kernel_doppler_tiles_with_group_chunks_not_aligned_to_the_tile(engine, name, items, B, dt):
+    """GACQ_OPT_SPLIT_DT: a workgroup of the prime-factor engine's inner kernel serves dt consecutive Doppler bins.  13 bins (not a multiple of 2
     or 3) and a workspace that holds the forward spectra plus a handful of correlation rows, so that the (epoch, item, Doppler)
     group chunks start and end inside a tile: byte-identical records to the roomy single pass with one bin per workgroup."""
     import torch
@@ -1005,10 +1019,10 @@ def test_doppler_slicing_when_one_epoch_exceeds_the_workspace(engine):
         small.close()
 
 
-NCO_KERNELS = {            # (fs, N) -> (script, forward kernels that serve this length: 1 mix_nco, 2 LDS, 3 split outer, 4 fused 16K)
+NCO_KERNELS = {            # (fs, N) -> (script, forward kernels that serve this length: 1 mix_nco, 2 LDS, 3 split outer, 4 fused 16K, 5 prime-factor outer)
     (4096000.0, 4096): ("gps-l1", (1, 2)),
     (8192000.0, 65536): ("galileo-e1b", (1, 3)),
-    (30690000.0, 61380): ("gps-l5i", (1, 3)),
+    (30690000.0, 61380): ("gps-l5i", (1, 3, 5)),
     (16384000.0, 16384): ("glonass-l1", (1, 2, 3, 4)),
     (8192000.0, 16384): ("beidou-b1i", (1, 2, 3, 4)),
 }
@@ -1033,7 +1047,7 @@ def test_device_nco_indices_are_bit_exact(engine, golden_nco):
             assert [int(i) for i in idx[:16]] == v["head"] and [int(i) for i in idx[-16:]] == v["tail"], (script, k, v["doppler"])
             assert hashlib.sha256(idx.tobytes()).hexdigest() == v["sha256"], (script, k, v["doppler"])
             checked += 1
-    assert checked == 6 * 2 + 3 * 2 + 3 * 2 + 2 * 4 + 2 * 4 + 2 * 4
+    assert checked == 6 * 2 + 3 * 2 + 3 * 3 + 2 * 4 + 2 * 4 + 2 * 4
     with pytest.raises(nat.GacqError) as ei:             # no LDS forward kernel for N = 65536
         engine.signal("galileo-e1b", [1]).nco_indices(2, 125.0)
     assert ei.value.code == -9
@@ -1313,21 +1327,21 @@ def test_full_size_configs_agree_with_the_complex128_pipeline(engine, cfg, name,
     assert float(rel[same].max()) <= 2e-6, (cfg, name, float(rel[same].max()))
 
 
-@pytest.mark.parametrize("cid", ["cfg4_l5i_subset", "gal_e6b", "bds_b2bq"])
-@pytest.mark.parametrize("teams", [1, 2, 4])
-def test_stockham_inner_kernel_teams_match_reference_golden(engine, golden_cases, cid, teams):
-    """The Stockham inner kernel with 1, 2 or 4 rows (teams of waves) per workgroup sharing one set of twiddle tables, incl. item
-    counts that are not multiples of the team count (idle teams walk through the barriers)."""
+@pytest.mark.parametrize("cid", ["cfg4_l5i_subset", "gal_e6b", "bds_b2bq", "xona_x5p"])
+@pytest.mark.parametrize("mfma", [0, 1])
+def test_prime_factor_inner_kernel_item_chunks_match_reference_golden(engine, golden_cases, cid, mfma):
+    """The prime-factor inner kernel with item chunks that do not divide the item count (the tail of a chunk is skipped row by row,
+    the code-spectrum prefetch runs past it) and both outer inverse kernels, raw and max/mean metric (xona_x5p), one and several blocks."""
     case = golden_cases[cid]
     x = case_iq(case)
-    engine.set_option("split_teams", teams)
+    engine.set_option("split_mfma", mfma)
     try:
-        for pch in (0, 3):
+        for pch in (0, 3, 1):
             engine.set_option("split_pch", pch)
             got = engine.search_all(case["script"], x, case["items"], case["doppler_search"], case["ms"])
             _assert_results(got, case["results"], case)
     finally:
-        engine.set_option("split_teams", 0)
+        engine.set_option("split_mfma", 0)
         engine.set_option("split_pch", 0)
 
 

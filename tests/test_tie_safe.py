@@ -200,7 +200,7 @@ def test_reevaluation_buffers_survive_changing_capacities(fresh):
 def test_option_ranges_are_validated(fresh):
     """gacq_set_option rejects values outside an option's range instead of storing them."""
     from gnss_dsp_tools_amd import _native as nat
-    for opt, bad in (("lds_pch", -1), ("lds_pch", 100000), ("lds_ugroup", -3), ("split_teams", 3), ("tie_eps_ppb", -5), ("fused_4k", 7),
+    for opt, bad in (("lds_pch", -1), ("lds_pch", 100000), ("lds_ugroup", -3), ("split_teams", 5), ("split_mfma", 2), ("fused_inner", 2), ("tie_eps_ppb", -5), ("fused_4k", 7),
                      ("tie_cap", 1 << 30)):
         with pytest.raises(nat.GacqError):
             fresh.set_option(opt, bad)

@@ -37,10 +37,8 @@ def draw(rng):
     B = int(rng.choice([1, 1, 2, 3])) if sig.nfft < 100000 else 1
     E = int(rng.choice([1, 2, 3, 5] if not big else [1, 2]))
     opts = {"lds_pch": int(rng.choice([0, 1, 3, 8])), "split_pch": int(rng.choice([0, 1, 3, 5])), "fused_4k": int(rng.choice([0, 1, 2])),
-            "fused_16k": int(rng.choice([0, 1])), "fused_inner": int(rng.choice([0, 1, 1, 1])), "split_teams": int(rng.choice([0, 0, 2, 4])),
+            "fused_16k": int(rng.choice([0, 1])), "fused_inner": int(rng.choice([0, 1, 1, 1])), "split_mfma": int(rng.choice([0, 0, 1])),
             "split_dt": int(rng.choice([0, 1, 2, 3])), "search1": int(rng.choice([0, 1, 1])), "lds_ugroup": int(rng.choice([0, 1, 2, 3]))}
-    if opts["split_teams"] > 1:
-        opts["split_dt"] = 1
     row = 8 * sig.nfft * B
     ws = int(rng.choice([row // 2, 3 * row, 3 * row * D + 7 * row, 64 * row * D]))
     seed = int(rng.integers(1, 1 << 30))
@@ -84,14 +82,15 @@ def main():
         n += 1
         searches += E * len(items)
         by_n[sig.nfft] = by_n.get(sig.nfft, 0) + 1
-        if sig.nfft % 31 == 0 and not opts["fused_inner"]:
-            # rocFFT instead of the Stockham kernel for the inner inverse transforms: other arithmetic, same answers within rounding
+        if sig.nfft % 31 == 0 and (not opts["fused_inner"] or opts["split_mfma"]):
+            # Cooley-Tukey form with rocFFT inner transforms instead of the prime-factor form, or its DFT-31 on the matrix pipe: other
+            # arithmetic, same answers within rounding
             qa, qb = a.view(acquire.PEAK_DTYPE).reshape(-1), b.view(acquire.PEAK_DTYPE).reshape(-1)
             relb = np.abs(qa["metric"] - qb["metric"]) / np.maximum(np.abs(qa["metric"]), 1e-30)
             moved = (qa["idx"] != qb["idx"]) | (qa["d_index"] != qb["d_index"])
             if (relb > 2e-6).any() or (moved & (relb > 1e-6)).any():
                 bugs += 1
-                print("MISMATCH fused vs rocFFT inner transforms:", float(relb.max()), json.dumps(desc), flush=True)
+                print("MISMATCH prime-factor form vs its other forms:", float(relb.max()), json.dumps(desc), flush=True)
         elif a.tobytes() != b.tobytes():
             bugs += 1
             print("MISMATCH default vs switches/workspace:", json.dumps(desc), flush=True)
