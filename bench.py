@@ -518,6 +518,7 @@ def main():
                     help="weak: N x EPOCHS epochs per step; strong: EPOCHS epochs per step whatever N is")
     ap.add_argument("--engine", type=int, default=0, help="0 auto, 1 rocFFT pipeline, 2 LDS FFT kernels, 3/4 split engines")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="gacq_set_option tuning switch (e.g. lds_variant=3)")
+    ap.add_argument("--distinct-epochs", type=int, default=0, help="N = 4096 signals: distinct seeded epochs per step, tiled to the batch (default: all 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lanes", type=int, default=1,
                     help="engine contexts / HIP streams the independent steps alternate between (2 fills the correlate kernel's tail, "
@@ -611,7 +612,7 @@ def main():
         dist.destroy_process_group()
 
 
-def build_jobs(cfg, E_total, dev):
+def build_jobs(cfg, E_total, dev, distinct=0):
     """One job per signal of a BASELINE configuration, samples resident in HBM."""
     from gnss_dsp_tools_amd import acquire, signals, synth
     jobs = []
@@ -624,8 +625,11 @@ def build_jobs(cfg, E_total, dev):
         flat = [it for lst in items for it in lst] if family else list(items)
         sats = synth.default_sats(items[0] if family else items)     # family: satellites of the first signal (first rows of the stack)
         nsamp = sig.samples_needed(B)
-        # a few distinct seeded epochs tiled to the batch (content does not change the work)
-        base = synth.make_epochs(sig, B, synth.BASE_SEED + cfg["seed"] + 100 * len(jobs), sats, min(8 if sig.nfft <= 4096 else 2, E_total), nsamp=nsamp)
+        # N = 4096 (the headline): every epoch of the step is its own seeded noise realisation (32 MB for 1024 epochs), so that the
+        # ~2e-4 near-ties per noise-only search of real data are in the timed region and the tie-safe re-evaluation actually runs
+        # (round 4 tiled 8 epochs 128 x: 256 distinct noise-only searches, none of them ambiguous).  The long lengths tile two epochs
+        # (content does not change the work there and an epoch is 0.5-1.5 MB of host arithmetic).
+        base = synth.make_epochs(sig, B, synth.BASE_SEED + cfg["seed"] + 100 * len(jobs), sats, min((distinct or 1024) if sig.nfft <= 4096 else 2, E_total), nsamp=nsamp)
         xs = np.concatenate([base] * ((E_total + len(base) - 1) // len(base)))[:E_total]
         jobs.append({"sig": sig, "name": sig, "family": family, "items": items, "flat": flat, "P": len(flat), "cpu_items": cpu_items, "ds": ds, "ms": ms,
                      "B": B, "dop": dop, "dopplers": dop, "blocks": B, "sats": sats, "host": base, "xs": xs,
@@ -763,7 +767,7 @@ def run(args, env):
     cfg = CONFIGS[args.config]
     epochs = args.epochs or cfg["epochs"]
     E_total = epochs * world if args.scaling == "weak" else epochs
-    jobs = build_jobs(cfg, E_total, dev)
+    jobs = build_jobs(cfg, E_total, dev, args.distinct_epochs)
     cells_step = sum(E_total * j["P"] * len(j["dop"]) * j["sig"].nfft for j in jobs)
     cell_blocks_step = sum(E_total * j["P"] * len(j["dop"]) * j["sig"].nfft * j["B"] for j in jobs)
 
@@ -1096,8 +1100,27 @@ def run(args, env):
         # re-evaluation launches); the counters say how many pairs of this run needed the complex128 re-evaluation -- the bench's
         # epochs carry strong injected satellites, so usually none (tools/tie_census.py is the noise-only census)
         try:
-            out["tie_safe"] = dict(lanes[0][1].tie_stats(), enabled=bool(lanes[0][1].get_option("tie_safe")),
-                                   eps=lanes[0][1].get_option("tie_eps_ppb") * 1e-9)
+            eng_t = lanes[0][1]
+            before = eng_t.tie_stats()
+            run_steps(1)                                           # one more (untimed) step on lane 0: the counters of exactly one step
+            torch.cuda.synchronize(dev)
+            after = eng_t.tie_stats()
+            out["tie_safe"] = dict(after, enabled=bool(eng_t.get_option("tie_safe")), eps=eng_t.get_option("tie_eps_ppb") * 1e-9,
+                                   distinct_epochs_per_step=int(sum(len(j["host"]) for j in jobs)),
+                                   per_step={k: after[k] - before[k] for k in before})
+            if after["kept_fp32"]:
+                out["tie_safe"]["warning"] = ("%d ambiguous pairs kept their fp32 answer (re-evaluation list full or unsupported length): raise "
+                                              "GACQ_OPT_TIE_CAP" % after["kept_fp32"])
+            if out["tie_safe"]["enabled"] and world == 1:
+                # what the tie-safe machinery costs: the same steps with it switched off, same process, right after the timed region
+                for _, e_l, _ in lanes:
+                    e_l.set_option("tie_safe", 0)
+                try:
+                    _, dt_off = timed(args.steps)
+                finally:
+                    for _, e_l, _ in lanes:
+                        e_l.set_option("tie_safe", 1)
+                out["tie_safe"]["ms_per_step_with_tie_safe_off"] = dt_off / args.steps * 1e3
         except Exception as exc:
             out["tie_safe"] = {"error": repr(exc)[:200]}
         if args.config == 2:            # keep the flat stage table of the single-signal line (profiles/)

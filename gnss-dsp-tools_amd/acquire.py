@@ -213,11 +213,13 @@ class Engine:
         """Map reference 'items' (PRNs, or GLONASS channels) to (AcqSignal, item indices, per-item bias).  The last plan is kept: a
         scan calls search_all with the same item list for every block of samples."""
         sig = _signals.get(name) if isinstance(name, str) else name
-        key = (sig.name, id(sig), tuple(items))          # id: a caller-made descriptor may reuse the name of a built-in one
-        if getattr(self, "_plan_key", None) == key:
+        key = (sig.name, tuple(items))
+        # identity, not id(): a caller-made descriptor may reuse the name of a built-in one, and the cache entry holds a reference to its
+        # descriptor so that a collected one cannot be impersonated by a new object at the same address
+        if getattr(self, "_plan_key", None) == key and getattr(self, "_plan_sig", None) is sig:
             return self._plan_val
         val = self._plan_uncached(sig, items)
-        self._plan_key, self._plan_val = key, val
+        self._plan_key, self._plan_sig, self._plan_val = key, sig, val
         # ctypes views of the index / bias arrays and a reusable result buffer: numpy's .ctypes accessor costs ~1 us per use, which shows
         # on the single-search latency path
         _, idx, bias = val
@@ -410,6 +412,7 @@ class Engine:
         sig = _signals.get(name) if isinstance(name, str) else name
         if not torch.is_tensor(iq_int8):
             iq_int8 = torch.from_numpy(np.array(iq_int8, dtype=np.int8, copy=True)).to("cuda:%d" % self.device)
+        self.use_torch_stream(iq_int8.device)            # see mix_int8_dev: torch-owned temporaries and the context's stream
         iq_int8 = iq_int8.contiguous().view(-1)
         n_in = iq_int8.numel() // 2
         per_ms = int(round(sig.fs * 0.001))
@@ -428,6 +431,9 @@ class Engine:
         import torch
         if not torch.is_tensor(iq_int8):
             iq_int8 = torch.from_numpy(np.array(iq_int8, dtype=np.int8, copy=True)).to("cuda:%d" % self.device)
+        # the kernel runs on the context's stream: make that torch's current stream, so that the caching allocator cannot hand the
+        # temporary above (dropped on return) or `out` to another torch allocation while the kernel still uses them
+        self.use_torch_stream(iq_int8.device)
         iq_int8 = iq_int8.contiguous().view(-1)
         n = iq_int8.numel() // 2
         out = torch.empty(n, dtype=torch.complex64, device=iq_int8.device)

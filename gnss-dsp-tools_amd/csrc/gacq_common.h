@@ -209,7 +209,7 @@ int pfa_debug_nco(gacq_ctx* ctx, int N, int n, const double* d_freq, int* d_idx)
 bool tie_supported(int N);                       // prime factors of N in {2, 3, 5, 7, 11, 13, 31}: every FFT length of the reference's scripts
 float tie_scale_of(const gacq_ctx* ctx);            // 1 - eps from GACQ_OPT_TIE_EPS_PPB
 int tie_prepare(gacq_sig* sig);                  // complex128 code spectra on first use
-int tie_lists(gacq_ctx* ctx, long nep, TieLists* out, gacq_peak** guesses);
+int tie_lists(gacq_ctx* ctx, long nep, int N, int B, TieLists* out, gacq_peak** guesses);      // capacity bounded by the memory budget of the re-evaluation
 int tie_resolve(gacq_sig* sig, const TieLists& tl, const gacq_peak* guesses, const float2* d_x, size_t nsamp, int P, int D, int B, gacq_peak* d_out);
 
 // Running (maximum, first argmax, runner-up) of magnitudes visited in ascending lag order, and the merge of two such partial results.

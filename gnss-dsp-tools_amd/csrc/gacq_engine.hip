@@ -879,7 +879,7 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
   gacq_peak* guesses = nullptr;
   if (tie) {
     if ((rc = tie_prepare(sig)) != GACQ_OK) return rc;
-    if ((rc = tie_lists(ctx, (long)nepoch * P, &tl, &guesses)) != GACQ_OK) return rc;
+    if ((rc = tie_lists(ctx, (long)nepoch * P, N, B, &tl, &guesses)) != GACQ_OK) return rc;
   }
 
   // epochs per pass so that the forward-spectra buffer respects the workspace limit
@@ -1179,7 +1179,7 @@ int gacq_merge_peaks_tiesafe_dev(gacq_sig* sig, const void* d_x, size_t nsamp, i
   TieLists tl{};
   gacq_peak* guesses = nullptr;
   if ((rc = tie_prepare(sig)) != GACQ_OK) return rc;
-  if ((rc = tie_lists(ctx, n, &tl, &guesses)) != GACQ_OK) return rc;
+  if ((rc = tie_lists(ctx, n, sig->N, blocks, &tl, &guesses)) != GACQ_OK) return rc;
   hipLaunchKernelGGL(merge_peaks_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const gacq_peak*)d_peaks,
                      (gacq_peak*)d_out, n, nshard, (const int*)ctx->d0.p, tl, guesses, tie_scale_of(ctx));
   GACQ_HIP(ctx, hipGetLastError());

@@ -503,9 +503,20 @@ bool tie_supported(int N) {
   return factorise(N, rad);
 }
 
-int tie_capacity(const gacq_ctx* ctx, long nep) {
-  if (ctx->opt[GACQ_OPT_TIE_CAP] > 0) return (int)std::min<long>(ctx->opt[GACQ_OPT_TIE_CAP], 1L << 24);
-  return (int)std::min<long>(64 + nep / 16, 1L << 20);
+// What the re-evaluation may allocate next to the search's own workspaces: an eighth of the workspace limit the caller has set
+// (gacq_set_workspace_limit), between 32 and 256 MiB.  The row buffers of tie_resolve are sized for the LIST CAPACITY (the host does
+// not know how many rows a launch will flag), so the capacity itself is bounded by this budget: pairs beyond it keep their fp32
+// answer and are counted (gacq_get_tie_stats()[2]) -- for the long lengths a handful of rows per call is what real data produces.
+size_t tie_budget(const gacq_ctx* ctx) {
+  return std::min<size_t>((size_t)256 << 20, std::max<size_t>((size_t)32 << 20, ctx->ws_limit / 8));
+}
+
+int tie_capacity(const gacq_ctx* ctx, long nep, int N, int B) {
+  long cap = ctx->opt[GACQ_OPT_TIE_CAP] > 0 ? std::min<long>(ctx->opt[GACQ_OPT_TIE_CAP], 1L << 24) : std::min<long>(64 + nep / 16, 1L << 20);
+  // per listed row: B per-block magnitude rows in fp64 (+ the twiddled inner transforms of the split kernels)
+  const size_t row = (size_t)std::max(1, B) * (size_t)N * (sizeof(double) + ((N == 4 * gacq::f64::kN || N == 16 * gacq::f64::kN) ? sizeof(double2) : 0)) + 64;
+  cap = std::min<long>(cap, (long)std::max<size_t>(16, tie_budget(ctx) / row));
+  return (int)cap;
 }
 
 float tie_scale_of(const gacq_ctx* ctx) {
@@ -514,8 +525,8 @@ float tie_scale_of(const gacq_ctx* ctx) {
 }
 
 // layout of ctx->tie: [TieCounters | fp32 guesses (gacq_peak x cap) | TieEp x cap | TieRow x cap | TieRec x cap]
-int tie_lists(gacq_ctx* ctx, long nep, TieLists* out, gacq_peak** guesses) {
-  const int cap = tie_capacity(ctx, nep);
+int tie_lists(gacq_ctx* ctx, long nep, int N, int B, TieLists* out, gacq_peak** guesses) {
+  const int cap = tie_capacity(ctx, nep, N, B);
   const size_t bytes = 64 + (size_t)cap * (sizeof(unsigned) * 2 + sizeof(gacq_peak) + sizeof(TieEp) + sizeof(TieRow) + sizeof(TieRec));
   if (cap > ctx->tie_cap || !ctx->tie.p) {
     TieCounters keep{};
@@ -589,16 +600,17 @@ int tie_resolve(gacq_sig* sig, const TieLists& tl, const gacq_peak* guesses, con
   const int Rs = (N == 4 * gacq::f64::kN) ? 4 : ((N == 16 * gacq::f64::kN) ? 16 : 0);
   const size_t split_bytes = (size_t)tl.cap * B * ((size_t)N * (sizeof(double) + sizeof(double2)) + 64);
   // B > 1: the blocks of a listed row are evaluated side by side by B workgroups when their per-block magnitude rows
-  // (capacity x B x N fp64 values) fit into 256 MiB; otherwise one workgroup takes the row's blocks in sequence (same bits)
+  // (capacity x B x N fp64 values) fit into the budget; otherwise one workgroup takes the row's blocks in sequence (same bits)
   double* qb = nullptr;
   const size_t qb_bytes = (size_t)tl.cap * B * N * sizeof(double);
-  if (B > 1 && qb_bytes <= ((size_t)256 << 20) && !(Rs && split_bytes <= ((size_t)768 << 20))) {
+  const size_t budget = tie_budget(ctx);
+  if (B > 1 && qb_bytes <= budget && !(Rs && split_bytes <= budget)) {
     if ((rc = ensure(ctx, ctx->tie_q, qb_bytes)) != GACQ_OK) return rc;
     qb = (double*)ctx->tie_q.p;
     // the per-row arrival counters are left at zero by the kernel; cleared per launch all the same (see above)
     GACQ_HIP(ctx, hipMemsetAsync(tl.done, 0, sizeof(unsigned) * (size_t)tl.cap, ctx->stream));
   }
-  if (Rs && split_bytes <= ((size_t)768 << 20)) {
+  if (Rs && split_bytes <= budget) {
     // per-(row, block) arrival counters in a buffer of their own (inside the data buffer their place would move with the capacity
     // and land on stale row data).  The kernels leave them at zero; they are cleared per launch all the same (a few KB): a faulted
     // or aborted launch must not leave the next one waiting on stale counts
@@ -632,9 +644,9 @@ int tie_resolve(gacq_sig* sig, const TieLists& tl, const gacq_peak* guesses, con
     GACQ_HIP(ctx, hipGetLastError());
     return GACQ_OK;
   }
-  // workgroups in flight: enough to take a burst of rows side by side, bounded by 64 MiB of row scratch (40 bytes per point)
+  // workgroups in flight: enough to take a burst of rows side by side, bounded by 64 MiB (or the budget) of row scratch (40 bytes per point)
   const size_t row_bytes = (size_t)N * 40;
-  const int G = (int)std::max<size_t>(4, std::min<size_t>(64, ((size_t)64 << 20) / row_bytes));
+  const int G = (int)std::max<size_t>(4, std::min<size_t>(64, std::min<size_t>((size_t)64 << 20, budget) / row_bytes));
   if ((rc = ensure(ctx, ctx->tie_scratch, row_bytes * G)) != GACQ_OK) return rc;
   hipLaunchKernelGGL(tie_recheck_kernel, dim3((unsigned)G), dim3(kTieThreads), 0, ctx->stream, tl, tl.done, qb, d_x, nsamp,
                      (const double2*)sig->spectra64, (const int*)ctx->items.p, (const int*)ctx->fset.p, (const double*)ctx->freq.p, tab64, WN,

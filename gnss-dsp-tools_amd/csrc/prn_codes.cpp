@@ -2,8 +2,9 @@
 //
 // One table-driven generator per code family; every family is registered under the name of the
 // reference module that defines it ("gps.ca" == gnsstools/gps/ca.py ...).  Chips are {0,1} bytes and
-// must be BIT-EXACT with the reference; tests/test_codes.py pins them
-// against SHA-256 goldens generated from the reference and against the ICD known-answer vectors.
+// must be BIT-EXACT with the reference; tests/test_native_cpu.py and
+// tests/test_driver_visible_parity.py pin all 2355 PRNs against SHA-256 goldens generated from the reference
+// (tests/golden/chips_sha256.json) and against the ICD known-answer vectors (tests/golden/icd_kat.json).
 //
 // Register convention used by every shift-register family below: bit i of `s` is stage x[i];
 // one shift inserts the feedback at stage 0 and moves stage i-1 -> i (the reference's

@@ -14,6 +14,20 @@ import numpy as np
 from . import acquire
 
 
+def _stamp(x):
+    """(tensor, version counter) of a sample tensor at launch time (None for non-torch inputs of the CPU tests)."""
+    return (x, x._version) if hasattr(x, "_version") else None
+
+
+def _check_unmodified(stamp):
+    """The tie-safe merge re-evaluates near-tied shard winners in complex128 FROM THE SAMPLES, at wait() time: a caller that refills
+    the sample tensor in place between launch and wait() would have step i's peaks resolved against step i+1's samples.  torch counts
+    in-place writes per tensor, so that mistake is caught here instead of producing silently wrong locations."""
+    if stamp is not None and stamp[0]._version != stamp[1]:
+        raise RuntimeError("sharded search: the sample tensor was modified in place between launch and wait(); the deferred tie-safe merge "
+                           "re-reads it -- keep x alive and unmodified until wait() returns (use a second buffer for the next step)")
+
+
 def doppler_bounds(nd, world):
     """Contiguous, balanced slices of the Doppler grid: rank r owns [b[r], b[r+1])."""
     return [(r * nd) // world for r in range(world + 1)]
@@ -99,12 +113,14 @@ class ShardedSearch:
     def search_batch_async(self, name, x, items, dopplers, blocks):
         """Like search_batch, but the all-gather is issued asynchronously (RCCL runs it on its own stream once the local
         kernels are done) and the merge is deferred to PendingSearch.wait().  Launching the next search before waiting on
-        the previous one overlaps the exchange of step i with the compute of step i+1."""
+        the previous one overlaps the exchange of step i with the compute of step i+1.
+        x must stay alive AND unmodified until wait() returns: the deferred tie-safe merge re-evaluates near-tied shard winners from
+        the samples (wait() raises if torch saw an in-place write to x in between)."""
         local, finish = self._launch(name, x, items, dopplers, blocks)
         if self._solo():
             return PendingSearch(local, None, None, None)
         gathered, work = self._exchange(local, async_op=True)
-        return PendingSearch(local, gathered, work, finish)
+        return PendingSearch(local, gathered, work, finish, _stamp(x))
 
     def search_jobs(self, jobs):
         """Cold-start style multi-constellation search (BASELINE config 5): `jobs` is a list of dicts
@@ -115,7 +131,8 @@ class ShardedSearch:
 
     def search_jobs_async(self, jobs, async_op=True):
         """search_jobs with the single all-gather issued asynchronously and the per-job merges deferred to
-        PendingJobs.wait(): queueing the next step before waiting puts the exchange under the next step's kernels."""
+        PendingJobs.wait(): queueing the next step before waiting puts the exchange under the next step's kernels.
+        Every job's x must stay alive and unmodified until wait() returns (see search_batch_async)."""
         import torch
         locals_, bounds, shapes = [], [], []
         for job in jobs:
@@ -152,8 +169,8 @@ class ShardedSearch:
 class PendingSearch:
     """A sharded search whose exchange may still be in flight (ShardedSearch.search_batch_async)."""
 
-    def __init__(self, local, gathered, work, finish):
-        self.local, self.gathered, self.work, self.finish = local, gathered, work, finish
+    def __init__(self, local, gathered, work, finish, stamp=None):
+        self.local, self.gathered, self.work, self.finish, self.stamp = local, gathered, work, finish, stamp
 
     def wait(self):
         """Merged peaks [nepoch, nitems, 2].  For RCCL, Work.wait() orders the current stream after the collective
@@ -162,6 +179,7 @@ class PendingSearch:
             return self.local
         if self.work is not None:
             self.work.wait()
+        _check_unmodified(self.stamp)
         return self.finish(self.gathered)
 
 
@@ -171,6 +189,7 @@ class PendingJobs:
     def __init__(self, owner, locals_, gathered, work, shapes, bounds, jobs=None):
         self.owner, self.locals_, self.gathered, self.work, self.shapes, self.bounds = owner, locals_, gathered, work, shapes, bounds
         self.jobs = jobs
+        self.stamps = [_stamp(j["x"]) for j in jobs] if (jobs and gathered is not None) else []
 
     def shards(self):
         """The un-merged exchange buffer [world, sum of job record counts * 2] (None on a single rank): what every rank
@@ -184,6 +203,8 @@ class PendingJobs:
         if self.gathered is None:
             return self.locals_
         g = self.shards()
+        for st in self.stamps:
+            _check_unmodified(st)
         out, off = [], 0
         for k, (shp, b) in enumerate(zip(self.shapes, self.bounds)):
             cnt = int(np.prod(shp))

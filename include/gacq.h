@@ -96,9 +96,10 @@ int gacq_use_null_stream(gacq_ctx* ctx);
 /* Engine selection: 0 = auto, 1 = rocFFT pipeline (any N), 2 = LDS-resident FFT kernels (N = 4096, 16384),
  * 3 = split engine, outer radix 31/16/4: prime-factor form for N = 61380 / 30690, rocFFT inner transforms otherwise (65536, 16384, ...),
  * 4 = split engine with the inner transforms on the LDS FFT kernels (N = 65536, 16384),
- * 5 = complex128 verification pipeline (any N): the rocFFT pipeline with every value in fp64 on the device, as the reference
- *     computes (numpy complex128); agrees with it to ~1e-12 and is what a near-tie disagreement of an fp32 engine is bisected
- *     against.  Never chosen by auto. */
+ * 5 = complex128 engine (any N): every value in fp64 on the device, as the reference computes (numpy complex128); agrees with it
+ *     to ~1e-12 and is what a near-tie disagreement of an fp32 engine is bisected against.  N = 4096 with one block and one carrier
+ *     runs as ONE fused kernel (fp64 transform resident in LDS, GACQ_OPT_FUSED_C128); every other shape as the five-stage pipeline
+ *     on rocFFT's double-precision transforms.  Never chosen by auto. */
 int gacq_set_engine(gacq_ctx* ctx, int engine);
 /* Upper bound for the library-owned correlation workspace in bytes (default 4 GiB).  A search whose forward spectra
  * for one epoch exceed it is cut into Doppler slices that fit; the slices are merged in grid order with strict '>'
@@ -137,7 +138,9 @@ int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes);
 #define GACQ_OPT_TIE_EPS_PPB 14   /* [8000] relative gap, in parts per billion, below which two magnitudes / metrics count as tied         */
                                 /*     (8e-6 ~ 6 x the worst fp32-vs-complex128 metric error observed); 1000000000 re-evaluates every row  */
 #define GACQ_OPT_TIE_CAP 15       /* [0 = auto: 64 + (epochs x items) / 16] rows one call can re-evaluate; pairs beyond it keep their fp32  */
-                                /*     answer and are counted in gacq_get_tie_stats()[2]                                                    */
+                                /*     answer and are counted in gacq_get_tie_stats()[2].  Whatever is asked for, the capacity is bounded   */
+                                /*     (never below 16) so that the re-evaluation's row buffers stay within an eighth of the workspace      */
+                                /*     limit (gacq_set_workspace_limit), between 32 and 256 MiB                                             */
 #define GACQ_OPT_FUSED_C128 16     /* [1] engine 5, N = 4096, B = 1, one carrier: the whole complex128 search row in one workgroup (one kernel     */
                                 /*     instead of the five-stage rocFFT double-precision pipeline); 0 = always the pipeline                  */
 #define GACQ_OPT_SPLIT_MFMA 17     /* [0] prime-factor engine: the inverse DFT-31 of the outer stage as two real 16 x 16 matrices on the       */
@@ -215,8 +218,11 @@ int gacq_group_search_batch(gacq_gsig* sig, const float* x_iq, size_t nsamp, int
                             const double* dopplers, int nd, const double* item_bias_hz, int blocks, gacq_result* out);
 
 /* Tie-safe bookkeeping since gacq_create (synchronises the ctx stream): out[0] ambiguous (epoch, item) pairs found, out[1] rows
- * re-evaluated in complex128, out[2] pairs that kept their fp32 answer because the re-evaluation list was full or the FFT length has
- * a prime factor the complex128 row kernel does not carry (it has 2, 3, 5, 7, 11, 13 and 31: every length the reference's scripts use), out[3] pairs whose location the re-evaluation changed. */
+ * re-evaluated in complex128, out[2] pairs that kept their fp32 answer because the re-evaluation list was full (GACQ_OPT_TIE_CAP and its
+ * memory bound) -- anything but 0 here means locations that are NOT guaranteed to be the complex128 ones: treat it as a warning
+ * (bench.py prints one), out[3] pairs whose location the re-evaluation changed.  FFT lengths with a prime factor the complex128 row kernel
+ * does not carry (it has 2, 3, 5, 7, 11, 13 and 31: every length the reference's scripts use) are searched without tie-safe locations
+ * and are not counted here. */
 int gacq_get_tie_stats(gacq_ctx* ctx, long long out[4]);
 
 /* Device-side shard merge: d_peaks [nshard][n] (as gathered from the ranks, shard s covering Doppler

@@ -167,3 +167,19 @@ def test_bench_driver_style_launch_over_gloo(world, config, extra):
     assert all(sum(b) == 8 and len(b) == world for b in cfg["doppler_bins_per_rank"])
     assert len(cfg["signals"]) == (4 if config == 5 else 1)
     assert cfg["epochs_per_step"] == (2 if "strong" in extra else world)
+
+
+def test_deferred_merge_refuses_samples_refilled_in_place():
+    """the deferred tie-safe merge re-reads the sample tensor at wait() time, so a caller that refills it in place for
+    the next step must get an error, not step-i peaks resolved against step-(i+1) samples.  torch's per-tensor version counter catches it."""
+    import torch
+    from gnss_dsp_tools_amd import sharded
+    x = torch.zeros(4, 8, dtype=torch.complex64)
+    stamp = sharded._stamp(x)
+    sharded._check_unmodified(stamp)                       # untouched: fine
+    pend = sharded.PendingSearch(local=None, gathered=torch.zeros(1), work=None, finish=lambda g: g, stamp=stamp)
+    assert pend.wait() is not None
+    x.copy_(torch.ones_like(x))                            # the in-place refill
+    with pytest.raises(RuntimeError, match="modified in place"):
+        sharded.PendingSearch(local=None, gathered=torch.zeros(1), work=None, finish=lambda g: g, stamp=stamp).wait()
+    assert sharded._stamp(np.zeros(3)) is None             # non-torch inputs of the CPU tests carry no counter
