@@ -95,6 +95,12 @@ SYMBOLS = {
     "gacq_search_batch_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
                                              c_int_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p,
                                              ctypes.c_int, ctypes.c_void_p]),
+    # complex128 samples (what the reference's search() is handed): same signatures, sample pointer to interleaved doubles
+    "gacq_search64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, c_int_p, ctypes.c_int,
+                                     ctypes.c_void_p, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.POINTER(Result)]),
+    "gacq_search_batch_dev64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                               c_int_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p,
+                                               ctypes.c_int, ctypes.c_void_p]),
     "gacq_search_batch": (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_size_t, ctypes.c_int, c_int_p, ctypes.c_int,
                                          c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.POINTER(Result)]),
     "gacq_group_create": (ctypes.c_int, [c_int_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
@@ -113,6 +119,9 @@ SYMBOLS = {
     "gacq_merge_peaks_tiesafe_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, c_int_p, ctypes.c_int,
                                                     c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, c_int_p,
                                                     ctypes.c_void_p]),
+    "gacq_merge_peaks_tiesafe_dev64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, c_int_p, ctypes.c_int,
+                                                      c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, c_int_p,
+                                                      ctypes.c_void_p]),
     "gacq_finalize": (ctypes.c_int, [ctypes.POINTER(SigDesc), ctypes.POINTER(Peak), ctypes.c_int, c_int_p, ctypes.c_int,
                                      c_double_p, ctypes.c_int, ctypes.POINTER(Result)]),
     "gacq_firwin_hann": (ctypes.c_int, [ctypes.c_int, ctypes.c_double, c_double_p]),

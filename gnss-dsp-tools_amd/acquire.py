@@ -267,10 +267,14 @@ class Engine:
             # the reference fails here with numpy's broadcast ValueError (short last block * w)
             raise ValueError("operands could not be broadcast together: search needs %d samples "
                              "(%d block(s) of n=%d%s), x has %d" % (need, blocks, sig.n, ", padded" if sig.pad else "", len(x)))
-        xc = np.ascontiguousarray(x[:need], dtype=np.complex64) if need else np.zeros(1, dtype=np.complex64)
+        # complex128 samples (what the reference's search() gets from np.interp, acquire-gps-l1.py:94-96) go down unrounded
+        # (gacq_search64: engine 5 and the tie-safe re-evaluation read them as given); everything else is searched as complex64
+        wide = x.dtype == np.complex128
+        xc = np.ascontiguousarray(x[:need], dtype=np.complex128 if wide else np.complex64) if need else np.zeros(1, dtype=np.complex64)
         idx_p, bias_p, res, view = self._plan_c
-        rc = nat.lib.gacq_search(s._h, xc.__array_interface__["data"][0], len(xc), idx_p, len(idx),
-                                 dopplers.__array_interface__["data"][0] if len(dopplers) else None, len(dopplers), bias_p, blocks, res)
+        fn = nat.lib.gacq_search64 if (wide and need and len(dopplers)) else nat.lib.gacq_search
+        rc = fn(s._h, xc.__array_interface__["data"][0], len(xc), idx_p, len(idx),
+                dopplers.__array_interface__["data"][0] if len(dopplers) else None, len(dopplers), bias_p, blocks, res)
         if rc < 0:
             nat.check(rc, self._ctx)
         return _as_tuples(view)
@@ -311,11 +315,13 @@ class Engine:
         x = np.asarray(x)
         if x.ndim != 1 or len(x) < need:
             raise ValueError("operands could not be broadcast together: search needs %d samples, x has shape %r" % (need, x.shape))
-        xc = np.ascontiguousarray(x[:need], dtype=np.complex64) if need else np.zeros(1, dtype=np.complex64)
+        wide = x.dtype == np.complex128 and need > 0 and len(dopplers) > 0          # see search_blocks
+        xc = np.ascontiguousarray(x[:need], dtype=np.complex128 if wide else np.complex64) if need else np.zeros(1, dtype=np.complex64)
         idx = np.arange(total, dtype=np.int32)
         res = (nat.Result * total)()
-        nat.check(nat.lib.gacq_search(fam._h, xc.ctypes.data_as(nat.c_float_p), len(xc), idx.ctypes.data_as(nat.c_int_p), total,
-                                      dopplers.ctypes.data_as(nat.c_double_p), len(dopplers), None, blocks, res), self._ctx)
+        fn = nat.lib.gacq_search64 if wide else nat.lib.gacq_search
+        nat.check(fn(fam._h, xc.ctypes.data_as(ctypes.c_void_p), len(xc), idx.ctypes.data_as(nat.c_int_p), total,
+                     dopplers.ctypes.data_as(nat.c_double_p), len(dopplers), None, blocks, res), self._ctx)
         flat = _as_tuples(res)
         out, at = [], 0
         for it in lists:
@@ -348,13 +354,13 @@ class Engine:
 
     # -- device-resident batched form (bench / sharded path) --------------------------------------
     def search_batch_dev(self, name, x_dev, items, dopplers, blocks, out=None, _signal=None):
-        """x_dev: torch complex64 CUDA tensor [nepoch, nsamp]; returns a torch tensor [nepoch, nitems, 2]
-        of float64 whose 16-byte rows are gacq_peak records (view with PEAK_DTYPE on the host).
-        Asynchronous on the engine's stream."""
+        """x_dev: torch complex64 (or complex128: searched unrounded where it matters, gacq_search_batch_dev64) CUDA tensor
+        [nepoch, nsamp]; returns a torch tensor [nepoch, nitems, 2] of float64 whose 16-byte rows are gacq_peak records (view with
+        PEAK_DTYPE on the host).  Asynchronous on the engine's stream."""
         import torch
         sig = _signals.get(name) if isinstance(name, str) else name
-        if not (x_dev.is_cuda and x_dev.dtype == torch.complex64 and x_dev.dim() == 2 and x_dev.is_contiguous()):
-            raise ValueError("x_dev must be a contiguous 2-D complex64 CUDA tensor")
+        if not (x_dev.is_cuda and x_dev.dtype in (torch.complex64, torch.complex128) and x_dev.dim() == 2 and x_dev.is_contiguous()):
+            raise ValueError("x_dev must be a contiguous 2-D complex64 (or complex128) CUDA tensor")
         if len(items) == 0:
             return torch.empty((x_dev.shape[0], 0, 2), dtype=torch.float64, device=x_dev.device)
         if _signal is not None:                # a stacked family signal: items are its row numbers
@@ -369,7 +375,8 @@ class Engine:
                   and (out.is_cuda or out.is_pinned())):
             # the last kernel writes 16-byte gacq_peak records into it: a wrong buffer would be overwritten silently
             raise ValueError("out must be a contiguous float64 tensor of shape (%d, %d, 2) on the device (or pinned host memory)" % (nepoch, len(idx)))
-        nat.check(nat.lib.gacq_search_batch_dev(
+        fn = nat.lib.gacq_search_batch_dev64 if x_dev.dtype == torch.complex128 else nat.lib.gacq_search_batch_dev
+        nat.check(fn(
             s._h, ctypes.c_void_p(x_dev.data_ptr()), nsamp, nepoch, idx.ctypes.data_as(nat.c_int_p), len(idx),
             dopplers.ctypes.data_as(nat.c_double_p), len(dopplers),
             bias.ctypes.data_as(nat.c_double_p) if bias is not None else None, int(blocks),
@@ -473,7 +480,8 @@ class Engine:
         if out is None:
             out = torch.empty(gathered.shape[1:], dtype=torch.float64, device=gathered.device)
         d0 = np.ascontiguousarray(shard_d0, dtype=np.int32)
-        nat.check(nat.lib.gacq_merge_peaks_tiesafe_dev(
+        fn = nat.lib.gacq_merge_peaks_tiesafe_dev64 if x_dev.dtype == torch.complex128 else nat.lib.gacq_merge_peaks_tiesafe_dev
+        nat.check(fn(
             s._h, ctypes.c_void_p(x_dev.data_ptr()), nsamp, nepoch, idx.ctypes.data_as(nat.c_int_p), len(idx),
             dopplers.ctypes.data_as(nat.c_double_p), len(dopplers), bias.ctypes.data_as(nat.c_double_p) if bias is not None else None,
             int(blocks), ctypes.c_void_p(gathered.data_ptr()), nshard, d0.ctypes.data_as(nat.c_int_p), ctypes.c_void_p(out.data_ptr())),

@@ -74,7 +74,7 @@ struct gacq_ctx {
   int engine = 0;
   size_t ws_limit = (size_t)4 << 30;
   std::map<std::pair<long, long>, gacq::FftPlan> plans;   // (N * 2 + inverse, batch)
-  gacq::DevBuf tab, xstage, X, Y, rows, freq, fset, items, out_peaks, d0, partial, fe_a, fe_b, fe_taps, chunk_peaks, arrivals;
+  gacq::DevBuf tab, xstage, x32, X, Y, rows, freq, fset, items, out_peaks, d0, partial, fe_a, fe_b, fe_taps, chunk_peaks, arrivals;
   gacq::DevBuf tie, tie_scratch, tie_q, tie_split, tie_done2;   // tie-safe re-evaluation: counters + lists, complex128 row scratch, per-block magnitude rows
   int tie_cap = 0;                     // list capacity the `tie` buffer was laid out for
   long opt[GACQ_NOPTS] = {1, 1, -1, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 1, 8000, 0, 1, 0};   // gacq_set_option values (defaults documented in include/gacq.h)
@@ -125,6 +125,22 @@ struct gacq_sig {
 
 namespace gacq {
 
+// The samples of a search as the caller handed them over: interleaved complex64, or (wide) interleaved complex128 -- what the
+// reference's search() actually receives from np.interp (acquire-gps-l1.py:94-96, used at :30-33).  The fp32 engines run on a
+// complex64 rounding of wide input; the complex128 engine and the tie-safe re-evaluation read it as given and widen nothing.
+struct XSrc {
+  const void* p;
+  int wide;
+  __host__ __device__ XSrc offset(size_t samples) const {
+    return XSrc{wide ? (const void*)((const double2*)p + samples) : (const void*)((const float2*)p + samples), wide};
+  }
+};
+__device__ __forceinline__ double2 ld_x(XSrc x, size_t i) {
+  if (x.wide) return reinterpret_cast<const double2*>(x.p)[i];
+  const float2 s = reinterpret_cast<const float2*>(x.p)[i];
+  return make_double2((double)s.x, (double)s.y);
+}
+
 int set_error(gacq_ctx* ctx, int code, const char* fmt, ...);
 void ring_destroy(gacq_ctx* ctx);
 int ensure(gacq_ctx* ctx, DevBuf& b, size_t bytes);
@@ -138,7 +154,7 @@ int twiddle_cache(gacq_ctx* ctx, const std::string& key, int N, int count, const
 int table_cache(gacq_ctx* ctx, const std::string& key, const void* host, size_t bytes, const void** out);
 int fft_exec(gacq_ctx* ctx, int N, long batch, bool inverse, void* data, bool fp64 = false);
 // engine 5: the pipeline in complex128 on the device (gacq_verify.hip); ctx->freq / items / fset already uploaded
-int verify_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, int P, int F, int D, int B, gacq_peak* d_out, float* d_qrow);
+int verify_search(gacq_sig* sig, XSrc d_x, size_t nsamp, int nepoch, int P, int F, int D, int B, gacq_peak* d_out, float* d_qrow);
 void stage_begin(gacq_ctx* ctx, int stage);
 void stage_end(gacq_ctx* ctx);
 
@@ -210,7 +226,7 @@ bool tie_supported(int N);                       // prime factors of N in {2, 3,
 float tie_scale_of(const gacq_ctx* ctx);            // 1 - eps from GACQ_OPT_TIE_EPS_PPB
 int tie_prepare(gacq_sig* sig);                  // complex128 code spectra on first use
 int tie_lists(gacq_ctx* ctx, long nep, int N, int B, TieLists* out, gacq_peak** guesses);      // capacity bounded by the memory budget of the re-evaluation
-int tie_resolve(gacq_sig* sig, const TieLists& tl, const gacq_peak* guesses, const float2* d_x, size_t nsamp, int P, int D, int B, gacq_peak* d_out);
+int tie_resolve(gacq_sig* sig, const TieLists& tl, const gacq_peak* guesses, XSrc d_x, size_t nsamp, int P, int D, int B, gacq_peak* d_out);
 
 // Running (maximum, first argmax, runner-up) of magnitudes visited in ascending lag order, and the merge of two such partial results.
 // An exact duplicate of the maximum counts as its runner-up.

@@ -519,7 +519,7 @@ void gacq_destroy(gacq_ctx* ctx) {
     if (kv.second.work) (void)hipFree(kv.second.work);
   }
   for (auto& ev : ctx->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-  DevBuf* bufs[] = {&ctx->tab, &ctx->xstage, &ctx->X, &ctx->Y, &ctx->rows, &ctx->freq, &ctx->fset, &ctx->items, &ctx->out_peaks, &ctx->d0, &ctx->partial, &ctx->fe_a, &ctx->fe_b, &ctx->fe_taps, &ctx->chunk_peaks, &ctx->arrivals, &ctx->tie, &ctx->tie_scratch, &ctx->tie_q, &ctx->tie_split, &ctx->tie_done2};
+  DevBuf* bufs[] = {&ctx->tab, &ctx->xstage, &ctx->x32, &ctx->X, &ctx->Y, &ctx->rows, &ctx->freq, &ctx->fset, &ctx->items, &ctx->out_peaks, &ctx->d0, &ctx->partial, &ctx->fe_a, &ctx->fe_b, &ctx->fe_taps, &ctx->chunk_peaks, &ctx->arrivals, &ctx->tie, &ctx->tie_scratch, &ctx->tie_q, &ctx->tie_split, &ctx->tie_done2};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   if (ctx->pin_x.p) (void)hipHostFree(ctx->pin_x.p);
   if (ctx->pin_peaks.p) (void)hipHostFree(ctx->pin_peaks.p);
@@ -843,7 +843,9 @@ int upload_grid(gacq_sig* sig, int nepoch, const int* items, int nitems, const d
   return GACQ_OK;
 }
 
-int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, const int* items, int nitems,
+// xs: the samples as the caller gave them (complex64 or complex128); d_x: their complex64 form for the fp32 engines (== xs.p for
+// complex64 input, a rounded copy for complex128 input, unused by engine 5)
+int launch_search(gacq_sig* sig, XSrc xs, const float2* d_x, size_t nsamp, int nepoch, const int* items, int nitems,
                   const double* dopplers, int nd, const double* bias, int blocks, gacq_peak* d_out, float* d_qrow) {
   gacq_ctx* ctx = sig->ctx;
   const gacq_sigdesc& ds = sig->desc;
@@ -853,7 +855,7 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
   int rc = upload_grid(sig, nepoch, items, nitems, dopplers, nd, bias, &F);
   if (rc != GACQ_OK) return rc;
 
-  if (ctx->engine == 5) return verify_search(sig, d_x, nsamp, nepoch, P, F, D, B, d_out, d_qrow);      // complex128 verification pipeline
+  if (ctx->engine == 5) return verify_search(sig, xs, nsamp, nepoch, P, F, D, B, d_out, d_qrow);      // complex128 engine: reads the samples as given
 
   const LdsPath path = lds_path(ctx, N, nepoch, P, F, D, B, d_qrow != nullptr);
   const bool use_lds = path.use_lds;
@@ -1016,7 +1018,7 @@ int launch_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, co
                          ds.metric_mode, tl, guesses, tscale);
     stage_end(ctx);
     GACQ_HIP(ctx, hipGetLastError());
-    if (tie && (rc = tie_resolve(sig, tl, guesses, xe, nsamp, P, D, B, d_out + (size_t)e0 * P)) != GACQ_OK) return rc;
+    if (tie && (rc = tie_resolve(sig, tl, guesses, xs.offset((size_t)e0 * nsamp), nsamp, P, D, B, d_out + (size_t)e0 * P)) != GACQ_OK) return rc;
   }
   return GACQ_OK;
 }
@@ -1105,12 +1107,29 @@ int upload_d0(gacq_ctx* ctx, const int* shard_d0, int nshard) {
 
 extern "C" {
 
-int gacq_search_batch_dev(gacq_sig* sig, const void* d_x, size_t nsamp, int nepoch, const int* items, int nitems,
-                          const double* dopplers, int nd, const double* item_bias_hz, int blocks, void* d_out) {
-  int rc = check_search_args(sig, d_x, nsamp, nepoch, items, nitems, dopplers, nd, blocks, d_out);
+static int merge_tiesafe(gacq_sig* sig, XSrc xs, size_t nsamp, int nepoch, const int* items, int nitems, const double* dopplers, int nd,
+                         const double* item_bias_hz, int blocks, const void* d_peaks, int nshard, const int* shard_d0, void* d_out);
+
+// complex128 samples -> the complex64 form the fp32 engines search (round to nearest, like x.astype(np.complex64))
+__global__ void narrow_x_kernel(const double2* __restrict__ in, float2* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const double2 v = in[i]; out[i] = make_float2((float)v.x, (float)v.y); }
+}
+
+static int search_batch_dev(gacq_sig* sig, XSrc xs, size_t nsamp, int nepoch, const int* items, int nitems,
+                            const double* dopplers, int nd, const double* item_bias_hz, int blocks, void* d_out) {
+  int rc = check_search_args(sig, xs.p, nsamp, nepoch, items, nitems, dopplers, nd, blocks, d_out);
   if (rc != GACQ_OK) return rc;
   gacq_ctx* ctx = sig->ctx;
   GACQ_DEVICE(ctx);
+  const void* d_x = xs.p;
+  if (xs.wide && ctx->engine != 5 && nd > 0 && blocks > 0) {
+    const size_t count = (size_t)nepoch * nsamp;
+    if ((rc = ensure(ctx, ctx->x32, sizeof(float2) * count)) != GACQ_OK) return rc;
+    hipLaunchKernelGGL(narrow_x_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, (const double2*)xs.p, (float2*)ctx->x32.p, count);
+    GACQ_HIP(ctx, hipGetLastError());
+    d_x = ctx->x32.p;
+  }
   if (nd == 0 || blocks == 0) {
     // empty Doppler grid -> the reference returns its initial (0,0,0) (acquire-gps-l1.py:25,40);
     // zero blocks -> q == 0 everywhere, nothing beats metric 0 either (raw) / NaN never wins (normalised)
@@ -1138,16 +1157,25 @@ int gacq_search_batch_dev(gacq_sig* sig, const void* d_x, size_t nsamp, int nepo
     std::vector<int> d0(nch);
     for (int c = 0; c < nch; c++) {
       d0[c] = c * Dc;
-      rc = launch_search(sig, (const float2*)d_x, nsamp, nepoch, items, nitems, dopplers + d0[c], std::min(Dc, nd - d0[c]), item_bias_hz,
+      rc = launch_search(sig, xs, (const float2*)d_x, nsamp, nepoch, items, nitems, dopplers + d0[c], std::min(Dc, nd - d0[c]), item_bias_hz,
                          blocks, (gacq_peak*)ctx->chunk_peaks.p + (size_t)c * n, nullptr);
       if (rc != GACQ_OK) return rc;
     }
     // slice winners within eps of each other are re-evaluated in complex128 like near-tied bins of one scan (tie-safe locations)
-    return gacq_merge_peaks_tiesafe_dev(sig, d_x, nsamp, nepoch, items, nitems, dopplers, nd, item_bias_hz, blocks, ctx->chunk_peaks.p, nch,
-                                        d0.data(), d_out);
+    return merge_tiesafe(sig, xs, nsamp, nepoch, items, nitems, dopplers, nd, item_bias_hz, blocks, ctx->chunk_peaks.p, nch, d0.data(), d_out);
   }
-  return launch_search(sig, (const float2*)d_x, nsamp, nepoch, items, nitems, dopplers, nd, item_bias_hz, blocks,
+  return launch_search(sig, xs, (const float2*)d_x, nsamp, nepoch, items, nitems, dopplers, nd, item_bias_hz, blocks,
                        (gacq_peak*)d_out, nullptr);
+}
+
+int gacq_search_batch_dev(gacq_sig* sig, const void* d_x, size_t nsamp, int nepoch, const int* items, int nitems,
+                          const double* dopplers, int nd, const double* item_bias_hz, int blocks, void* d_out) {
+  return search_batch_dev(sig, XSrc{d_x, 0}, nsamp, nepoch, items, nitems, dopplers, nd, item_bias_hz, blocks, d_out);
+}
+
+int gacq_search_batch_dev64(gacq_sig* sig, const void* d_x_c128, size_t nsamp, int nepoch, const int* items, int nitems,
+                            const double* dopplers, int nd, const double* item_bias_hz, int blocks, void* d_out) {
+  return search_batch_dev(sig, XSrc{d_x_c128, 1}, nsamp, nepoch, items, nitems, dopplers, nd, item_bias_hz, blocks, d_out);
 }
 
 int gacq_merge_peaks_dev(gacq_ctx* ctx, const void* d_peaks, int nshard, const int* shard_d0, long n, void* d_out) {
@@ -1165,6 +1193,18 @@ int gacq_merge_peaks_dev(gacq_ctx* ctx, const void* d_peaks, int nshard, const i
 int gacq_merge_peaks_tiesafe_dev(gacq_sig* sig, const void* d_x, size_t nsamp, int nepoch, const int* items, int nitems, const double* dopplers,
                                  int nd, const double* item_bias_hz, int blocks, const void* d_peaks, int nshard, const int* shard_d0,
                                  void* d_out) {
+  return merge_tiesafe(sig, XSrc{d_x, 0}, nsamp, nepoch, items, nitems, dopplers, nd, item_bias_hz, blocks, d_peaks, nshard, shard_d0, d_out);
+}
+
+int gacq_merge_peaks_tiesafe_dev64(gacq_sig* sig, const void* d_x_c128, size_t nsamp, int nepoch, const int* items, int nitems,
+                                   const double* dopplers, int nd, const double* item_bias_hz, int blocks, const void* d_peaks, int nshard,
+                                   const int* shard_d0, void* d_out) {
+  return merge_tiesafe(sig, XSrc{d_x_c128, 1}, nsamp, nepoch, items, nitems, dopplers, nd, item_bias_hz, blocks, d_peaks, nshard, shard_d0, d_out);
+}
+
+static int merge_tiesafe(gacq_sig* sig, XSrc xs, size_t nsamp, int nepoch, const int* items, int nitems, const double* dopplers, int nd,
+                         const double* item_bias_hz, int blocks, const void* d_peaks, int nshard, const int* shard_d0, void* d_out) {
+  const void* d_x = xs.p;
   int rc = check_search_args(sig, d_x, nsamp, nepoch, items, nitems, dopplers, nd, blocks, d_out);
   if (rc != GACQ_OK) return rc;
   gacq_ctx* ctx = sig->ctx;
@@ -1183,7 +1223,7 @@ int gacq_merge_peaks_tiesafe_dev(gacq_sig* sig, const void* d_x, size_t nsamp, i
   hipLaunchKernelGGL(merge_peaks_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const gacq_peak*)d_peaks,
                      (gacq_peak*)d_out, n, nshard, (const int*)ctx->d0.p, tl, guesses, tie_scale_of(ctx));
   GACQ_HIP(ctx, hipGetLastError());
-  return tie_resolve(sig, tl, guesses, (const float2*)d_x, nsamp, nitems, nd, blocks, (gacq_peak*)d_out);
+  return tie_resolve(sig, tl, guesses, xs, nsamp, nitems, nd, blocks, (gacq_peak*)d_out);
 }
 
 int gacq_finalize(const gacq_sigdesc* desc, const gacq_peak* peaks, int nshard, const int* shard_d0, int nitems,
@@ -1278,6 +1318,26 @@ int gacq_search(gacq_sig* sig, const float* x_iq, size_t nsamp, const int* items
   return gacq_finalize(&sig->desc, (const gacq_peak*)ctx->pin_peaks.p, 1, nullptr, nitems, dopplers, nd, out);
 }
 
+int gacq_search64(gacq_sig* sig, const double* x_iq, size_t nsamp, const int* items, int nitems, const double* dopplers,
+                  int nd, const double* item_bias_hz, int blocks, gacq_result* out) {
+  int rc = check_search_args(sig, x_iq, nsamp, 1, items, nitems, dopplers, nd, blocks, out);
+  if (rc != GACQ_OK) return rc;
+  gacq_ctx* ctx = sig->ctx;
+  if (nd == 0 || blocks == 0) {      // as gacq_search: the reference never looks at x here (acquire-gps-l1.py:25,40)
+    for (int p = 0; p < nitems; p++) { out[p].metric = 0.0; out[p].code_chips = 0.0; out[p].doppler_hz = 0.0; out[p].idx = -1; out[p].d_index = -1; }
+    return GACQ_OK;
+  }
+  GACQ_DEVICE(ctx);
+  const size_t need = (size_t)(blocks + (sig->desc.pad ? 1 : 0)) * sig->desc.n;      // <= nsamp (check_search_args)
+  if ((rc = ensure_pinned(ctx, ctx->pin_peaks, sizeof(gacq_peak) * nitems)) != GACQ_OK) return rc;
+  if ((rc = ensure(ctx, ctx->xstage, sizeof(double2) * need)) != GACQ_OK) return rc;
+  GACQ_HIP(ctx, hipMemcpyAsync(ctx->xstage.p, x_iq, sizeof(double2) * need, hipMemcpyHostToDevice, ctx->stream));
+  rc = gacq_search_batch_dev64(sig, ctx->xstage.p, need, 1, items, nitems, dopplers, nd, item_bias_hz, blocks, ctx->pin_peaks.p);
+  if (rc != GACQ_OK) return rc;
+  GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return gacq_finalize(&sig->desc, (const gacq_peak*)ctx->pin_peaks.p, 1, nullptr, nitems, dopplers, nd, out);
+}
+
 int gacq_debug_nco_indices(gacq_sig* sig, int kernel, double doppler, double bias_hz, int* idx_out) {
   if (!sig || !idx_out || !std::isfinite(doppler) || !std::isfinite(bias_hz))
     return set_error(sig ? sig->ctx : nullptr, GACQ_ERR_BAD_ARG, "gacq_debug_nco_indices: bad argument");
@@ -1335,7 +1395,7 @@ int gacq_debug_row(gacq_sig* sig, const float* x_iq, size_t nsamp, int item, dou
   // row dump: the engine that was asked for -- rocFFT pipeline (also what auto means here), LDS kernels (two-kernel path), split
   // engines, fp64 pipeline
   ctx->engine = (saved >= 2 && saved <= 5) ? saved : 1;
-  rc = launch_search(sig, (const float2*)ctx->xstage.p, need, 1, &item, 1, &doppler, 1, bias_hz != 0.0 ? &bias_hz : nullptr, blocks,
+  rc = launch_search(sig, XSrc{ctx->xstage.p, 0}, (const float2*)ctx->xstage.p, need, 1, &item, 1, &doppler, 1, bias_hz != 0.0 ? &bias_hz : nullptr, blocks,
                      (gacq_peak*)ctx->out_peaks.p, d_q);
   ctx->engine = saved;
   if (rc == GACQ_OK && hipMemcpyAsync(q_out, d_q, sizeof(float) * sig->N, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)

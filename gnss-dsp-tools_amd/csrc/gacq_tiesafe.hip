@@ -190,7 +190,7 @@ __device__ __forceinline__ bool arrive_last(unsigned* counter, int B) {
 //   q[k] = sum_b | ifft( C_p * conj(fft(x[b n : b n + N] * nco)) )[k] |   in complex128   (acquire-gps-l1.py:28-35;
 // |ifft(Y)| = |fft(conj(Y))| / N, so one forward transform routine serves both directions)
 __global__ __launch_bounds__(kTieThreads) void tie_recheck_kernel(TieLists tl, unsigned* __restrict__ done, double* __restrict__ qb,
-                                                                   const float2* __restrict__ x, size_t epoch_stride,
+                                                                   XSrc x, size_t epoch_stride,
                                                                    const double2* __restrict__ C64, const int* __restrict__ items,
                                                                    const int* __restrict__ fset, const double* __restrict__ freq,
                                                                    const double2* __restrict__ tab64, const double2* __restrict__ WN,
@@ -214,11 +214,11 @@ __global__ __launch_bounds__(kTieThreads) void tie_recheck_kernel(TieLists tl, u
     const double2* Cp = C64 + (long)items[p] * N;
     double* q = qb ? qb + ((size_t)slot * B + b0) * N : qown;
     for (int b = b0; b < b1; b++) {
-      const float2* src = x + e * epoch_stride + (size_t)b * n;
+      const XSrc src = x.offset(e * epoch_stride + (size_t)b * n);
       for (int i = t; i < N; i += kTieThreads) {
-        const float2 sv = src[i];
+        const double2 sv = ld_x(src, i);
         const double2 wv = tab64[nco_index(f, i)];                    // gnsstools/nco.py:6-10
-        bufa[i] = make_double2((double)sv.x * wv.x - (double)sv.y * wv.y, (double)sv.x * wv.y + (double)sv.y * wv.x);
+        bufa[i] = make_double2(sv.x * wv.x - sv.y * wv.y, sv.x * wv.y + sv.y * wv.x);
       }
       double2* X = fft_row(bufa, bufb, WN, N, rad);
       double2* other = (X == bufa) ? bufb : bufa;
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(kTieThreads) void tie_recheck_kernel(TieLists tl, u
 // items on the LDS-resident complex128 transform of gacq_fft64.h -- ~10 us per (row, block) instead of ~50 us through the
 // global-memory Stockham passes above, so that the re-evaluation stays invisible next to the 5.6 ms search it follows.
 __global__ __launch_bounds__(256, 1) void tie_recheck4k_kernel(TieLists tl, unsigned* __restrict__ done, double* __restrict__ qb,
-                                                               const float2* __restrict__ x, size_t epoch_stride,
+                                                               XSrc x, size_t epoch_stride,
                                                                const double2* __restrict__ C64, const int* __restrict__ items,
                                                                const int* __restrict__ fset, const double* __restrict__ freq,
                                                                const double2* __restrict__ tab64, const double2* __restrict__ WN, int n, int P,
@@ -273,14 +273,14 @@ __global__ __launch_bounds__(256, 1) void tie_recheck4k_kernel(TieLists tl, unsi
     const double2* cp = C64 + (long)items[p] * kN + t;
     double q[16];
     for (int b = b0; b < b1; b++) {
-      const float2* src = x + e * epoch_stride + (size_t)b * n;
+      const XSrc src = x.offset(e * epoch_stride + (size_t)b * n);
       cd v[16];
 #pragma unroll
       for (int j = 0; j < 16; j++) {
         const int i = t + 256 * j;
-        const float2 sv = src[i];
+        const double2 sv = ld_x(src, i);
         const double2 wv = tab64[nco_index(f, i)];
-        v[j] = cd{(double)sv.x, (double)sv.y} * cd{wv.x, wv.y};
+        v[j] = cd{sv.x, sv.y} * cd{wv.x, wv.y};
       }
       fft4096<false>(v, lds64, wa, wb, t);
       cd y[16];
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256, 1) void tie_recheck4k_kernel(TieLists tl, unsi
 template <int R>
 __global__ __launch_bounds__(256, 1) void tie_recheck_split_kernel(TieLists tl, unsigned* __restrict__ done, unsigned* __restrict__ done2,
                                                                    double* __restrict__ qb, double2* __restrict__ zs,
-                                                                   const float2* __restrict__ x, size_t epoch_stride,
+                                                                   XSrc x, size_t epoch_stride,
                                                                    const double2* __restrict__ C64, const int* __restrict__ items,
                                                                    const int* __restrict__ fset, const double* __restrict__ freq,
                                                                    const double2* __restrict__ tab64, const double2* __restrict__ WN, int n, int P,
@@ -374,23 +374,23 @@ __global__ __launch_bounds__(256, 1) void tie_recheck_split_kernel(TieLists tl, 
     const int p = row.ep - (int)e * P;
     const double f = freq[(long)fset[p] * D + row.d];
     const double2* Cp = C64 + (long)items[p] * N;
-    const float2* src = x + e * epoch_stride + (size_t)b * n;
+    const XSrc src = x.offset(e * epoch_stride + (size_t)b * n);
     cd v[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) v[j] = cd{0.0, 0.0};
     for (int n1 = 0; n1 < R; n1++) {
       // the 16 sample loads and the 16 table gathers of one n1 are independent: issued together, one round trip each
-      float2 sv[16];
+      double2 sv[16];
       double2 wv[16];
 #pragma unroll
       for (int j = 0; j < 16; j++) {
         const int i = M * n1 + t + 256 * j;
-        sv[j] = src[i];
+        sv[j] = ld_x(src, i);
         wv[j] = tab64[nco_index(f, i)];                                // gnsstools/nco.py:6-10
       }
       const cd wr = ldc(WN + ((n1 * k1) % R) * M);                     // W_R^{n1 k1}
 #pragma unroll
-      for (int j = 0; j < 16; j++) v[j] = v[j] + (cd{(double)sv[j].x, (double)sv[j].y} * cd{wv[j].x, wv[j].y}) * wr;
+      for (int j = 0; j < 16; j++) v[j] = v[j] + (cd{sv[j].x, sv[j].y} * cd{wv[j].x, wv[j].y}) * wr;
     }
     {
       cd tw[16];
@@ -505,9 +505,12 @@ bool tie_supported(int N) {
 
 // What the re-evaluation may allocate next to the search's own workspaces: an eighth of the workspace limit the caller has set
 // (gacq_set_workspace_limit), between 32 and 256 MiB.  The row buffers of tie_resolve are sized for the LIST CAPACITY (the host does
-// not know how many rows a launch will flag), so the capacity itself is bounded by this budget: pairs beyond it keep their fp32
+// not know how many rows a launch will flag), so the automatic capacity is bounded by this budget: pairs beyond it keep their fp32
 // answer and are counted (gacq_get_tie_stats()[2]) -- for the long lengths a handful of rows per call is what real data produces.
+// A caller who sets the capacity himself (GACQ_OPT_TIE_CAP) gets what he asked for; the side-by-side row buffers are then used up to
+// 768 MiB, beyond that the sequential forms (a few rows of scratch).
 size_t tie_budget(const gacq_ctx* ctx) {
+  if (ctx->opt[GACQ_OPT_TIE_CAP] > 0) return (size_t)768 << 20;
   return std::min<size_t>((size_t)256 << 20, std::max<size_t>((size_t)32 << 20, ctx->ws_limit / 8));
 }
 
@@ -515,7 +518,7 @@ int tie_capacity(const gacq_ctx* ctx, long nep, int N, int B) {
   long cap = ctx->opt[GACQ_OPT_TIE_CAP] > 0 ? std::min<long>(ctx->opt[GACQ_OPT_TIE_CAP], 1L << 24) : std::min<long>(64 + nep / 16, 1L << 20);
   // per listed row: B per-block magnitude rows in fp64 (+ the twiddled inner transforms of the split kernels)
   const size_t row = (size_t)std::max(1, B) * (size_t)N * (sizeof(double) + ((N == 4 * gacq::f64::kN || N == 16 * gacq::f64::kN) ? sizeof(double2) : 0)) + 64;
-  cap = std::min<long>(cap, (long)std::max<size_t>(16, tie_budget(ctx) / row));
+  if (ctx->opt[GACQ_OPT_TIE_CAP] <= 0) cap = std::min<long>(cap, (long)std::max<size_t>(16, tie_budget(ctx) / row));
   return (int)cap;
 }
 
@@ -567,7 +570,7 @@ int tie_prepare(gacq_sig* sig) {
 
 // Re-evaluate the listed rows and rewrite the records of the ambiguous pairs; asynchronous on the ctx stream.
 // ctx->freq / fset / items hold the grid of the search that filled the lists.
-int tie_resolve(gacq_sig* sig, const TieLists& tl, const gacq_peak* guesses, const float2* d_x, size_t nsamp, int P, int D, int B, gacq_peak* d_out) {
+int tie_resolve(gacq_sig* sig, const TieLists& tl, const gacq_peak* guesses, XSrc d_x, size_t nsamp, int P, int D, int B, gacq_peak* d_out) {
   gacq_ctx* ctx = sig->ctx;
   const int N = sig->N;
   Radices rad;

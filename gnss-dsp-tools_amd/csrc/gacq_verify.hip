@@ -23,7 +23,7 @@ struct RowRec64 {
 };
 
 // K1: y = x * tab64[floor((f*i)*1024) & 1023]   (acquire-gps-l1.py:28,30-31, gnsstools/nco.py:6-10), samples widened to fp64
-__global__ __launch_bounds__(kBlock) void mix64_kernel(const float2* __restrict__ x, size_t epoch_stride, double2* __restrict__ y,
+__global__ __launch_bounds__(kBlock) void mix64_kernel(XSrc x, size_t epoch_stride, double2* __restrict__ y,
                                                         const double* __restrict__ freq, const double2* __restrict__ tab, int n, int span,
                                                         int FD, int B, unsigned cols) {
   const unsigned row = blockIdx.x / cols;           // ((e*FD + fd)*B + b)
@@ -34,9 +34,9 @@ __global__ __launch_bounds__(kBlock) void mix64_kernel(const float2* __restrict_
   const double f = freq[fd];
   const int i = (int)(blockIdx.x % cols) * kBlock + threadIdx.x;
   if (i >= span) return;
-  const float2 s = x[e * epoch_stride + (size_t)b * n + i];
+  const double2 s = ld_x(x, e * epoch_stride + (size_t)b * n + i);
   const double2 w = tab[nco_index(f, i)];
-  y[row * (long)span + i] = make_double2((double)s.x * w.x - (double)s.y * w.y, (double)s.x * w.y + (double)s.y * w.x);
+  y[row * (long)span + i] = make_double2(s.x * w.x - s.y * w.y, s.x * w.y + s.y * w.x);
 }
 
 // K2: Y = C_p * conj(X)   (acquire-gps-l1.py:32)
@@ -114,7 +114,7 @@ __global__ void best_doppler64_kernel(const RowRec64* __restrict__ rows, gacq_pe
 // (max, first argmax, sum) of the row.  Nothing but x, the complex128 code spectra (natural order: lane t reads C[t + 256 j], 16
 // bytes per lane, 1 KiB per wave and instruction) and one 24-byte record per row touches HBM; the rocFFT pipeline this replaces
 // moves 5 x 64 KB per row.  64 KB of LDS per workgroup (gacq_fft64.h) -> two workgroups per CU, <= 256 VGPRs.
-__global__ __launch_bounds__(kBlock, 2) void fused4k_c128_kernel(const float2* __restrict__ x, size_t epoch_stride, const double2* __restrict__ C,
+__global__ __launch_bounds__(kBlock, 2) void fused4k_c128_kernel(XSrc x, size_t epoch_stride, const double2* __restrict__ C,
                                                                  const int* __restrict__ items, const double* __restrict__ freq,
                                                                  const double2* __restrict__ tab, const double2* __restrict__ tw,
                                                                  RowRec64* __restrict__ rows, int E, int P, int D, int pch, int nchunk) {
@@ -147,14 +147,14 @@ __global__ __launch_bounds__(kBlock, 2) void fused4k_c128_kernel(const float2* _
   cd xr[16];
   {
     const double f = freq[d];
-    const float2* src = x + e * epoch_stride;
+    const XSrc src = x.offset(e * epoch_stride);
     cd v[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       const int i = t + 256 * j;
-      const float2 sv = src[i];
+      const double2 sv = ld_x(src, i);
       const double2 w = tab[nco_index(f, i)];                     // gnsstools/nco.py:6-10
-      v[j] = cd{(double)sv.x, (double)sv.y} * cd{w.x, w.y};
+      v[j] = cd{sv.x, sv.y} * cd{w.x, w.y};
     }
     fft4096<false>(v, lds64, wa, wb, t);
 #pragma unroll
@@ -260,7 +260,7 @@ int verify_spectra(gacq_sig* s) {
   return GACQ_OK;
 }
 
-int verify_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, int P, int F, int D, int B, gacq_peak* d_out, float* d_qrow) {
+int verify_search(gacq_sig* sig, XSrc d_x, size_t nsamp, int nepoch, int P, int F, int D, int B, gacq_peak* d_out, float* d_qrow) {
   gacq_ctx* ctx = sig->ctx;
   hipStream_t st = ctx->stream;
   const int n = sig->desc.n, N = sig->N;
@@ -304,7 +304,7 @@ int verify_search(gacq_sig* sig, const float2* d_x, size_t nsamp, int nepoch, in
     RowRec64* rows = (RowRec64*)ctx->rows.p;
     const long rows_x = (long)ne * F * D * B;
     if (rows_x * cols >= (1L << 31)) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "verification engine: too many forward rows in one pass (lower the workspace limit)");
-    hipLaunchKernelGGL(mix64_kernel, dim3((unsigned)(rows_x * cols)), dim3(kBlock), 0, st, d_x + (size_t)e0 * nsamp, nsamp, X, (const double*)ctx->freq.p, tab, n,
+    hipLaunchKernelGGL(mix64_kernel, dim3((unsigned)(rows_x * cols)), dim3(kBlock), 0, st, d_x.offset((size_t)e0 * nsamp), nsamp, X, (const double*)ctx->freq.p, tab, n,
                        N, F * D, B, cols);
     GACQ_HIP(ctx, hipGetLastError());
     if ((rc = fft_exec(ctx, N, rows_x, false, X, true)) != GACQ_OK) return rc;

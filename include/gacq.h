@@ -138,9 +138,10 @@ int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes);
 #define GACQ_OPT_TIE_EPS_PPB 14   /* [8000] relative gap, in parts per billion, below which two magnitudes / metrics count as tied         */
                                 /*     (8e-6 ~ 6 x the worst fp32-vs-complex128 metric error observed); 1000000000 re-evaluates every row  */
 #define GACQ_OPT_TIE_CAP 15       /* [0 = auto: 64 + (epochs x items) / 16] rows one call can re-evaluate; pairs beyond it keep their fp32  */
-                                /*     answer and are counted in gacq_get_tie_stats()[2].  Whatever is asked for, the capacity is bounded   */
-                                /*     (never below 16) so that the re-evaluation's row buffers stay within an eighth of the workspace      */
-                                /*     limit (gacq_set_workspace_limit), between 32 and 256 MiB                                             */
+                                /*     answer and are counted in gacq_get_tie_stats()[2].  The automatic capacity is bounded (never below   */
+                                /*     16) so that the re-evaluation's row buffers (B x N x 8-24 bytes per listed row, allocated for the    */
+                                /*     capacity) stay within an eighth of the workspace limit (gacq_set_workspace_limit), between 32 and    */
+                                /*     256 MiB; an explicit value is taken as given                                                         */
 #define GACQ_OPT_FUSED_C128 16     /* [1] engine 5, N = 4096, B = 1, one carrier: the whole complex128 search row in one workgroup (one kernel     */
                                 /*     instead of the five-stage rocFFT double-precision pipeline); 0 = always the pipeline                  */
 #define GACQ_OPT_SPLIT_MFMA 17     /* [0] prime-factor engine: the inverse DFT-31 of the outer stage as two real 16 x 16 matrices on the       */
@@ -186,6 +187,19 @@ int gacq_search(gacq_sig* sig, const float* x_iq, size_t nsamp, const int* items
 int gacq_search_batch_dev(gacq_sig* sig, const void* d_x, size_t nsamp, int nepoch,
                           const int* items, int nitems, const double* dopplers, int nd,
                           const double* item_bias_hz, int blocks, void* d_out);
+
+/* The same two entry points for complex128 samples -- the type the reference's search() is actually handed (np.interp's output,
+ * acquire-gps-l1.py:94-96, used at :30-33).  x_iq / d_x_c128: interleaved (re, im) doubles.  Nothing is rounded where it matters:
+ * engine 5 reads the samples as given; the fp32 engines search a complex64 rounding of them (made on the device) and every
+ * (epoch, item) whose winner has a runner-up within GACQ_OPT_TIE_EPS_PPB -- which covers the rounding of the input, ~1e-7 -- is
+ * re-evaluated in complex128 FROM THE UNROUNDED SAMPLES (tie-safe locations), so peak locations are those of the reference on its
+ * own input and metrics agree within the 1e-5 of the fp32 engines.  gacq_search64 is synchronous (staged H2D copy, no BAR path). */
+int gacq_search64(gacq_sig* sig, const double* x_iq, size_t nsamp, const int* items, int nitems,
+                  const double* dopplers, int nd, const double* item_bias_hz, int blocks,
+                  gacq_result* out);
+int gacq_search_batch_dev64(gacq_sig* sig, const void* d_x_c128, size_t nsamp, int nepoch,
+                            const int* items, int nitems, const double* dopplers, int nd,
+                            const double* item_bias_hz, int blocks, void* d_out);
 
 /* Host-buffer batch: nepoch independent sample blocks in HOST memory (x_iq: complex64 [nepoch][nsamp]) -> out [nepoch][nitems]
  * on the host.  Synchronous for the caller, pipelined inside: the epochs go through a ring of pinned staging slots in chunks,
@@ -238,6 +252,10 @@ int gacq_merge_peaks_dev(gacq_ctx* ctx, const void* d_peaks, int nshard, const i
  * search writes, bit for bit.  The search arguments are those of the search the shards came from, with the FULL Doppler grid
  * (d_x: [nepoch][nsamp] on the device).  Asynchronous on the ctx stream. */
 int gacq_merge_peaks_tiesafe_dev(gacq_sig* sig, const void* d_x, size_t nsamp, int nepoch, const int* items, int nitems,
+                                 const double* dopplers, int nd, const double* item_bias_hz, int blocks, const void* d_peaks,
+                                 int nshard, const int* shard_d0, void* d_out);
+/* ... with the samples in complex128 (see gacq_search_batch_dev64) */
+int gacq_merge_peaks_tiesafe_dev64(gacq_sig* sig, const void* d_x_c128, size_t nsamp, int nepoch, const int* items, int nitems,
                                  const double* dopplers, int nd, const double* item_bias_hz, int blocks, const void* d_peaks,
                                  int nshard, const int* shard_d0, void* d_out);
 

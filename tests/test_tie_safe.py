@@ -206,3 +206,63 @@ def test_option_ranges_are_validated(fresh):
             fresh.set_option(opt, bad)
     fresh.set_option("lds_pch", 8)
     assert fresh.get_option("lds_pch") == 8
+
+
+@pytest.mark.parametrize("name,items,ds,ms,seed", [
+    ("gps-l1", [2, 9, 13, 30], [-3000.0, 3000.0, 250.0], 1, 801),
+    ("beidou-b1i", [1, 20], [-1000.0, 1000.0, 250.0], 2, 802),
+    ("gps-l5i", [7, 8], [-400.0, 400.0, 200.0], 1, 803),
+    ("galileo-e1b", [3], [1000.0, 1500.0, 125.0], 8, 804),
+])
+def test_complex128_samples_are_searched_unrounded(engine, name, items, ds, ms, seed):
+    """The reference's search() is handed complex128 samples (np.interp's output, acquire-gps-l1.py:94-96).  gacq_search64: engine 5
+    reads them as given -- 1e-10 against the numpy oracle on the UNROUNDED samples, and measurably different from what it makes of
+    their complex64 rounding; the fp32 engines locate like the oracle on the unrounded samples (their near-ties are re-evaluated from
+    them) with metrics inside the 1e-5 bar."""
+    from gnss_dsp_tools_amd import signals, synth
+    from oracle import acq_oracle
+    sig = signals.get(name)
+    x128 = synth.make_iq(sig, sig.blocks(ms), seed, [(items[0], 0.3, ds[0] + 0.4 * (ds[1] - ds[0]), 1234)], dtype=np.complex128)
+    assert x128.dtype == np.complex128 and np.any(x128 != x128.astype(np.complex64))
+    want = [acq_oracle.search_script(name, x128, it, ds, ms) for it in items]
+    engine.set_engine(5)
+    try:
+        got5 = engine.search_all(sig, x128, items, ds, ms)
+        got5_rounded = engine.search_all(sig, x128.astype(np.complex64), items, ds, ms)
+    finally:
+        engine.set_engine(0)
+    for g, w in zip(got5, want):
+        assert float(g[1]) == float(w[1]) and float(g[2]) == float(w[2])
+        assert float(g[0]) == pytest.approx(float(w[0]), rel=1e-10)
+    assert max(abs(float(a[0]) - float(b[0])) / float(b[0]) for a, b in zip(got5_rounded, want)) > 1e-9      # the rounding is visible at this level
+    got = engine.search_all(sig, x128, items, ds, ms)
+    for g, w in zip(got, want):
+        assert float(g[1]) == float(w[1]) and float(g[2]) == float(w[2])
+        assert float(g[0]) == pytest.approx(float(w[0]), rel=1e-5)
+
+
+def test_complex128_device_batches_locate_like_the_complex128_engine_on_noise(engine):
+    """Noise-only epochs (every search a near-tie lottery) as complex128 device tensors: the default engine's locations must be
+    those of engine 5 on the same unrounded samples, batch entry point and shard merge included."""
+    import torch
+    from gnss_dsp_tools_amd import acquire, signals, synth
+    sig = signals.get("gps-l1")
+    E, items = 96, list(range(1, 33))
+    dop = acquire.doppler_grid([-5000.0, 5000.0, 250.0])
+    xs = np.stack([synth.make_iq(sig, 1, 9000 + e, [], nsamp=sig.n, dtype=np.complex128) for e in range(E)])
+    xd = torch.from_numpy(xs).cuda()
+    engine.use_torch_stream()
+    got = engine.search_batch_dev(sig, xd, items, dop, 1).cpu().numpy().view(acquire.PEAK_DTYPE).reshape(E, -1)
+    engine.set_engine(5)
+    try:
+        ref = engine.search_batch_dev(sig, xd, items, dop, 1).cpu().numpy().view(acquire.PEAK_DTYPE).reshape(E, -1)
+    finally:
+        engine.set_engine(0)
+    assert np.array_equal(got["idx"], ref["idx"]) and np.array_equal(got["d_index"], ref["d_index"])
+    assert np.max(np.abs(got["metric"] - ref["metric"]) / ref["metric"]) < 1e-5
+    # two Doppler slices merged with the tie-safe merge on the complex128 samples
+    half = len(dop) // 2
+    a = engine.search_batch_dev(sig, xd, items, dop[:half], 1)
+    b = engine.search_batch_dev(sig, xd, items, dop[half:], 1)
+    merged = engine.merge_peaks_tiesafe_dev(sig, xd, items, dop, 1, torch.stack([a, b]), [0, half]).cpu().numpy().view(acquire.PEAK_DTYPE).reshape(E, -1)
+    assert np.array_equal(merged["idx"], ref["idx"]) and np.array_equal(merged["d_index"], ref["d_index"])
