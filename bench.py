@@ -320,6 +320,59 @@ def reference_precision(args, env, f32_value, epochs=1024, seconds=1.0):
     return res
 
 
+def reference_precision_other_configs(args, env, seconds=0.6):
+    """BASELINE configs 3, 4 and 5 in the reference's arithmetic type: engine 5 (complex128 on the device; for these lengths the
+    five-stage pipeline on rocFFT's double-precision transforms) on each config's own step, >= `seconds` timed per config, the fp32
+    engines timed in the same loop, and the two engines' peak records compared on the same epochs (identical locations, metrics
+    within 1e-5)."""
+    from gnss_dsp_tools_amd import acquire
+    dev = env["dev"]
+    out = []
+    for k in (3, 4, 5):
+        cfg = CONFIGS[k]
+        E = cfg["epochs"]
+        jobs = build_jobs(cfg, E, dev)
+        cells = sum(E * j["P"] * len(j["dop"]) * j["sig"].nfft for j in jobs)
+        rec = {"baseline_config": k, "workload": cfg["label"], "epochs_per_step": E, "unit": "cells/s", "dtype": "f64"}
+        peaks = {}
+        try:
+            for label, which in (("f64", 5), ("f32", 0)):
+                eng = acquire.Engine(env["local_rank"], engine=which)
+                eng.use_torch_stream(dev)
+                try:
+                    def step():
+                        res = []
+                        for j in jobs:
+                            if j["family"]:
+                                res.append(eng.search_family_batch_dev(j["family"], j["x"], j["items"], j["dop"], j["B"]))
+                            else:
+                                res.append(eng.search_batch_dev(j["sig"], j["x"], j["items"], j["dop"], j["B"]))
+                        return res
+                    res = step()
+                    torch.cuda.synchronize(dev)
+                    peaks[label] = np.concatenate([r.cpu().numpy().view(acquire.PEAK_DTYPE).reshape(-1) for r in res])
+                    n, t0 = 0, time.perf_counter()
+                    while time.perf_counter() - t0 < seconds or n < 2:
+                        step()
+                        torch.cuda.synchronize(dev)
+                        n += 1
+                    dt = time.perf_counter() - t0
+                    rec[label if label == "f32" else "f64_timing"] = {"value": n * cells / dt, "ms_per_step": dt / n * 1e3, "steps_timed": n, "seconds_timed": dt}
+                finally:
+                    eng.close()
+            rec.update(rec.pop("f64_timing"))
+            rec["f32_same_loop"] = rec.pop("f32")
+            rec["f32_over_f64"] = rec["f32_same_loop"]["value"] / rec["value"]
+            a, b = peaks["f32"], peaks["f64"]
+            rec["f32_vs_f64_on_the_same_epochs"] = {
+                "searches": int(a.size), "peak_location_mismatches": int(((a["idx"] != b["idx"]) | (a["d_index"] != b["d_index"])).sum()),
+                "max_rel_metric_error": float(np.max(np.abs(a["metric"] - b["metric"]) / np.abs(b["metric"])))}
+        except Exception as exc:
+            rec["error"] = repr(exc)[:300]
+        out.append(rec)
+    return out
+
+
 _STREAM_CEILINGS = {}
 
 
@@ -599,8 +652,9 @@ def main():
         out["other_configs"] = others
         try:
             out["reference_precision"] = reference_precision(args, env, out["value"])
+            out["reference_precision"]["other_configs"] = reference_precision_other_configs(args, env)
         except Exception as exc:
-            out["reference_precision"] = {"error": repr(exc)[:300]}
+            out.setdefault("reference_precision", {})["error"] = repr(exc)[:300]
         try:
             out["next_rows"] = next_rows(args, env)
         except Exception as exc:
