@@ -590,6 +590,7 @@ def main():
     ap.add_argument("--emulate-ranks", type=int, default=0, metavar="N",
                     help="PROJECTION, not a measurement: on this one GPU, time every rank's slice of an N-rank job (the Doppler slices "
                          "ShardedSearch would cut) one after the other and report the slowest slice, per-slice roofline and exchange bytes")
+    ap.add_argument("--dry-bins", type=int, default=8, help="--dry-run-cpu: Doppler bins of the miniature grid (fewer than ranks leaves ranks without a slice)")
     ap.add_argument("--dry-run-cpu", default="", metavar="FILE.py:FUNCTION",
                     help="NOT A MEASUREMENT: run the N-rank launch path on CPU tensors over gloo with FUNCTION(name, x, items, dopplers, blocks) "
                          "-> peaks as the per-rank compute (tests pass an oracle-backed stand-in); no GPU is touched")
@@ -756,8 +757,19 @@ def shard_census(sh, jobs, world, dev):
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
     assert g.shape[0] == world, ("exchange buffer has %d shards, world is %d" % (g.shape[0], world))
-    metrics = g.view(world, -1, 2)[:, :, 0]
-    assert bool((metrics > 0).all()), "a shard of the all-gather arrived empty"
+    recs = g.view(world, -1, 2)
+    off = 0
+    for job in jobs:                           # per job: a rank that owns Doppler bins must have sent positive metrics, one that owns none
+        from gnss_dsp_tools_amd import sharded as _sh      # (grid with fewer bins than ranks) "nothing found" records: metric 0
+        b = _sh.doppler_bounds(len(job["dop"]), world)
+        cnt = int(job["x"].shape[0]) * job["P"]
+        for r in range(world):
+            m = recs[r, off:off + cnt, 0]
+            if b[r + 1] > b[r]:
+                assert bool((m > 0).all()), "shard %d of the all-gather arrived empty" % r
+            else:
+                assert bool((m == 0).all()), "shard %d owns no Doppler bin but sent peaks" % r
+        off += cnt
     return int(g.shape[0]), pj.wait()
 
 
@@ -774,13 +786,17 @@ def run_dry(args, env, local_fn):
     epochs = args.epochs or 1
     E_total = epochs * world if args.scaling == "weak" else epochs
     jobs = []
+    members = []
     for name, items, ds, ms in cfg["jobs"]:
-        if isinstance(name, tuple):                                  # family jobs need the stacked device signal: first member only
-            name, items = name[0], items[0]
+        if isinstance(name, tuple):            # a family (E1B + E1C): the stacked device signal needs a GPU; here one job per member, same samples
+            members += [(n, it, ds, ms) for n, it in zip(name, items)]
+        else:
+            members.append((name, items, ds, ms))
+    for name, items, ds, ms in members:
         sig = signals.get(name)
         B = min(2, ms[1] if isinstance(ms, tuple) else sig.blocks(ms))
         items = list(items)[:3]
-        dop = acquire.doppler_grid(ds)[:8]
+        dop = acquire.doppler_grid(ds)[:args.dry_bins]
         xs = synth.make_epochs(sig, B, synth.BASE_SEED + cfg["seed"], synth.default_sats(items), E_total, nsamp=sig.samples_needed(B))
         jobs.append({"sig": sig, "name": sig.name, "family": None, "items": items, "P": len(items), "dop": dop, "dopplers": dop, "blocks": B, "B": B,
                      "x": torch.from_numpy(xs), "label": sig.name})
@@ -806,7 +822,7 @@ def run_dry(args, env, local_fn):
             "metric": "acquisition cells/s (PRN x Doppler x code-phase), " + "+".join(j["label"] for j in jobs), "value": None, "unit": "cells/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64 (stand-in)", "data": "synthetic",
-            "config": {"workload": "miniature of BASELINE config %d (3 items, 8 Doppler bins, %d epoch(s)/step)" % (args.config, E_total),
+            "config": {"workload": "miniature of BASELINE config %d (3 items, %d Doppler bins, %d epoch(s)/step)" % (args.config, args.dry_bins, E_total),
                        "baseline_config": args.config, "signals": [j["label"] for j in jobs], "epochs_per_step": E_total, "cells_per_step": cells_step,
                        "doppler_bins_per_rank": [[sharded.doppler_bounds(len(j["dop"]), world)[r + 1] - sharded.doppler_bounds(len(j["dop"]), world)[r]
                                                   for r in range(world)] for j in jobs],

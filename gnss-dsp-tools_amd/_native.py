@@ -106,6 +106,7 @@ SYMBOLS = {
     "gacq_group_create": (ctypes.c_int, [c_int_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "gacq_group_destroy": (None, [ctypes.c_void_p]),
     "gacq_group_size": (ctypes.c_int, [ctypes.c_void_p]),
+    "gacq_group_set_exchange": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "gacq_group_member": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
     "gacq_group_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
     "gacq_group_signal_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(SigDesc), ctypes.c_char_p, c_int_p, ctypes.c_int,

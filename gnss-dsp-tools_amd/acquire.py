@@ -492,7 +492,8 @@ class Engine:
 class DeviceGroup:
     """Several GPUs driven from one process through the library alone (gacq_group_*): the Doppler grid (or, for coarse grids,
     the item list) is cut over the devices, every device reads the same samples, the 16-byte peak records are merged on the
-    host with the reference's tie rule.  `devices` may repeat an index (several contexts on one GPU).
+    host with the reference's tie rule (or, set_exchange("rccl"), gathered over xGMI by RCCL and merged on a device).  `devices` may
+    repeat an index (several contexts on one GPU; host exchange only).
     One-process-per-GPU deployments use sharded.ShardedSearch over torch.distributed / RCCL instead."""
 
     def __init__(self, devices):
@@ -511,6 +512,11 @@ class DeviceGroup:
     def set_engine(self, engine):
         for k in range(len(self.devices)):
             nat.check(nat.lib.gacq_set_engine(ctypes.c_void_p(nat.lib.gacq_group_member(self._g, k)), int(engine)))
+
+    def set_exchange(self, mode):
+        """gacq_group_set_exchange: "host" (records through pinned memory, merged on the host; default) or "rccl" (records stay on
+        the devices, one ncclAllGather per chunk over xGMI, tie-safe merge on a member; needs distinct devices)."""
+        self._check(nat.lib.gacq_group_set_exchange(self._g, {"host": 0, "rccl": 1}[mode] if isinstance(mode, str) else int(mode)))
 
     def _signal(self, sig, prns):
         key = (sig.name, tuple(prns))

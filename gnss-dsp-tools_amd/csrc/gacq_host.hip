@@ -14,10 +14,44 @@
 //                            single-process caller; multi-process callers use torch.distributed / RCCL (sharded.py).
 #include "gacq_common.h"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstring>
 
 using namespace gacq;
+
+// RCCL, loaded on demand (gacq_group_set_exchange(group, GACQ_EXCHANGE_RCCL)): the library has no link-time dependency on it, a
+// caller that never asks for the in-library collective never loads it.  Only the handful of entry points the one exchange step
+// needs, declared here with the ABI of rccl.h (ncclResult_t and ncclDataType_t are ints; ncclChar == 0; comms are opaque pointers).
+namespace {
+struct Rccl {
+  void* lib = nullptr;
+  int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+  int (*CommDestroy)(void* comm) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*AllGather)(const void* sendbuff, void* recvbuff, size_t sendcount, int datatype, void* comm, hipStream_t stream) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok() const { return CommInitAll && CommDestroy && GroupStart && GroupEnd && AllGather && GetErrorString; }
+};
+Rccl* rccl_load() {
+  static Rccl r;
+  if (r.lib) return r.ok() ? &r : nullptr;
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (r.lib) break;
+  }
+  if (!r.lib) return nullptr;
+  r.CommInitAll = (decltype(r.CommInitAll))dlsym(r.lib, "ncclCommInitAll");
+  r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+  r.GroupStart = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
+  r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
+  r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
+  r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+  return r.ok() ? &r : nullptr;
+}
+}  // namespace
 
 namespace gacq {
 
@@ -31,6 +65,7 @@ struct BatchRing {
   hipStream_t copy = nullptr;
   hipEvent_t h2d[kRingDepth] = {}, done[kRingDepth] = {};
   DevBuf pin_in[kRingDepth], dev_in[kRingDepth], pin_out[kRingDepth];
+  DevBuf dev_out[kRingDepth], dev_all[kRingDepth];      // RCCL exchange of a device group: this member's records, every member's records
 };
 
 void ring_destroy(gacq_ctx* ctx) {
@@ -42,6 +77,8 @@ void ring_destroy(gacq_ctx* ctx) {
     if (r->pin_in[s].p) (void)hipHostFree(r->pin_in[s].p);
     if (r->dev_in[s].p) (void)hipFree(r->dev_in[s].p);
     if (r->pin_out[s].p) (void)hipHostFree(r->pin_out[s].p);
+    if (r->dev_out[s].p) (void)hipFree(r->dev_out[s].p);
+    if (r->dev_all[s].p) (void)hipFree(r->dev_all[s].p);
   }
   if (r->copy) (void)hipStreamDestroy(r->copy);
   delete r;
@@ -74,22 +111,26 @@ int epochs_per_chunk(size_t nsamp, int nepoch) {
 
 // Queue one chunk on `sig`'s device: H2D of ne*nsamp samples from pinned `src` on the copy stream, then the search of this
 // device's (items, dopplers) share on the compute stream; peaks land in pin_out[slot].  The slot must have been collected.
+// to_device: the records stay on the device (dev_out[slot]) for the RCCL exchange of a device group.
 int ring_submit(gacq_sig* sig, BatchRing* r, int slot, const void* src, size_t nsamp, int ne, const int* items, int nitems,
-                const double* dopplers, int nd, const double* bias, int blocks) {
+                const double* dopplers, int nd, const double* bias, int blocks, bool to_device = false) {
   gacq_ctx* ctx = sig->ctx;
   GACQ_DEVICE(ctx);
   int rc;
   const size_t bytes = sizeof(float2) * nsamp * (size_t)ne;
   if ((rc = ensure(ctx, r->dev_in[slot], bytes)) != GACQ_OK) return rc;
-  if ((rc = ensure_pinned(ctx, r->pin_out[slot], sizeof(gacq_peak) * (size_t)ne * nitems)) != GACQ_OK) return rc;
+  if (to_device) rc = ensure(ctx, r->dev_out[slot], sizeof(gacq_peak) * (size_t)ne * nitems);
+  else rc = ensure_pinned(ctx, r->pin_out[slot], sizeof(gacq_peak) * (size_t)ne * nitems);
+  if (rc != GACQ_OK) return rc;
   GACQ_HIP(ctx, hipMemcpyAsync(r->dev_in[slot].p, src, bytes, hipMemcpyHostToDevice, r->copy));
   GACQ_HIP(ctx, hipEventRecord(r->h2d[slot], r->copy));
   // one-way dependency: the compute stream waits for the copy, the copy stream never waits for compute (the host knows a slot
   // is free once its results were collected) -- a device-side wait in that direction cost 0.3 ms per batch
   GACQ_HIP(ctx, hipStreamWaitEvent(ctx->stream, r->h2d[slot], 0));
-  rc = gacq_search_batch_dev(sig, r->dev_in[slot].p, nsamp, ne, items, nitems, dopplers, nd, bias, blocks, r->pin_out[slot].p);
+  rc = gacq_search_batch_dev(sig, r->dev_in[slot].p, nsamp, ne, items, nitems, dopplers, nd, bias, blocks,
+                             to_device ? r->dev_out[slot].p : r->pin_out[slot].p);
   if (rc != GACQ_OK) return rc;
-  GACQ_HIP(ctx, hipEventRecord(r->done[slot], ctx->stream));
+  if (!to_device) GACQ_HIP(ctx, hipEventRecord(r->done[slot], ctx->stream));      // (exchange mode: recorded after the collective and the merge)
   return GACQ_OK;
 }
 
@@ -165,6 +206,8 @@ struct gacq_group {
   std::vector<gacq_ctx*> ctx;
   std::string err;
   DevBuf pin_in[kRingDepth];          // portable pinned staging shared by all members (every device DMAs from it)
+  int exchange = GACQ_EXCHANGE_HOST;
+  std::vector<void*> comm;            // one RCCL communicator per member (ncclCommInitAll), GACQ_EXCHANGE_RCCL only
 };
 
 struct gacq_gsig {
@@ -206,12 +249,43 @@ int gacq_group_create(const int* device_ids, int ndev, gacq_group** out) {
 
 void gacq_group_destroy(gacq_group* g) {
   if (!g) return;
+  if (!g->comm.empty()) {
+    Rccl* nc = rccl_load();
+    for (size_t k = 0; k < g->comm.size(); k++) {
+      DeviceGuard dg(g->ctx[k]->device);
+      (void)hipStreamSynchronize(g->ctx[k]->stream);
+      if (nc && g->comm[k]) (void)nc->CommDestroy(g->comm[k]);
+    }
+  }
   for (gacq_ctx* c : g->ctx) gacq_destroy(c);
   for (DevBuf& b : g->pin_in) if (b.p) (void)hipHostFree(b.p);
   delete g;
 }
 
 int gacq_group_size(const gacq_group* g) { return g ? (int)g->ctx.size() : GACQ_ERR_BAD_ARG; }
+
+int gacq_group_set_exchange(gacq_group* g, int mode) {
+  if (!g || (mode != GACQ_EXCHANGE_HOST && mode != GACQ_EXCHANGE_RCCL)) return group_error(g, GACQ_ERR_BAD_ARG, "gacq_group_set_exchange: bad argument");
+  if (mode == GACQ_EXCHANGE_RCCL && g->comm.empty()) {
+    const int G = (int)g->ctx.size();
+    std::vector<int> devs(G);
+    for (int k = 0; k < G; k++) devs[k] = g->ctx[k]->device;
+    for (int a = 0; a < G; a++)
+      for (int b = a + 1; b < G; b++)
+        if (devs[a] == devs[b]) return group_error(g, GACQ_ERR_UNSUPPORTED, "gacq_group_set_exchange: RCCL needs distinct devices (a device is listed twice)");
+    Rccl* nc = rccl_load();
+    if (!nc) return group_error(g, GACQ_ERR_UNSUPPORTED, "gacq_group_set_exchange: librccl.so could not be loaded");
+    std::vector<void*> comm(G, nullptr);
+    const int st = nc->CommInitAll(comm.data(), G, devs.data());
+    if (st != 0) {
+      g->err = std::string("gacq_group_set_exchange: ncclCommInitAll failed: ") + nc->GetErrorString(st);
+      return GACQ_ERR_HIP;
+    }
+    g->comm = comm;
+  }
+  g->exchange = mode;
+  return GACQ_OK;
+}
 
 gacq_ctx* gacq_group_member(gacq_group* g, int k) { return (g && k >= 0 && k < (int)g->ctx.size()) ? g->ctx[k] : nullptr; }
 
@@ -264,12 +338,69 @@ int gacq_group_search_batch(gacq_gsig* s, const float* x_iq, size_t nsamp, int n
     if (by_doppler) { it = items; nit = nitems; dop = dopplers + lo[k]; ndk = lo[k + 1] - lo[k]; bias = item_bias_hz; }
     else { it = items + lo[k]; nit = lo[k + 1] - lo[k]; dop = dopplers; ndk = nd; bias = item_bias_hz ? item_bias_hz + lo[k] : nullptr; }
   };
+  // GACQ_EXCHANGE_RCCL (Doppler slices only: an item split needs no merge): every member's records stay on its device, ONE
+  // ncclAllGather per chunk moves them over xGMI, the first member with a slice merges them on the device -- tie-safe, from the samples
+  // it holds in its staging slot -- and writes the merged records into its pinned result slot.  The north-star exchange step for a
+  // caller without torch; GACQ_EXCHANGE_HOST merges the same records on the host out of pinned memory.
+  const bool use_rccl = g->exchange == GACQ_EXCHANGE_RCCL && by_doppler && !g->comm.empty();
+  int kmerge = 0;
+  while (kmerge < G - 1 && lo[kmerge + 1] == lo[kmerge]) kmerge++;
+  auto exchange = [&](int slot, int ne) -> int {
+    Rccl* nc = rccl_load();
+    if (!nc) return group_error(g, GACQ_ERR_UNSUPPORTED, "gacq_group_search_batch: librccl.so is gone");
+    const size_t n = (size_t)ne * nitems;
+    for (int k = 0; k < G; k++) {
+      gacq_ctx* c = g->ctx[k];
+      DeviceGuard dg(c->device);
+      int rck = ensure(c, ring[k]->dev_all[slot], sizeof(gacq_peak) * n * G);
+      if (rck == GACQ_OK && lo[k + 1] == lo[k]) {
+        // a member without a slice sends "nothing found" records: idx = d_index = -1 in every second 8-byte word, metric 0
+        rck = ensure(c, ring[k]->dev_out[slot], sizeof(gacq_peak) * n);
+        if (rck == GACQ_OK && hipMemset2DAsync(ring[k]->dev_out[slot].p, 16, 0, 8, n, c->stream) != hipSuccess) rck = GACQ_ERR_HIP;
+        if (rck == GACQ_OK && hipMemset2DAsync((char*)ring[k]->dev_out[slot].p + 8, 16, 0xff, 8, n, c->stream) != hipSuccess) rck = GACQ_ERR_HIP;
+      }
+      if (rck != GACQ_OK) return group_fail(g, k, rck);
+    }
+    int st = nc->GroupStart();
+    for (int k = 0; k < G && st == 0; k++) {
+      DeviceGuard dg(g->ctx[k]->device);
+      st = nc->AllGather(ring[k]->dev_out[slot].p, ring[k]->dev_all[slot].p, sizeof(gacq_peak) * n, /*ncclChar*/ 0, g->comm[k], g->ctx[k]->stream);
+    }
+    const int st2 = nc->GroupEnd();
+    if (st != 0 || st2 != 0) {
+      g->err = std::string("gacq_group_search_batch: ncclAllGather failed: ") + nc->GetErrorString(st ? st : st2);
+      return GACQ_ERR_HIP;
+    }
+    // the merge (on the member that holds a slice: it has the samples) + the completion events of every member
+    gacq_ctx* c0 = g->ctx[kmerge];
+    {
+      DeviceGuard dg(c0->device);
+      int rcm = ensure_pinned(c0, ring[kmerge]->pin_out[slot], sizeof(gacq_peak) * n);
+      if (rcm == GACQ_OK)
+        rcm = gacq_merge_peaks_tiesafe_dev(s->sig[kmerge], ring[kmerge]->dev_in[slot].p, nsamp, ne, items, nitems, dopplers, nd, item_bias_hz, blocks,
+                                           ring[kmerge]->dev_all[slot].p, G, lo.data(), ring[kmerge]->pin_out[slot].p);
+      if (rcm != GACQ_OK) return group_fail(g, kmerge, rcm);
+    }
+    for (int k = 0; k < G; k++) {
+      DeviceGuard dg(g->ctx[k]->device);
+      if (hipEventRecord(ring[k]->done[slot], g->ctx[k]->stream) != hipSuccess) return group_error(g, GACQ_ERR_HIP, "gacq_group_search_batch: event record failed");
+    }
+    return GACQ_OK;
+  };
   auto finish = [&](int c) -> int {
     const int slot = c % kRingDepth, e0 = c * Ec, ne = std::min(Ec, nepoch - e0);
     for (int k = 0; k < G; k++) {
-      if (lo[k + 1] == lo[k]) continue;
+      if (lo[k + 1] == lo[k] && !use_rccl) continue;
       const int rck = ring_collect(g->ctx[k], ring[k], slot);
       if (rck != GACQ_OK) return group_fail(g, k, rck);
+    }
+    if (use_rccl) {
+      const gacq_peak* merged = (const gacq_peak*)ring[kmerge]->pin_out[slot].p;
+      for (int e = 0; e < ne; e++) {
+        const int rcf = gacq_finalize(&s->desc, merged + (size_t)e * nitems, 1, nullptr, nitems, dopplers, nd, out + (size_t)(e0 + e) * nitems);
+        if (rcf != GACQ_OK) return group_error(g, rcf, gacq_last_error(nullptr));
+      }
+      return GACQ_OK;
     }
     if (by_doppler && G > 1) {
       // Tie-safe locations across devices: device winners whose metrics come within eps of the best one cannot be ordered in fp32.
@@ -359,9 +490,10 @@ int gacq_group_search_batch(gacq_gsig* s, const float* x_iq, size_t nsamp, int n
       const int* it; int nit; const double* dop; int ndk; const double* bias;
       share(k, it, nit, dop, ndk, bias);
       if (nit == 0 || ndk == 0) continue;
-      rc = ring_submit(s->sig[k], ring[k], slot, g->pin_in[slot].p, nsamp, ne, it, nit, dop, ndk, bias, blocks);
+      rc = ring_submit(s->sig[k], ring[k], slot, g->pin_in[slot].p, nsamp, ne, it, nit, dop, ndk, bias, blocks, use_rccl);
       if (rc != GACQ_OK) return fail(group_fail(g, k, rc));
     }
+    if (use_rccl && (rc = exchange(slot, ne)) != GACQ_OK) return fail(rc);
   }
   for (int c = std::max(0, nchunk - kRingDepth); c < nchunk; c++)
     if ((rc = finish(c)) != GACQ_OK) return fail(rc);

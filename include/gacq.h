@@ -224,6 +224,15 @@ int gacq_group_create(const int* device_ids, int ndev, gacq_group** out);
 void gacq_group_destroy(gacq_group* group);
 int gacq_group_size(const gacq_group* group);
 gacq_ctx* gacq_group_member(gacq_group* group, int k);   /* member context, e.g. for gacq_set_engine / gacq_set_option */
+/* How the members' peak records meet.  GACQ_EXCHANGE_HOST [default]: each member's last kernel writes its records into pinned host
+ * memory and the host merges them (near-ties re-evaluated on a member).  GACQ_EXCHANGE_RCCL: the records stay on the devices, ONE
+ * ncclAllGather per chunk moves them over xGMI (single-process communicators from ncclCommInitAll; librccl.so is loaded on this
+ * call, the library does not link against it) and a member merges them on the device with the tie-safe merge -- the same result bit
+ * for bit.  Needs distinct devices; GACQ_ERR_UNSUPPORTED otherwise or when RCCL cannot be loaded (the group then stays on the host
+ * merge).  Applies to Doppler-sliced searches; an item split needs no merge. */
+#define GACQ_EXCHANGE_HOST 0
+#define GACQ_EXCHANGE_RCCL 1
+int gacq_group_set_exchange(gacq_group* group, int mode);
 const char* gacq_group_last_error(gacq_group* group);
 int gacq_group_signal_create(gacq_group* group, const gacq_sigdesc* desc, const char* code, const int* prns, int nprn,
                              gacq_gsig** out);

@@ -1105,6 +1105,42 @@ def test_in_library_device_group_equals_one_device(engine):
         grp.close()
 
 
+def test_device_group_rccl_exchange_equals_the_host_merge(engine):
+    """gacq_group_set_exchange(GACQ_EXCHANGE_RCCL): the members' records stay on the devices, ONE ncclAllGather per chunk (single-
+    process communicators, librccl.so loaded on demand) and the tie-safe merge on a member.  The test box has one GPU: the
+    collective runs with one rank -- the RCCL call sequence, the stream ordering against the search and the merge, the device-side
+    records and the pinned result slot are what is exercised; the merge itself is the one the sharded path uses.  Duplicate
+    devices are refused (RCCL needs distinct ones) and leave the group on the host merge."""
+    from gnss_dsp_tools_amd import _native as nat
+    from gnss_dsp_tools_amd import acquire, signals
+    grp = acquire.DeviceGroup([0])
+    try:
+        grp.set_exchange("rccl")
+        for name, items, ds, ms, E in [("gps-l1", list(range(1, 33)), [-5000.0, 5000.0, 250.0], 1, 700),      # three chunks through the ring
+                                       ("beidou-b1i", [6, 33], [-3000.0, 3000.0, 250.0], 2, 8),
+                                       ("gps-l5i", [1, 2, 3], [-400.0, 400.0, 200.0], 1, 3)]:
+            sig = signals.get(name)
+            B = sig.blocks(ms)
+            xs = _shifted_epochs(sig, B, 655, [(items[0], 0.4, 137.0, 1201)], E, sig.samples_needed(B))
+            dop = acquire.doppler_grid(ds)
+            assert grp.search_batch_host(sig, xs, items, dop, B) == engine.search_batch_host(sig, xs, items, dop, B), name
+        grp.set_exchange("host")
+        assert grp.search_batch_host(sig, xs, items, dop, B) == engine.search_batch_host(sig, xs, items, dop, B)
+    finally:
+        grp.close()
+    dup = acquire.DeviceGroup([0, 0])
+    try:
+        with pytest.raises(nat.GacqError) as ei:
+            dup.set_exchange("rccl")
+        assert ei.value.code == -9 and "distinct" in str(ei.value)
+        sig = signals.get("gps-l1")
+        xs = _shifted_epochs(sig, 1, 656, [], 4, sig.n)
+        dop = acquire.doppler_grid([-2000.0, 2000.0, 250.0])
+        assert dup.search_batch_host(sig, xs, [1, 2], dop, 1) == engine.search_batch_host(sig, xs, [1, 2], dop, 1)
+    finally:
+        dup.close()
+
+
 @pytest.mark.parametrize("cid", ALL_CASES)
 def test_complex128_verification_engine_matches_reference_to_1e_10(engine, golden_cases, cid):
     """Engine 5 = the pipeline in complex128 on the device (rocFFT double, fp64 NCO table, fp64 magnitudes and metric): the same

@@ -175,6 +175,12 @@ def test_new_entry_points_fail_loudly_without_crashing():
     assert lib.gacq_search_batch(None, *args) == -1
     assert lib.gacq_group_search_batch(None, *args) == -1
     assert lib.gacq_group_size(None) == -1 and lib.gacq_group_member(None, 0) is None
+    assert lib.gacq_group_set_exchange(None, 1) == -1            # round 5: RCCL exchange of a device group, complex128 samples in
+    x128 = np.zeros(8, dtype=np.complex128)
+    assert lib.gacq_search64(None, x128.ctypes.data_as(ctypes.c_void_p), 4, items.ctypes.data_as(nat.c_int_p), 2, dop.ctypes.data_as(ctypes.c_void_p), 2, None, 1, res) == -1
+    assert lib.gacq_search_batch_dev64(None, None, 4, 1, items.ctypes.data_as(nat.c_int_p), 2, dop.ctypes.data_as(nat.c_double_p), 2, None, 1, None) == -1
+    assert lib.gacq_merge_peaks_tiesafe_dev64(None, None, 4, 1, items.ctypes.data_as(nat.c_int_p), 2, dop.ctypes.data_as(nat.c_double_p), 2, None, 1, None, 1,
+                                              items.ctypes.data_as(nat.c_int_p), None) == -1
     h = ctypes.c_void_p()
     assert lib.gacq_group_create(None, 1, ctypes.byref(h)) == -1
     ids = (ctypes.c_int * 2)(0, 1)

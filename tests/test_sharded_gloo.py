@@ -145,13 +145,16 @@ def test_merge_tie_rule_lowest_doppler_wins():
     assert acquire.finalize("gps-l1", [1, 2], none, np.arange(12) * 100.0, shard_d0=[0, 6]) == [(0, 0, 0), (0, 0, 0)]
 
 
-@pytest.mark.parametrize("world,config,extra", [(2, 2, []), (3, 2, ["--scaling", "strong", "--epochs", "2"]), (2, 5, [])])
+@pytest.mark.parametrize("world,config,extra", [(2, 2, []), (3, 2, ["--scaling", "strong", "--epochs", "2"]), (2, 5, []),
+                                                (8, 2, []), (8, 3, []), (8, 4, ["--dry-bins", "5"]), (8, 5, ["--scaling", "strong"])])
 def test_bench_driver_style_launch_over_gloo(world, config, extra):
     """`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` exactly as the driver launches the scaling runs,
     but with --dry-run-cpu: CPU tensors over gloo, the per-rank compute stood in by the oracle (tests/_gloo_worker.py:oracle_local).
     What runs is bench.py's own N > 1 path -- RANK / LOCAL_RANK / WORLD_SIZE from the environment, Doppler slices per rank, ONE
     all-gather with two steps in flight, merge, shard census, barrier-bracketed MAX-reduced timing, one JSON line from rank 0 --
-    so the 8-GPU scaling run does not meet that code for the first time on hardware.  Config 5 = four signals in one exchange."""
+    so the 8-GPU scaling run does not meet that code for the first time on hardware.  Config 5 = four signals in one exchange; the
+    world-8 rows are the driver's own N = 8 launch for every BASELINE configuration: config 3's family as one job per member signal,
+    config 4 with fewer Doppler bins (5) than ranks, so that three ranks hold no slice at all and contribute "nothing found" records."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--config", str(config), "--steps", "2",
            "--warmup", "1", "--dry-run-cpu", os.path.join(ROOT, "tests", "_gloo_worker.py") + ":oracle_local"] + extra
@@ -164,9 +167,10 @@ def test_bench_driver_style_launch_over_gloo(world, config, extra):
     assert j["n_gpus"] == world and j["steps"] == 2 and j["warmup"] == 1 and j["ms_per_step"] > 0 and j["higher_is_better"] is True
     cfg = j["config"]
     assert cfg["shards_seen_by_every_rank"] == world and cfg["merged_equals_single_rank_scan"] is True
-    assert all(sum(b) == 8 and len(b) == world for b in cfg["doppler_bins_per_rank"])
-    assert len(cfg["signals"]) == (4 if config == 5 else 1)
-    assert cfg["epochs_per_step"] == (2 if "strong" in extra else world)
+    bins = int(extra[extra.index("--dry-bins") + 1]) if "--dry-bins" in extra else 8
+    assert all(sum(b) == bins and len(b) == world for b in cfg["doppler_bins_per_rank"])
+    assert len(cfg["signals"]) == {2: 1, 3: 2, 4: 2, 5: 4}[config]
+    assert cfg["epochs_per_step"] == ((2 if "--epochs" in extra else 1) if "strong" in extra else world)
 
 
 def test_deferred_merge_refuses_samples_refilled_in_place():
