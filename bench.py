@@ -1147,7 +1147,7 @@ def run(args, env):
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f64" if args.engine == 5 else "f32",
             "data": "synthetic",
             "config": {"workload": "BASELINE config %d: %s; %d epoch(s)/step%s batched, inputs resident in HBM"
                                    % (args.config, cfg["label"], epochs, "/GPU" if args.scaling == "weak" else " in total"),
@@ -1156,7 +1156,7 @@ def run(args, env):
                        "lags": [j["sig"].nfft for j in jobs], "blocks": [j["B"] for j in jobs], "epochs_per_step": E_total,
                        "cells_per_step": cells_step, "cell_blocks_per_step": cell_blocks_step, "sharding": sharding,
                        "shards_seen_by_every_rank": shards_seen,
-                       "engine": {0: "auto", 1: "rocfft", 2: "lds-fft", 3: "split", 4: "split-lds"}[args.engine],
+                       "engine": {0: "auto", 1: "rocfft", 2: "lds-fft", 3: "split", 4: "split-lds", 5: "complex128"}[args.engine],
                        "steps_in_flight": len(lanes)},
             "preroll": preroll,
             "sustained": sustained,

@@ -523,6 +523,35 @@ def test_bench_under_torchrun_single_rank_exercises_rccl_path(config, extra):
     assert j["sustained"]["seconds"] >= 0.2 and len(j["roofline"]["per_rank"]) == 1
 
 
+def test_bench_torchrun_single_rank_value_equals_the_plain_run():
+    """The driver takes the N = 1 point of the scaling curve from a plain `python bench.py --gpus 1` and the N > 1 points from
+    torchrun launches: the two launch styles must measure the same thing.  Same steps, sustained region of 1 s each, the torchrun
+    run with its (one-rank) RCCL exchange and merge inside the timed region: the sustained values agree within 3 % (two processes,
+    two clock ramps; the kernels are the same)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    common = [os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-pmc", "--no-others",
+              "--no-latency", "--sustained-s", "1.0"]
+    vals = {}
+    for label, cmd in (("plain", [sys.executable] + common),
+                       ("torchrun", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                                     "--master-port", str(port)] + common)):
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+        assert out.returncode == 0, (label, out.stderr[-3000:])
+        j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        vals[label] = j["sustained"]["value"]
+        assert j["n_gpus"] == 1 and j["config"]["baseline_config"] == 2
+    assert abs(vals["torchrun"] / vals["plain"] - 1.0) < 0.03, vals
+
+
 def test_bench_measures_hbm_traffic_live_with_pmc_child_runs():
     """bench.py's roofline.traffic is measured in the run itself: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of the same
     command (separate passes).  The fused N = 4096 kernel must read each epoch's samples and write 16-byte peak records: the

@@ -71,8 +71,12 @@ def main():
                              "counts half of a wide coalesced read, MI355X_MICROARCH.md HBM section)",
                    "source": "profiles/%s_pmc_counters_config2.txt" % tag, "valu_pipe_busy": float(busy.group(1)) / 100 if busy else None},
                   open(os.path.join(out, "traffic_latest.json"), "w"), indent=1)
+    # the headline workload in the reference's arithmetic type (engine 5: one fused complex128 kernel per search), its own trace + counters
+    c128 = bench + ["--engine", "5", "--steps", "3", "--warmup", "1", "--preroll-s", "0.2", "--sustained-s", "1.0"]
+    trace(out, "config2_complex128", c128)
+    pmc(out, "config2_complex128", c128 + ["--steps", "2", "--sustained-s", "0", "--preroll-s", "0"], "fused4k_c128|best_doppler64")
     cfgs = [py, os.path.join(ROOT, "tools", "bench_configs.py"), "--reps", "2", "cfg3_e1b", "cfg4_l5i", "cfg4_b2ad_b1", "cfg5_b1i", "cfg5_glonass", "cfg5_e1b", "gps_l1_ms10"]
-    pmc(out, "configs345", cfgs, "inner_corr|outer_inverse|lds16k|lds_inner|outer_forward|lds_correlate|lds_forward")
+    pmc(out, "configs345", cfgs, "inner_corr|outer_inverse|lds16k|lds_inner|outer_forward|inner_forward|lds_correlate|lds_forward")
     r = subprocess.run([py, os.path.join(ROOT, "tools", "bench_configs.py"), "--stages"], capture_output=True, text=True)
     open(os.path.join(out, "all_configs_stage_times.log"), "w").write("\n".join(l for l in r.stdout.splitlines() if "amdgpu.ids" not in l) + "\n")
 
