@@ -60,7 +60,7 @@ ERRORS = {0: "GACQ_OK", -1: "GACQ_ERR_BAD_ARG", -2: "GACQ_ERR_UNKNOWN_CODE", -3:
 
 # GACQ_OPT_* of include/gacq.h
 OPTIONS = {"fused_inner": 0, "fused_16k": 1, "lds_variant": 2, "lds_pch": 3, "split_pch": 4, "split_teams": 5, "fused_4k": 6, "split_dt": 7, "fe_generic": 8, "lds_ugroup": 9, "search1": 10, "bar_upload": 11, "watch_results": 12,
-           "tie_safe": 13, "tie_eps_ppb": 14, "tie_cap": 15, "fused_c128": 16, "split_mfma": 17, "split_fused": 18}
+           "tie_safe": 13, "tie_eps_ppb": 14, "tie_cap": 15, "fused_c128": 16, "split_mfma": 17}
 
 # name -> (restype, argtypes): every symbol include/gacq.h declares
 SYMBOLS = {

@@ -75,11 +75,9 @@ struct gacq_ctx {
   size_t ws_limit = (size_t)4 << 30;
   std::map<std::pair<long, long>, gacq::FftPlan> plans;   // (N * 2 + inverse, batch)
   gacq::DevBuf tab, xstage, x32, X, Y, rows, freq, fset, items, out_peaks, d0, partial, fe_a, fe_b, fe_taps, chunk_peaks, arrivals;
-  gacq::DevBuf fused_ring, fused_sync;   // prime-factor engine, one-launch form: the teams' Z' rings (L2-resident) and their counters
-  gacq::DevBuf fused_err;                // pinned: raised by the kernel when a wait expires
   gacq::DevBuf tie, tie_scratch, tie_q, tie_split, tie_done2;   // tie-safe re-evaluation: counters + lists, complex128 row scratch, per-block magnitude rows
   int tie_cap = 0;                     // list capacity the `tie` buffer was laid out for
-  long opt[GACQ_NOPTS] = {1, 1, -1, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 1, 8000, 0, 1, 0, 1};   // gacq_set_option values (defaults documented in include/gacq.h)
+  long opt[GACQ_NOPTS] = {1, 1, -1, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 1, 8000, 0, 1, 0};   // gacq_set_option values (defaults documented in include/gacq.h)
   gacq::DevBuf pin_x, pin_peaks;       // pinned host staging for the host-buffer entry point (gacq_search)
   gacq::DevBuf bar_x;                  // fine-grained device memory the host writes directly through the PCIe BAR (small gacq_search inputs)
   gacq::DevBuf bar_s;                  // the same for the correlator specs of gacq_correlate_batch_dev
@@ -222,9 +220,6 @@ int pfa_inner_correlate(gacq_ctx* ctx, const float2* X, const float2* C, const i
 // need_sum: the row sum feeds the max/mean metric (acquire-gps-l1.py:35); raw-metric signals skip it (RowRec::sum = 0)
 int pfa_inverse_reduce(gacq_ctx* ctx, const float2* Z, RowRec* rows, long g0, long ng, int B, int N, float* q_out, float tie_scale, bool need_sum);
 int pfa_debug_nco(gacq_ctx* ctx, int N, int n, const double* d_freq, int* d_idx);
-// writer and reader of the Z' round trip in one launch (one block, raw metric); GACQ_ERR_UNSUPPORTED = take the two-launch path
-int pfa_fused_correlate(gacq_ctx* ctx, const float2* X, const float2* C, const int* d_items, const int* d_fset, int nepoch, int P, int F, int D,
-                        int N, RowRec* rows, float tie_scale);
 
 // tie-safe re-evaluation (gacq_tiesafe.hip)
 bool tie_supported(int N);                       // prime factors of N in {2, 3, 5, 7, 11, 13, 31}: every FFT length of the reference's scripts

@@ -519,11 +519,10 @@ void gacq_destroy(gacq_ctx* ctx) {
     if (kv.second.work) (void)hipFree(kv.second.work);
   }
   for (auto& ev : ctx->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-  DevBuf* bufs[] = {&ctx->tab, &ctx->xstage, &ctx->x32, &ctx->X, &ctx->Y, &ctx->rows, &ctx->freq, &ctx->fset, &ctx->items, &ctx->out_peaks, &ctx->d0, &ctx->partial, &ctx->fe_a, &ctx->fe_b, &ctx->fe_taps, &ctx->chunk_peaks, &ctx->arrivals, &ctx->tie, &ctx->tie_scratch, &ctx->tie_q, &ctx->tie_split, &ctx->tie_done2, &ctx->fused_ring, &ctx->fused_sync};
+  DevBuf* bufs[] = {&ctx->tab, &ctx->xstage, &ctx->x32, &ctx->X, &ctx->Y, &ctx->rows, &ctx->freq, &ctx->fset, &ctx->items, &ctx->out_peaks, &ctx->d0, &ctx->partial, &ctx->fe_a, &ctx->fe_b, &ctx->fe_taps, &ctx->chunk_peaks, &ctx->arrivals, &ctx->tie, &ctx->tie_scratch, &ctx->tie_q, &ctx->tie_split, &ctx->tie_done2};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   if (ctx->pin_x.p) (void)hipHostFree(ctx->pin_x.p);
   if (ctx->pin_peaks.p) (void)hipHostFree(ctx->pin_peaks.p);
-  if (ctx->fused_err.p) (void)hipHostFree(ctx->fused_err.p);
   if (ctx->bar_x.p) (void)hipFree(ctx->bar_x.p);
   if (ctx->bar_s.p) (void)hipFree(ctx->bar_s.p);
   for (auto& sl : ctx->grid_slots) for (DevBuf* b : {&sl.dfreq, &sl.dfset, &sl.ditems}) if (b->p) (void)hipFree(b->p);
@@ -559,7 +558,7 @@ int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes) {
 int gacq_set_option(gacq_ctx* ctx, int option, long value) {
   if (!ctx || option < 0 || option >= GACQ_NOPTS) return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_set_option: unknown option %d", option);
   // accepted range per option (GACQ_OPT_* order): switches 0/1(/2), counts bounded by what the kernels' index arithmetic carries
-  static const long kMax[GACQ_NOPTS] = {1, 1, 1000, 4096, 4096, 4, 2, 3, 1, 64, 1, 1, 1, 1, 1000000000L, 1L << 24, 1, 1, 1};
+  static const long kMax[GACQ_NOPTS] = {1, 1, 1000, 4096, 4096, 4, 2, 3, 1, 64, 1, 1, 1, 1, 1000000000L, 1L << 24, 1, 1};
   const long lo = (option == GACQ_OPT_LDS_VARIANT) ? -1 : 0;
   if (value < lo || value > kMax[option])
     return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_set_option: value %ld out of range [%ld, %ld] for option %d", value, lo, kMax[option], option);
@@ -955,17 +954,6 @@ int launch_search(gacq_sig* sig, XSrc xs, const float2* d_x, size_t nsamp, int n
       }
       // correlation workspace: chunks of whole (e,p,d) groups, B rows each
       const long groups = (long)ne * P * D;
-      bool rows_ready = false;
-      if (use_pfa && B == 1 && !d_qrow && ds.metric_mode == 0 && ctx->opt[GACQ_OPT_SPLIT_FUSED]) {
-        // one launch for K2 + inner inverse transforms + inverse DFT-31 + |.| + reduce: Z' goes from its writers to its readers through
-        // the XCDs' L2s and never touches HBM (pfa_fused_kernel); anything it does not serve takes the two launches below
-        stage_begin(ctx, 6);
-        rc = pfa_fused_correlate(ctx, X, sig->spectra_pfa, (const int*)ctx->items.p, (const int*)ctx->fset.p, ne, P, F, D, N, rows, tscale);
-        stage_end(ctx);
-        if (rc == GACQ_OK) rows_ready = true;
-        else if (rc != GACQ_ERR_UNSUPPORTED) return rc;
-      }
-      if (!rows_ready) {
       const int zpitch = use_pfa ? pfa_row_pitch(N) : 0;       // prime-factor engine: Z' rows are whole reader workgroups of 128-byte lines
       const size_t group_bytes = sizeof(float2) * (size_t)B * (zpitch ? (size_t)zpitch * R : (size_t)N);
       long gc = (long)std::max<size_t>(1, std::min<size_t>((size_t)groups, ctx->ws_limit / group_bytes));
@@ -1018,7 +1006,6 @@ int launch_search(gacq_sig* sig, XSrc xs, const float2* d_x, size_t nsamp, int n
           stage_end(ctx);
           GACQ_HIP(ctx, hipGetLastError());
         }
-      }
       }
     }
     const long nep = (long)ne * P;

@@ -30,7 +30,6 @@
 
 #include <algorithm>
 #include <cmath>
-#include <cstring>
 
 using namespace gacq;
 
@@ -665,236 +664,6 @@ __global__ __launch_bounds__(PfaReader<M>::RW * 64, MODE == 2 ? 3 : 4) void pfa_
   }
 }
 
-// ---- writer and reader of the Z' round trip in ONE launch: Z' never leaves the XCD's L2 --------------------------------------------
-// Two launches hand Z' (0.5 MB per (epoch, item, Doppler bin) group) from the inner kernel to the outer kernel through HBM: 2 x 1.1 GB per
-// 32-item search at N = 61380, the one thing that paces both kernels.  An XCD's 4 MB L2 would hold a handful of groups -- if the workgroups
-// that write a group and the ones that read it sit on the same XCD and run at the same time.  HIP promises neither, so the kernel arranges
-// it for itself: the grid is persistent (every workgroup resident), a workgroup reads its XCC id (s_getreg HW_REG_XCC_ID) and takes a
-// ticket in ITS XCD's counter; 31 consecutive tickets form a team -- one member per row k1 of the DFT-31, all on one XCD by construction,
-// whatever the placement.  A team pulls batches (an item chunk x DT Doppler bins, what one workgroup of pfa_inner_corr_kernel serves) from
-// a global counter and walks the batch's rows in step: member k1 transforms row k1 of group g (K2 + passes a, b, c) into slot g mod S of
-// the team's ring, and then -- the other half of the same loop body -- takes 64 columns of group g-1, all 31 rows of them, through the
-// inverse DFT-31 on the matrix pipe (reader_tile; the VALU is busy with the next row's passes in the team's other waves).
-// Hand-over inside an XCD (tools/exp/l2_ring_probe.hip: 0 stale words in 4e9, 1 % of the stored bytes reach HBM): plain stores,
-// s_waitcnt vmcnt(0) (they are in the L2 now), a relaxed agent-scope counter; the reader polls the counter and loads with sc1 (past
-// its L1, from the shared L2).  No buffer_wbl2 anywhere -- that is the price (2-7 us per 16 KB row) that ruled this out across XCDs.
-// Per ring slot two monotone counters: `ready` (members that have written the slot's current group) and `consumed` (members that have read
-// it); a slot of generation n may be written once consumed == 31 n and read once ready == 31 (n + 1).  Every wait is on work with a
-// lower sequence number that a resident workgroup has already claimed: no cycle.  Every spin is bounded; on expiry the kernel raises
-// `error` (the host checks it before the next search and falls back to the two-launch path) instead of hanging the device.
-constexpr int kFusedTeams = 3;           // teams per XCD the ring is laid out for (3 x 31 = 93 of the 96 workgroups an XCD holds at 3 per CU)
-constexpr int kFusedSlots = 2;           // ring slots per team: 8 XCDs x 3 teams x 2 slots x 0.5 MB -- 3 MB of each 4 MB L2
-constexpr unsigned kFusedSpin = 1u << 22;
-
-struct FusedSync {
-  unsigned tickets[8][16];               // per XCD (own 64-byte line each)
-  unsigned started[16];
-  unsigned next_batch[16];
-  unsigned error[16];
-  unsigned ready[8 * kFusedTeams][kFusedSlots][16];
-  unsigned consumed[8 * kFusedTeams][kFusedSlots][16];
-};
-
-__device__ __forceinline__ unsigned xcc_id() {
-  unsigned v;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
-  return v & 15u;
-}
-__device__ __forceinline__ unsigned ld_flag(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// lane 0 of the workgroup waits until *p >= want (or the kernel has been told to give up); false = give up
-__device__ __forceinline__ bool wait_flag(const unsigned* p, unsigned want, unsigned* error) {
-  for (unsigned spin = 0; spin < kFusedSpin; spin++) {
-    if (ld_flag(p) >= want) return true;
-    if ((spin & 255) == 255 && ld_flag(error)) return false;
-    __builtin_amdgcn_s_sleep(1);
-  }
-  __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return false;
-}
-
-template <int M> struct FusedRing {
-  static constexpr int RCOLS = ((M + kR * 16 - 1) / (kR * 16)) * 16;
-  static constexpr int RP = RCOLS * kR;            // 1984 / 992
-  static_assert(RP >= M && RCOLS <= 64, "31 members x RCOLS columns cover a row");
-  static constexpr size_t ring_elems() { return (size_t)8 * kFusedTeams * kFusedSlots * kR * RP; }
-};
-
-template <int M, int DT>
-__global__ __launch_bounds__(256, 3) void pfa_fused_kernel(const float2* __restrict__ X, const float2* __restrict__ C, float2* __restrict__ ring,
-                                                          FusedSync* __restrict__ sync, unsigned* __restrict__ pub, RowRec* __restrict__ partial,
-                                                          const float* __restrict__ cs_tab, const int* __restrict__ items, const int* __restrict__ fset,
-                                                          long ngroups, int nblk_ep, int nbatch, int pch, int P, int F, int D, float inv_n,
-                                                          float tie_scale, unsigned* __restrict__ host_error) {
-  using S = Pfa<M>;
-  constexpr int RCOLS = FusedRing<M>::RCOLS;       // columns a member reads per group: 64 / 32
-  constexpr int RP = FusedRing<M>::RP;             // ring row pitch: 31 members x RCOLS columns = unpadded column layout + a tail of zeros
-  constexpr int RWAVES = RCOLS / 16;               // waves with a 16-column tile: 4 / 2
-  __shared__ __attribute__((aligned(16))) v2 buf[2][M];
-  __shared__ unsigned s_bcast[4];
-  const int tid = threadIdx.x;
-  unsigned* error = sync->error;
-  // ---- team formation
-  if (tid == 0) {
-    const unsigned xcc = xcc_id() & 7u;
-    s_bcast[0] = xcc;
-    s_bcast[1] = atomicAdd(&sync->tickets[xcc][0], 1u);
-    atomicAdd(&sync->started[0], 1u);
-    s_bcast[2] = wait_flag(sync->started, gridDim.x, error) ? ld_flag(&sync->tickets[xcc][0]) : 0u;      // everyone has a ticket: team sizes are final
-  }
-  __syncthreads();
-  const unsigned xcc = s_bcast[0], ticket = s_bcast[1], xcd_pop = s_bcast[2];
-  const unsigned tl = ticket / kR;
-  const int k1 = (int)(ticket - tl * kR);
-  if (tl >= (unsigned)kFusedTeams || (tl + 1) * kR > xcd_pop) return;       // no complete team for this workgroup: it leaves the work to the others
-  const unsigned team = xcc * kFusedTeams + tl;
-  float2* tring = ring + (size_t)team * kFusedSlots * kR * RP;
-  unsigned* tpub = pub + (size_t)team * (nbatch + 1);
-  const int pb = pfa_pass_b_base<M>(tid);
-  const bool act_a = tid < S::BC, act_c = tid < S::AB;
-  const int lane = tid & 63, wave = tid >> 6, ci = lane & 15, gq = lane >> 4;      // the reader's lane roles (pfa_outer_inverse_mfma_kernel)
-  const int DG = (D + DT - 1) / DT;
-  // ---- the walk
-  unsigned gseq = 0;                                 // rows this team has started
-  long gprev = -1;                                   // group whose columns are still to be read (the previous row's)
-  unsigned par = 0;
-  bool ok = true;
-  auto read_group = [&](long g, unsigned seq) {
-    // columns [64 k1, 64 k1 + 64) of group g: all 31 rows, inverse DFT-31 on the matrix pipe, |z|^2 key scan (raw metric, one block)
-    const unsigned slot = seq % kFusedSlots, gen = seq / kFusedSlots;
-    if (tid == 0) s_bcast[3] = wait_flag(sync->ready[team][slot], kR * (gen + 1), error) ? 1u : 0u;
-    __syncthreads();
-    if (!s_bcast[3]) { ok = false; return; }
-    const unsigned long long* zr = reinterpret_cast<const unsigned long long*>(tring + (size_t)slot * kR * RP);
-    KeyScan ks;
-    if (wave < RWAVES) {
-      // the reader's per-lane constants are rebuilt per group (a few dozen scalar-ish instructions and 8 cached loads) rather than held
-      // across the writer's passes: the X operands of DT rows already fill the register budget of three workgroups per CU
-      const int rpos = k1 * RCOLS + 16 * wave + ci;      // this lane's column of every group
-      v2 v[4], vp[4];
-#pragma unroll
-      for (int kk = 0; kk < 4; kk++) {
-        const int rk = (S::Minv * (4 * kk + gq)) % kR;
-        v[kk] = __builtin_bit_cast(v2, __hip_atomic_load(zr + (rk * RP + rpos), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));      // sc1: past the L1, from the team's L2
-        vp[kk] = __builtin_bit_cast(v2, __hip_atomic_load(zr + (((kR - rk) % kR) * RP + rpos), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      }
-      float ca[4], sa[4];
-#pragma unroll
-      for (int kk = 0; kk < 4; kk++) { ca[kk] = cs_tab[lane * 8 + kk]; sa[kk] = cs_tab[lane * 8 + 4 + kk]; }
-      int na, nb;
-      {
-        int t, q0;
-        (void)pfa_column<M, S::AB>(rpos, t, q0);         // the tail columns (>= M) hold zeros for ever: t = q0 = 0
-        const int q0p = kR - 1 - q0;
-        int qa = q0p + kR - 4 * gq;
-        qa -= (qa >= kR) ? kR : 0;
-        int qb = q0p + 4 * gq;
-        qb -= (qb >= kR) ? kR : 0;
-        na = (M - 1 - t) + M * qa;
-        nb = (M - 1 - t) + M * qb;
-      }
-      reader_tile(v, vp, ca, sa, [&](int i, float m1, float m2) {
-        unsigned n1 = (unsigned)(na - M * i), n2 = (unsigned)(nb + M * i);
-        n1 = min(n1, n1 + (unsigned)S::N);
-        n2 = min(n2, n2 - (unsigned)S::N);
-        if (i == 0) m2 = (gq == 0) ? 0.f : m2;       // u = 0 has no partner
-        ks.add(m1, n1);
-        ks.add(m2, n2);
-      });
-    }
-    Top2 top;
-    top.peak = __builtin_amdgcn_sqrtf(__uint_as_float((unsigned)(ks.key >> 32))) * inv_n;
-    top.second = __builtin_amdgcn_sqrtf(fmaxf(ks.second, 0.f)) * inv_n;
-    top.idx = S::N - 1 - (int)(unsigned)(ks.key & 0xffffffffu);
-    if (wave >= RWAVES) { top.peak = -1.0f; top.second = -1.0f; top.idx = 0x7fffffff; }
-    reduce_and_store_nw<4>(top, 0.0, partial, g * kR + k1, tie_scale, (int)(seq & 1));      // (its barrier also orders the ring loads before the signal)
-    if (tid == 0) atomicAdd(&sync->consumed[team][slot][0], 1u);
-  };
-  for (unsigned bseq = 0; ok; bseq++) {
-    // ---- the team's next batch: the member with row 0 draws it, everybody reads it from the team's list
-    if (tid == 0) {
-      if (k1 == 0) __hip_atomic_store(tpub + bseq, atomicAdd(&sync->next_batch[0], 1u) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_bcast[3] = wait_flag(tpub + bseq, 1u, error) ? ld_flag(tpub + bseq) : 0u;
-    }
-    __syncthreads();
-    const unsigned bid1 = s_bcast[3];
-    __syncthreads();
-    if (bid1 == 0) { ok = false; break; }
-    if (bid1 > (unsigned)nbatch) break;              // no batch left
-    const unsigned bid = bid1 - 1;
-    const int d0 = (int)(bid % (unsigned)DG) * DT;
-    const unsigned ep0 = (bid / (unsigned)DG) * (unsigned)pch;
-    const float2* have[DT];
-    float2 xv[DT][S::Na];
-#pragma unroll
-    for (int dd = 0; dd < DT; dd++) have[dd] = nullptr;
-    float2 cv[S::Na];
-    unsigned cv_ep = 0xffffffffu;
-    for (int i0 = 0; i0 < pch && ok; i0++) {
-      const unsigned ep = ep0 + (unsigned)i0;
-      const unsigned e = ep / (unsigned)P;
-      const int p = (int)(ep - e * (unsigned)P);
-#pragma unroll
-      for (int dd = 0; dd < DT; dd++) {
-        const int d = d0 + dd;
-        const long g = (long)ep * D + d;
-        if (!(d < D && g < ngroups) || !ok) continue;                      // uniform over the team
-        const unsigned slot = gseq % kFusedSlots, gen = gseq / kFusedSlots;
-        const float2* gx = X + ((((long)e * F + fset[p]) * D + d) * kR + k1) * (long)M;
-        v2* bw = buf[par & 1];
-        par++;
-        if (act_a) {
-          if (cv_ep != ep) {
-            const float2* gc = C + ((long)items[p] * kR + k1) * (long)M;
-#pragma unroll
-            for (int t = 0; t < S::Na; t++) cv[t] = gc[tid + t * S::BC];
-          }
-          if (gx != have[dd]) {
-#pragma unroll
-            for (int t = 0; t < S::Na; t++) xv[dd][t] = gx[tid + t * S::BC];
-          }
-          v2 x[S::Na];
-#pragma unroll
-          for (int t = 0; t < S::Na; t++)
-            x[t] = v2{cv[t].x * xv[dd][t].x + cv[t].y * xv[dd][t].y, cv[t].y * xv[dd][t].x - cv[t].x * xv[dd][t].y};      // C * conj(X)   acquire-gps-l1.py:32
-          SmallDft<S::Na, true>::run(x);
-#pragma unroll
-          for (int t = 0; t < S::Na; t++) bw[S::Na * tid + t] = x[t];
-        }
-        cv_ep = ep;
-        have[dd] = gx;
-        // the slot's previous group must have been read by every member before it is overwritten (checked by lane 0 under passes a / b)
-        if (tid == 0) s_bcast[3] = wait_flag(sync->consumed[team][slot], kR * gen, error) ? 1u : 0u;
-        __syncthreads();
-        if (!s_bcast[3]) ok = false;
-        pfa_pass_b<M, true>(bw, pb);
-        __syncthreads();
-        if (ok) {
-          float2* gz = tring + ((size_t)slot * kR + k1) * RP;
-          if (act_c) {
-            v2 y[S::Nc];
-#pragma unroll
-            for (int t = 0; t < S::Nc; t++) { y[t] = bw[tid + S::AB * t]; GACQ_UNPAIR(); }
-            SmallDft<S::Nc, true>::run(y);
-#pragma unroll
-            for (int t = 0; t < S::Nc; t++) gz[t * S::AB + tid] = make_float2(y[t].x, y[t].y);
-          }
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this thread's part of the row is in the L2
-        }
-        __syncthreads();
-        if (tid == 0 && ok) atomicAdd(&sync->ready[team][slot][0], 1u);
-        if (gprev >= 0 && ok) read_group(gprev, gseq - 1);
-        gprev = g;
-        gseq++;
-      }
-    }
-  }
-  if (gprev >= 0 && ok) read_group(gprev, gseq - 1);
-  if (!ok && tid == 0) {
-    __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(host_error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
-
 // cos / sin(2 pi u k / 31) in the lane order of the MFMA A operand: entry [lane][kk] = cos, [lane][4 + kk] = sin with
 // u = lane & 15, k = 4 kk + (lane >> 4); column k = 0 is the x0 term (cos 1/2 against 2 v0, sin 0)
 int mfma_table(gacq_ctx* ctx, const float** out) {
@@ -997,75 +766,11 @@ int inverse_t(gacq_ctx* ctx, const float2* Z, RowRec* partial, int B, long ng, f
   return GACQ_OK;
 }
 
-template <int M>
-int fused_t(gacq_ctx* ctx, const float2* X, const float2* C, const int* d_items, const int* d_fset, long ngroups, int nep, int P, int F, int D,
-            RowRec* rows, float tie_scale) {
-  using S = Pfa<M>;
-  using RG = FusedRing<M>;
-  int rc;
-  const float* cs = nullptr;
-  if ((rc = mfma_table(ctx, &cs)) != GACQ_OK) return rc;
-  int pch = (int)std::max<long>(1, std::min<long>(8, (long)nep * D * kR / 2048));
-  if (ctx->opt[GACQ_OPT_SPLIT_PCH] >= 1) pch = (int)ctx->opt[GACQ_OPT_SPLIT_PCH];
-  int dt = (D >= 8) ? (M == 1980 ? 3 : 2) : 1;
-  if (ctx->opt[GACQ_OPT_SPLIT_DT] >= 1) dt = (int)ctx->opt[GACQ_OPT_SPLIT_DT];
-  if (dt < 1 || dt > 3) return set_error(ctx, GACQ_ERR_BAD_ARG, "split engine: Doppler bins per workgroup must be 1, 2 or 3");
-  const int nblk_ep = (nep + pch - 1) / pch, DG = (D + dt - 1) / dt;
-  const long nbatch_l = (long)nblk_ep * DG;
-  if (nbatch_l > (1L << 24)) return GACQ_ERR_UNSUPPORTED;          // the caller falls back to the two-launch path
-  const int nbatch = (int)nbatch_l;
-  // persistent grid: exactly what the device holds at once (every workgroup must be resident: the teams wait for each other)
-  static int resident = 0;
-  if (!resident) {
-    int per_cu = 0, cus = 0;
-    const void* k = dt == 3 ? (const void*)pfa_fused_kernel<M, 3> : dt == 2 ? (const void*)pfa_fused_kernel<M, 2> : (const void*)pfa_fused_kernel<M, 1>;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 256, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); return GACQ_ERR_UNSUPPORTED; }
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus < 1) { (void)hipGetLastError(); return GACQ_ERR_UNSUPPORTED; }
-    resident = std::min(per_cu, 3) * cus;
-  }
-  if (resident < 8 * kR) return GACQ_ERR_UNSUPPORTED;
-  const bool fresh = ctx->fused_ring.cap < sizeof(float2) * RG::ring_elems();
-  if ((rc = ensure(ctx, ctx->fused_ring, sizeof(float2) * RG::ring_elems())) != GACQ_OK) return rc;
-  if (fresh) GACQ_HIP(ctx, hipMemsetAsync(ctx->fused_ring.p, 0, ctx->fused_ring.cap, ctx->stream));      // the tail columns of every row stay zero for ever
-  const size_t pub_bytes = sizeof(unsigned) * (size_t)8 * kFusedTeams * (nbatch + 1);
-  if ((rc = ensure(ctx, ctx->fused_sync, sizeof(FusedSync) + pub_bytes)) != GACQ_OK) return rc;
-  GACQ_HIP(ctx, hipMemsetAsync(ctx->fused_sync.p, 0, sizeof(FusedSync) + pub_bytes, ctx->stream));
-  if (!ctx->fused_err.p) {
-    if ((rc = ensure_pinned(ctx, ctx->fused_err, 64)) != GACQ_OK) return rc;
-    std::memset(ctx->fused_err.p, 0, 64);
-  }
-  if ((rc = ensure(ctx, ctx->partial, sizeof(RowRec) * (size_t)ngroups * kR)) != GACQ_OK) return rc;
-  FusedSync* sync = (FusedSync*)ctx->fused_sync.p;
-  unsigned* pub = (unsigned*)((char*)ctx->fused_sync.p + sizeof(FusedSync));
-  const float inv_n = 1.0f / (float)S::N;
-#define GACQ_LAUNCH_FUSED(DT_)                                                                                                                      \
-  hipLaunchKernelGGL((pfa_fused_kernel<M, DT_>), dim3((unsigned)resident), dim3(256), 0, ctx->stream, X, C, (float2*)ctx->fused_ring.p, sync, pub,   \
-                     (RowRec*)ctx->partial.p, cs, d_items, d_fset, ngroups, nblk_ep, nbatch, pch, P, F, D, inv_n, tie_scale, (unsigned*)ctx->fused_err.p)
-  if (dt == 3) GACQ_LAUNCH_FUSED(3);
-  else if (dt == 2) GACQ_LAUNCH_FUSED(2);
-  else GACQ_LAUNCH_FUSED(1);
-#undef GACQ_LAUNCH_FUSED
-  GACQ_HIP(ctx, hipGetLastError());
-  return split_combine(ctx, (const RowRec*)ctx->partial.p, rows, 0, ngroups, kR, tie_scale);
-}
-
 }  // namespace
 
 namespace gacq {
 
 bool pfa_supported(int N) { return N == 61380 || N == 30690; }
-
-// K2 + inner inverse transforms + inverse DFT-31 + |.| + reduce in ONE launch, Z' through the XCDs' L2s (pfa_fused_kernel): one block, raw
-// metric.  GACQ_ERR_UNSUPPORTED = use the two-launch path.
-int pfa_fused_correlate(gacq_ctx* ctx, const float2* X, const float2* C, const int* d_items, const int* d_fset, int nepoch, int P, int F, int D,
-                        int N, RowRec* rows, float tie_scale) {
-  const long ngroups = (long)nepoch * P * D;
-  if ((long)nepoch * P >= (1L << 30) || ngroups * kR >= (1L << 31)) return GACQ_ERR_UNSUPPORTED;
-  if (ctx->fused_err.p && *(volatile unsigned*)ctx->fused_err.p) return GACQ_ERR_UNSUPPORTED;      // a wait expired in an earlier launch: stay on the two-launch path
-  if (N == 61380) return fused_t<1980>(ctx, X, C, d_items, d_fset, ngroups, nepoch * P, P, F, D, rows, tie_scale);
-  if (N == 30690) return fused_t<990>(ctx, X, C, d_items, d_fset, ngroups, nepoch * P, P, F, D, rows, tie_scale);
-  return GACQ_ERR_UNSUPPORTED;
-}
 
 int pfa_row_pitch(int N) { return N == 61380 ? Pfa<1980>::Mp : (N == 30690 ? Pfa<990>::Mp : 0); }
 

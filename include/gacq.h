@@ -148,10 +148,7 @@ int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes);
                                 /*     matrix pipe (v_mfma_f32_16x16x4_f32, exact fp32) instead of packed math on the VALU.  Off: measured     */
                                 /*     12-18 % slower -- the stage is paced by its load stream, not by arithmetic                             */
                                 /*     (profiles/r05_engine3_prime_factor_vs_cooley_tukey_ab.log)                                             */
-#define GACQ_OPT_SPLIT_FUSED 18    /* [1] prime-factor engine, one block, raw metric: the writer and the reader of the Z' round trip in ONE      */
-                                /*     persistent launch -- teams of 31 workgroups that the kernel forms per XCD (XCC id) pass Z' through that   */
-                                /*     XCD's L2, nothing of it reaches HBM; 0 = two launches through HBM                                      */
-#define GACQ_NOPTS 19
+#define GACQ_NOPTS 18
 int gacq_set_option(gacq_ctx* ctx, int option, long value);
 int gacq_get_option(gacq_ctx* ctx, int option, long* value);
 

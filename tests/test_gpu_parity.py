@@ -667,10 +667,9 @@ R31_CASES = ["cfg4_l5i_subset", "l5q_subset", "cfg4_b2ad_b80", "gal_e6b", "gal_e
              "xona_x5p", "bds_b2ap", "bds_b2bq", "gal_e5ai", "gal_e5aq", "gal_e5bi", "gal_e6c", "glo_l3ocp"]
 
 
-# engine 3 at N = 61380 / 30690: the prime-factor form as ONE launch (Z' through the L2s; default where it applies: one block, raw
-# metric), as two launches with the DFT-31 on the VALU / on the matrix pipe, and the Cooley-Tukey form with rocFFT inner transforms
-# (GACQ_OPT_FUSED_INNER 0) -- next to the rocFFT pipeline five different arithmetic / control paths.  (engine, fused_inner, split_mfma, split_fused)
-R31_FORMS = {"rocfft-pipeline": (1, 1, 0, 1), "pfa-one-launch": (3, 1, 0, 1), "pfa-valu": (3, 1, 0, 0), "pfa-mfma": (3, 1, 1, 0), "ct-rocfft": (3, 0, 0, 0)}
+# engine 3 at N = 61380 / 30690: the prime-factor form with the DFT-31 on the VALU (default) / on the matrix pipe, and the
+# Cooley-Tukey form with rocFFT inner transforms (GACQ_OPT_FUSED_INNER 0) -- next to the rocFFT pipeline four different arithmetic paths
+R31_FORMS = {"rocfft-pipeline": (1, 1, 0), "pfa-valu": (3, 1, 0), "pfa-mfma": (3, 1, 1), "ct-rocfft": (3, 0, 0)}
 
 
 @pytest.mark.parametrize("cid", R31_CASES)
@@ -679,18 +678,16 @@ def test_radix31_split_and_rocfft_match_reference_golden(engine, golden_cases, c
     """N = 61380 / 30690: rocFFT (Bluestein) pipeline (1) and every form of the radix-31 split engine (3) separately."""
     case = golden_cases[cid]
     x = case_iq(case)
-    eng, fused, mfma, one = R31_FORMS[form]
+    eng, fused, mfma = R31_FORMS[form]
     engine.set_engine(eng)
     engine.set_option("fused_inner", fused)
     engine.set_option("split_mfma", mfma)
-    engine.set_option("split_fused", one)
     try:
         got = engine.search_all(case["script"], x, case["items"], case["doppler_search"], case["ms"])
     finally:
         engine.set_engine(0)
         engine.set_option("fused_inner", 1)
         engine.set_option("split_mfma", 0)
-        engine.set_option("split_fused", 1)
     _assert_results(got, case["results"], case)
 
 
