@@ -106,18 +106,37 @@ __device__ __forceinline__ v2 lds_ld1(const v2& x) { const v2 r = x; GACQ_UNPAIR
 // PRE: bit 0 = the pass-1 powers (W_4096^t)^k, bit 1 = the pass-2 powers (W_256^(t&15))^k come precomputed in *pa / *pb (already
 // conjugated for an inverse transform) instead of being rebuilt from wa / wb by 14 complex products per pass.
 // bit 2 = the pass-2 powers are read from an LDS table (tb2[16 (k - 1)], tb2 already offset by the lane's class t & 15).
+// bit 3 = rising wave priority through the row (F4K_PRIO above).
+// Rising wave priority through the segments of a 4096-point row (PRE bit 3 of fft4096; the caller resets it to GACQ_F4K_P4 at the top
+// of its row loop): after the exchange-1 writes | after the exchange-2 writes | after the exchange-2 reads have been issued.  The four
+// waves of a SIMD belong to four independent workgroups; letting the one that is furthest into its row issue first keeps the workgroups
+// out of phase, so one's LDS round trips and barriers fall under another's arithmetic.  Headline step (1024 epochs x 40 bins x 32 PRNs):
+// 5.50-5.53 -> 5.30-5.34 ms, falling levels (3-2-1-0, what the 16384-point kernels use inside ONE workgroup) 5.56, levels raised only
+// in the last segment 5.48 (profiles/r05_headline_kernel_wave_priority_sweep.log).  -1 = leave the priority alone.
+#ifndef GACQ_F4K_P1
+#define GACQ_F4K_P1 1
+#define GACQ_F4K_P2 2
+#define GACQ_F4K_P3 3
+#define GACQ_F4K_P4 0
+#endif
+#ifndef GACQ_F4K_P0
+#define GACQ_F4K_P0 -1      // at the first radix-16 pass (sweeps only)
+#endif
+#define F4K_PRIO(n) do { if ((n) >= 0) asm volatile("s_setprio %0" :: "n"(n) : "memory"); } while (0)
 template <bool INV, int PRE = 0>
 __device__ __forceinline__ void fft4096(v2 (&v)[kR], v2* lds, v2 wa, v2 wb, const v2 (*pa)[15] = nullptr, const v2 (*pb)[15] = nullptr,
                                         int t = -1, const v2* tb2 = nullptr) {
   if (t < 0) t = threadIdx.x;                       // lane index within the 256-lane group that owns this transform
   if (INV && !(PRE & 1)) wa.y = -wa.y;
   if (INV && !(PRE & 2)) wb.y = -wb.y;
+  F4K_PRIO((PRE & 8) ? GACQ_F4K_P0 : -1);
   dft16<INV>(v);
   if (PRE & 1) apply_table(v, *pa); else apply_powers(v, wa);
   {  // exchange 1: (n0,n1;k0) -> (n0,k0;n1)
     const int wbase = (t & 15) + 256 * (t >> 4);
 #pragma unroll
     for (int k = 0; k < kR; k++) lds[wbase + 16 * k] = v[rev16(k)];
+    F4K_PRIO((PRE & 8) ? GACQ_F4K_P1 : -1);
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < kR; j++) v[j] = LDS_LD(lds[t + 256 * j]);
@@ -133,9 +152,11 @@ __device__ __forceinline__ void fft4096(v2 (&v)[kR], v2* lds, v2 wa, v2 wb, cons
     const int wbase = (t >> 4) + kPitch * (t & 15);
 #pragma unroll
     for (int k = 0; k < kR; k++) lds[wbase + 16 * k] = v[rev16(k)];
+    F4K_PRIO((PRE & 8) ? GACQ_F4K_P2 : -1);
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < kR; j++) v[j] = LDS_LD(lds[t + kPitch * j]);
+    F4K_PRIO((PRE & 8) ? GACQ_F4K_P3 : -1);
   }
   dft16<INV>(v);
 }
@@ -900,7 +921,7 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float
 #define GACQ_F4K_PF 0     // experiment: 1 = the batch kernel issues the next item's code-spectrum loads right after the magnitudes
 #endif
 #ifndef GACQ_PRE4K
-#define GACQ_PRE4K 5      // batch kernel: pass-1 powers in registers (1) + pass-2 powers from the LDS table (4); A/B partner: 1
+#define GACQ_PRE4K 13     // batch kernel: pass-1 powers in registers (1) + pass-2 powers from the LDS table (4) + rising wave priorities (8)
 #endif
 
 // ---- pieces of the single-launch search (lds_fused4k_kernel<.., SCAN>) ------------------------------------------------------------
@@ -1054,6 +1075,7 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_fused4k_kernel(const float2*
     for (int jp = 0; jp < kR / 2; jp++) ld_pair(cres, lane_off, jp, v[2 * jp], v[2 * jp + 1]);
   }
   for (int p = p0; p < p1; p++) {
+    if (PREA && (GACQ_PRE4K & 8)) F4K_PRIO(GACQ_F4K_P4);
     // keep the (remaining) twiddle powers out of the loop-invariant set
     if (PREA) asm volatile("" : "+v"(wb.x), "+v"(wb.y));
     else asm volatile("" : "+v"(wa.x), "+v"(wa.y), "+v"(wb.x), "+v"(wb.y));
@@ -1082,7 +1104,11 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_fused4k_kernel(const float2*
 #pragma unroll
     for (int k = 0; k < kR; k++) {
       const v2 r = v[rev16(k)];
+#ifdef GACQ_ABL_NOSQRT                                               // ablation build (wrong results): what the 16 quarter-rate square roots cost
+      m[k] = norm2(r);
+#else
       m[k] = __builtin_amdgcn_sqrtf(norm2(r));                      // np.absolute(ifft(...)) * N
+#endif
     }
     if (PF && p + 1 < p1) {                             // v is dead: the next item's operands travel under the peak search and the barrier
 #pragma unroll
