@@ -123,6 +123,8 @@ __device__ __forceinline__ v2 lds_ld1(const v2& x) { const v2 r = x; GACQ_UNPAIR
 #define GACQ_F4K_P0 -1      // at the first radix-16 pass (sweeps only)
 #endif
 #define F4K_PRIO(n) do { if ((n) >= 0) asm volatile("s_setprio %0" :: "n"(n) : "memory"); } while (0)
+// (The same levels in lds_inner_correlate_kernel -- engine 4's writer, store-bound -- and in lds_correlate_kernel with B = 10 measured within
+// the run-to-run noise, 0-2 %: not applied there.)
 template <bool INV, int PRE = 0>
 __device__ __forceinline__ void fft4096(v2 (&v)[kR], v2* lds, v2 wa, v2 wb, const v2 (*pa)[15] = nullptr, const v2 (*pb)[15] = nullptr,
                                         int t = -1, const v2* tb2 = nullptr) {

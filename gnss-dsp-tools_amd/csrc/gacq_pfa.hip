@@ -195,6 +195,15 @@ __global__ __launch_bounds__(Pfa<M>::NT) void pfa_inner_forward_kernel(float2* _
 // unnormalised.  Workgroup = (k1, chunk of pch consecutive (epoch, item) pairs, DT consecutive Doppler bins, block): the pass-a operands
 // of the DT rows X[e,f,d..d+DT-1,b][k1][.] stay in registers while the items change, and every code-spectrum row fetched serves DT
 // correlation rows.  Two row buffers: the pass-c reads of a row need no barrier before the next row's pass-a writes.
+// Rising wave priority through a row (row start | before the barrier after pass a | before the barrier after pass b), as in the 4096-point
+// batch kernel (gacq_ldsfft.hip, F4K_PRIO): the workgroups of a CU stay out of phase.  Worth 1-2 % at M = 1980 and 3-5 % at M = 990
+// (profiles/r05_engine3_writer_wave_priority_sweep.log; falling levels and a raise only before the stores measured no better).
+#ifndef GACQ_PFA_P0
+#define GACQ_PFA_P0 0
+#define GACQ_PFA_P1 1
+#define GACQ_PFA_P2 2
+#endif
+#define PFA_PRIO(n) do { if ((n) >= 0) asm volatile("s_setprio %0" :: "n"(n) : "memory"); } while (0)
 template <int M, int DT>
 __global__ __launch_bounds__(Pfa<M>::NT, DT >= 3 ? 3 : 4) void pfa_inner_corr_kernel(
     const float2* __restrict__ X, const float2* __restrict__ C, float2* __restrict__ Z, const int* __restrict__ items, const int* __restrict__ fset,
@@ -233,6 +242,7 @@ __global__ __launch_bounds__(Pfa<M>::NT, DT >= 3 ? 3 : 4) void pfa_inner_corr_ke
       float2* gz = Z + (((g - g0) * B + b) * kR + k1) * (long)S::Mp;
       v2* bw = buf[par & 1];
       par++;
+      PFA_PRIO(GACQ_PFA_P0);
       if (act_a) {
         if (cv_ep != ep) {
           const float2* gc = C + ((long)items[p] * kR + k1) * (long)M;
@@ -261,8 +271,10 @@ __global__ __launch_bounds__(Pfa<M>::NT, DT >= 3 ? 3 : 4) void pfa_inner_corr_ke
       }
       cv_ep = (dd == DT - 1 && i0 + 1 < pch) ? ep + 1 : ep;
       have[dd] = gx;
+      PFA_PRIO(GACQ_PFA_P1);
       __syncthreads();
       pfa_pass_b<M, true>(bw, pb);
+      PFA_PRIO(GACQ_PFA_P2);
       __syncthreads();
       if (act_c) {
         v2 y[S::Nc];
