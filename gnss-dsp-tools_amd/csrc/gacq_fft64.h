@@ -143,7 +143,10 @@ __device__ __forceinline__ void make_powers(cd (&pw)[15], cd w1) {
 #else
 #define F64_UR() do {} while (0)
 #endif
-template <bool INV, bool TAB2 = false>
+// PRIO: rising wave priority through the row (1 after the exchange-1 writes, 2 after the exchange-2 writes, 3 once the exchange-2 reads
+// are issued; the caller resets to 0 at the top of its row loop) -- see F4K_PRIO in gacq_ldsfft.hip.
+#define F64_PRIO(n) do { if (PRIO) asm volatile("s_setprio %0" :: "n"(n) : "memory"); } while (0)
+template <bool INV, bool TAB2 = false, bool PRIO = false>
 __device__ __forceinline__ void fft4096(cd (&v)[16], double* lds, cd wa, cd wb, int t, const cd* tb2 = nullptr) {
   double* lre = lds;
   double* lim = lds + kPlane;
@@ -154,6 +157,7 @@ __device__ __forceinline__ void fft4096(cd (&v)[16], double* lds, cd wa, cd wb, 
     const int wbase = (t & 15) + 256 * (t >> 4);
 #pragma unroll
     for (int k = 0; k < 16; k++) { lre[wbase + 16 * k] = v[rev16(k)].x; lim[wbase + 16 * k] = v[rev16(k)].y; }
+    F64_PRIO(1);
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; j++) { v[j].x = lre[t + 256 * j]; F64_UR(); v[j].y = lim[t + 256 * j]; F64_UR(); }
@@ -170,9 +174,11 @@ __device__ __forceinline__ void fft4096(cd (&v)[16], double* lds, cd wa, cd wb, 
     const int wbase = (t >> 4) + kPitch * (t & 15);
 #pragma unroll
     for (int k = 0; k < 16; k++) { lre[wbase + 16 * k] = v[rev16(k)].x; lim[wbase + 16 * k] = v[rev16(k)].y; }
+    F64_PRIO(2);
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; j++) { v[j].x = lre[t + kPitch * j]; F64_UR(); v[j].y = lim[t + kPitch * j]; F64_UR(); }
+    F64_PRIO(3);
   }
   dft16<INV>(v);
 }

@@ -114,6 +114,9 @@ __global__ void best_doppler64_kernel(const RowRec64* __restrict__ rows, gacq_pe
 // (max, first argmax, sum) of the row.  Nothing but x, the complex128 code spectra (natural order: lane t reads C[t + 256 j], 16
 // bytes per lane, 1 KiB per wave and instruction) and one 24-byte record per row touches HBM; the rocFFT pipeline this replaces
 // moves 5 x 64 KB per row.  64 KB of LDS per workgroup (gacq_fft64.h) -> two workgroups per CU, <= 256 VGPRs.
+#ifndef GACQ_C128_PRIO
+#define GACQ_C128_PRIO true      // rising wave priorities (gacq_fft64.h F64_PRIO): 13.67 -> 12.88 ms per 1024-epoch step, profiles/r05_headline_kernel_wave_priority_sweep.log
+#endif
 __global__ __launch_bounds__(kBlock, 2) void fused4k_c128_kernel(XSrc x, size_t epoch_stride, const double2* __restrict__ C,
                                                                  const int* __restrict__ items, const double* __restrict__ freq,
                                                                  const double2* __restrict__ tab, const double2* __restrict__ tw,
@@ -164,12 +167,13 @@ __global__ __launch_bounds__(kBlock, 2) void fused4k_c128_kernel(XSrc x, size_t 
   const double inv_n = 1.0 / (double)kN;
   for (int p = p0; p < p1; p++) {
     const double2* cp = C + (long)items[p] * kN + t;
+    if (GACQ_C128_PRIO) asm volatile("s_setprio 0" ::: "memory");
     cd v[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) { const double2 c = cp[256 * j]; v[j] = cd{c.x, c.y}; }
 #pragma unroll
     for (int j = 0; j < 16; j++) v[j] = v[j] * xr[j];
-    fft4096<true, true>(v, lds64, wa, wb, t, s_tw2 + (t & 15));
+    fft4096<true, true, GACQ_C128_PRIO>(v, lds64, wa, wb, t, s_tw2 + (t & 15));
     // (max, first argmax, sum) of the wave's 1024 magnitudes: maximum first (per lane, then over the wave on DPP), location second
     // (one compare per register against the wave-uniform maximum, lane masks folded on the scalar unit) -- wave_first_max's scheme
     double m[16], sum = 0.0, lmax = 0.0;
