@@ -185,6 +185,15 @@ __device__ __forceinline__ bool arrive_last(unsigned* counter, int B) {
   return s_last != 0;
 }
 
+// Rows to re-evaluate in this launch.  A list that overflowed is dropped WHOLE: which pairs found room depends on the arrival order of
+// the listing kernel's atomics, and a result that differs from run to run (or from rank to rank of a sharded merge, where every rank
+// resolves the same gathered records on its own) is worse than fp32 locations that are at least reproducible.  The overflow test
+// itself -- all candidate rows of the launch against the capacity -- does not depend on the order.
+__device__ __forceinline__ unsigned list_count(const TieLists& tl) {
+  const unsigned n = tl.c->nrows;
+  return n > (unsigned)tl.cap ? 0u : n;
+}
+
 // Work item = (listed row, block) when the per-block magnitude rows fit (qb != nullptr: B workgroups share a row, ~1 / B of the
 // latency -- a re-evaluation sits in the stream between two searches), else one listed row with its blocks in sequence.
 //   q[k] = sum_b | ifft( C_p * conj(fft(x[b n : b n + N] * nco)) )[k] |   in complex128   (acquire-gps-l1.py:28-35;
@@ -195,7 +204,7 @@ __global__ __launch_bounds__(kTieThreads) void tie_recheck_kernel(TieLists tl, u
                                                                    const int* __restrict__ fset, const double* __restrict__ freq,
                                                                    const double2* __restrict__ tab64, const double2* __restrict__ WN,
                                                                    char* __restrict__ scratch, int n, int N, int P, int D, int B, Radices rad) {
-  const unsigned count = min(tl.c->nrows, (unsigned)tl.cap);
+  const unsigned count = list_count(tl);
   const unsigned nwork = qb ? count * (unsigned)B : count;
   char* mine = scratch + (size_t)blockIdx.x * ((size_t)N * 40);
   double2* bufa = reinterpret_cast<double2*>(mine);
@@ -256,7 +265,7 @@ __global__ __launch_bounds__(256, 1) void tie_recheck4k_kernel(TieLists tl, unsi
   extern __shared__ __attribute__((aligned(16))) double lds64[];
   __shared__ double s_peak[4], s_sum[4];
   __shared__ int s_idx[4];
-  const unsigned count = min(tl.c->nrows, (unsigned)tl.cap);
+  const unsigned count = list_count(tl);
   const unsigned nwork = qb ? count * (unsigned)B : count;
   const int t = threadIdx.x;
   const double2 wa2 = WN[t], wb2 = WN[16 * (t & 15)];
@@ -358,7 +367,7 @@ __global__ __launch_bounds__(256, 1) void tie_recheck_split_kernel(TieLists tl, 
   using namespace gacq::f64;
   constexpr int M = kN, N = R * kN;
   extern __shared__ __attribute__((aligned(16))) double lds64[];
-  const unsigned count = min(tl.c->nrows, (unsigned)tl.cap);
+  const unsigned count = list_count(tl);
   const unsigned nwork = count * (unsigned)B * (unsigned)R;
   const int t = threadIdx.x;
   const cd wa = ldc(WN + t * R), wb = ldc(WN + 16 * (t & 15) * R);      // W_4096^t, W_256^(t & 15)
@@ -454,9 +463,11 @@ __global__ __launch_bounds__(256, 1) void tie_recheck_split_kernel(TieLists tl, 
 __global__ __launch_bounds__(256) void tie_resolve_kernel(TieLists tl, gacq_peak* __restrict__ out, const gacq_peak* __restrict__ fp32_guess, int N,
                                                            int normalised) {
   const unsigned neps = min(tl.c->neps, (unsigned)tl.cap);
+  const bool dropped = tl.c->nrows > (unsigned)tl.cap;      // see list_count(): every listed pair keeps its fp32 answer as well
   unsigned moved = 0;
   for (unsigned i = threadIdx.x; i < neps; i += blockDim.x) {
     const TieEp ep = tl.eps[i];
+    if (dropped) { out[ep.ep] = fp32_guess[i]; continue; }
     double best = 0.0;
     int bidx = -1, bd = -1;
     for (int s = ep.slot0; s < ep.slot0 + ep.cnt; s++) {
@@ -476,7 +487,8 @@ __global__ __launch_bounds__(256) void tie_resolve_kernel(TieLists tl, gacq_peak
   __syncthreads();
   if (threadIdx.x == 0) {
     tl.c->flagged += neps;
-    tl.c->rows += min(tl.c->nrows, (unsigned)tl.cap);
+    if (dropped) tl.c->overflow += neps;      // (the pairs that found no room were counted by the listing kernel)
+    else tl.c->rows += tl.c->nrows;
     tl.c->nrows = 0;
     tl.c->neps = 0;
   }

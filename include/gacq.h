@@ -137,8 +137,10 @@ int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes);
                                 /*     the complex128 one and not whichever side of a near-tie the fp32 rounding fell on                   */
 #define GACQ_OPT_TIE_EPS_PPB 14   /* [8000] relative gap, in parts per billion, below which two magnitudes / metrics count as tied         */
                                 /*     (8e-6 ~ 6 x the worst fp32-vs-complex128 metric error observed); 1000000000 re-evaluates every row  */
-#define GACQ_OPT_TIE_CAP 15       /* [0 = auto: 64 + (epochs x items) / 16] rows one call can re-evaluate; pairs beyond it keep their fp32  */
-                                /*     answer and are counted in gacq_get_tie_stats()[2].  The automatic capacity is bounded (never below   */
+#define GACQ_OPT_TIE_CAP 15       /* [0 = auto: 64 + (epochs x items) / 16] rows one call can re-evaluate.  A call whose candidate rows      */
+                                /*     exceed it re-evaluates NONE: every ambiguous pair of the call keeps its fp32 answer (reproducible,    */
+                                /*     the same on every rank of a sharded merge -- which pairs would have found room is not) and is         */
+                                /*     counted in gacq_get_tie_stats()[2].  The automatic capacity is bounded (never below                  */
                                 /*     16) so that the re-evaluation's row buffers (B x N x 8-24 bytes per listed row, allocated for the    */
                                 /*     capacity) stay within an eighth of the workspace limit (gacq_set_workspace_limit), between 32 and    */
                                 /*     256 MiB; an explicit value is taken as given                                                         */
