@@ -164,8 +164,25 @@ class GacqError(RuntimeError):
         self.code = code
 
 
+WARN_TIE_LIST_FULL = 1
+
+
+class TieListFull(UserWarning):
+    """gacq.h GACQ_WARN_TIE_LIST_FULL: the results are valid, but the call's near-ties were NOT re-evaluated in complex128."""
+
+
 def check(rc, ctx=None):
     if rc < 0:
         msg = lib.gacq_last_error(ctx)
         raise GacqError(rc, msg.decode() if msg else "")
     return rc
+
+
+def check_search(rc, ctx=None):
+    """check() for gacq_search / gacq_search64, whose positive return is a warning (other entry points return counts)."""
+    if rc == WARN_TIE_LIST_FULL:
+        import warnings
+        warnings.warn("tie-safe re-evaluation list full (option tie_cap / workspace limit): every near-tied (epoch, item) of this call kept "
+                      "its fp32 location", TieListFull, stacklevel=3)
+        return rc
+    return check(rc, ctx)

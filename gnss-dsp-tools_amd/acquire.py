@@ -275,8 +275,8 @@ class Engine:
         fn = nat.lib.gacq_search64 if (wide and need and len(dopplers)) else nat.lib.gacq_search
         rc = fn(s._h, xc.__array_interface__["data"][0], len(xc), idx_p, len(idx),
                 dopplers.__array_interface__["data"][0] if len(dopplers) else None, len(dopplers), bias_p, blocks, res)
-        if rc < 0:
-            nat.check(rc, self._ctx)
+        if rc:
+            nat.check_search(rc, self._ctx)
         return _as_tuples(view)
 
     def _family(self, names, items, ms=None):
@@ -320,8 +320,8 @@ class Engine:
         idx = np.arange(total, dtype=np.int32)
         res = (nat.Result * total)()
         fn = nat.lib.gacq_search64 if wide else nat.lib.gacq_search
-        nat.check(fn(fam._h, xc.ctypes.data_as(ctypes.c_void_p), len(xc), idx.ctypes.data_as(nat.c_int_p), total,
-                     dopplers.ctypes.data_as(nat.c_double_p), len(dopplers), None, blocks, res), self._ctx)
+        nat.check_search(fn(fam._h, xc.ctypes.data_as(ctypes.c_void_p), len(xc), idx.ctypes.data_as(nat.c_int_p), total,
+                            dopplers.ctypes.data_as(nat.c_double_p), len(dopplers), None, blocks, res), self._ctx)
         flat = _as_tuples(res)
         out, at = [], 0
         for it in lists:

@@ -440,7 +440,12 @@ __global__ __launch_bounds__(256) void best_doppler_kernel(const RowRec* __restr
   if (slot0 + cnt > tl.cap || slot0 < 0) {
     // no room: the pair keeps its fp32 answer; the slots reserved below the capacity are voided
     for (int s = slot0 + lane; s < slot0 + cnt && s < tl.cap && s >= 0; s += 64) { TieRow v; v.ep = -1; v.d = 0; tl.rows[s] = v; }
-    if (lane == 0) { out[ep] = o; atomicAdd(&tl.c->overflow, 1ull); }
+    if (lane == 0) {
+      *(volatile unsigned*)tl.host_full = 1u;      // reaches the host before the record does (gacq_search watches the records)
+      __threadfence_system();
+      out[ep] = o;
+      atomicAdd(&tl.c->overflow, 1ull);
+    }
     return;
   }
   if (lane == 0) {
@@ -523,6 +528,7 @@ void gacq_destroy(gacq_ctx* ctx) {
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   if (ctx->pin_x.p) (void)hipHostFree(ctx->pin_x.p);
   if (ctx->pin_peaks.p) (void)hipHostFree(ctx->pin_peaks.p);
+  if (ctx->pin_tie.p) (void)hipHostFree(ctx->pin_tie.p);
   if (ctx->bar_x.p) (void)hipFree(ctx->bar_x.p);
   if (ctx->bar_s.p) (void)hipFree(ctx->bar_s.p);
   for (auto& sl : ctx->grid_slots) for (DevBuf* b : {&sl.dfreq, &sl.dfset, &sl.ditems}) if (b->p) (void)hipFree(b->p);
@@ -1073,6 +1079,8 @@ __global__ void merge_peaks_kernel(const gacq_peak* __restrict__ peaks, gacq_pea
   const int slot0 = (int)atomicAdd(&tl.c->nrows, (unsigned)cnt);
   if (slot0 < 0 || slot0 + cnt > tl.cap) {
     for (int sl = slot0; sl < slot0 + cnt && sl < tl.cap && sl >= 0; sl++) { TieRow v; v.ep = -1; v.d = 0; tl.rows[sl] = v; }
+    *(volatile unsigned*)tl.host_full = 1u;
+    __threadfence_system();
     out[i] = best;
     atomicAdd(&tl.c->overflow, 1ull);
     return;
@@ -1254,6 +1262,16 @@ int gacq_finalize(const gacq_sigdesc* desc, const gacq_peak* peaks, int nshard, 
   return GACQ_OK;
 }
 
+// GACQ_WARN_TIE_LIST_FULL for the host-buffer searches: the listing kernels set a pinned host word BEFORE they write the record of a pair
+// that found no room, so a caller who has seen every record has seen the word.  It is cleared only with the stream drained (the
+// re-evaluation kernels that trail the records are still running when the watched records are complete).
+static int tie_list_full_warning(gacq_ctx* ctx) {
+  if (!ctx->pin_tie.p || *(volatile unsigned*)ctx->pin_tie.p == 0u) return GACQ_OK;
+  GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *(volatile unsigned*)ctx->pin_tie.p = 0u;
+  return GACQ_WARN_TIE_LIST_FULL;
+}
+
 int gacq_search(gacq_sig* sig, const float* x_iq, size_t nsamp, const int* items, int nitems, const double* dopplers,
                 int nd, const double* item_bias_hz, int blocks, gacq_result* out) {
   int rc = check_search_args(sig, x_iq, nsamp, 1, items, nitems, dopplers, nd, blocks, out);
@@ -1315,7 +1333,8 @@ int gacq_search(gacq_sig* sig, const float* x_iq, size_t nsamp, const int* items
     std::atomic_thread_fence(std::memory_order_acquire);
   }
   if (!complete) GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return gacq_finalize(&sig->desc, (const gacq_peak*)ctx->pin_peaks.p, 1, nullptr, nitems, dopplers, nd, out);
+  rc = gacq_finalize(&sig->desc, (const gacq_peak*)ctx->pin_peaks.p, 1, nullptr, nitems, dopplers, nd, out);
+  return rc != GACQ_OK ? rc : tie_list_full_warning(ctx);
 }
 
 int gacq_search64(gacq_sig* sig, const double* x_iq, size_t nsamp, const int* items, int nitems, const double* dopplers,
@@ -1335,7 +1354,8 @@ int gacq_search64(gacq_sig* sig, const double* x_iq, size_t nsamp, const int* it
   rc = gacq_search_batch_dev64(sig, ctx->xstage.p, need, 1, items, nitems, dopplers, nd, item_bias_hz, blocks, ctx->pin_peaks.p);
   if (rc != GACQ_OK) return rc;
   GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return gacq_finalize(&sig->desc, (const gacq_peak*)ctx->pin_peaks.p, 1, nullptr, nitems, dopplers, nd, out);
+  rc = gacq_finalize(&sig->desc, (const gacq_peak*)ctx->pin_peaks.p, 1, nullptr, nitems, dopplers, nd, out);
+  return rc != GACQ_OK ? rc : tie_list_full_warning(ctx);
 }
 
 int gacq_debug_nco_indices(gacq_sig* sig, int kernel, double doppler, double bias_hz, int* idx_out) {

@@ -559,6 +559,12 @@ int tie_lists(gacq_ctx* ctx, long nep, int N, int B, TieLists* out, gacq_peak** 
     GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->tie_cap = cap;
   }
+  if (!ctx->pin_tie.p) {
+    int rc = ensure_pinned(ctx, ctx->pin_tie, 64);
+    if (rc != GACQ_OK) return rc;
+    *(volatile unsigned*)ctx->pin_tie.p = 0u;
+  }
+  out->host_full = (unsigned*)ctx->pin_tie.p;
   // the lists are always laid out for the allocated capacity; a smaller request only lowers the fill limit
   char* base = (char*)ctx->tie.p;
   const int lay = ctx->tie_cap;

@@ -33,6 +33,10 @@ extern "C" {
 #define GACQ_ERR_NO_DEVICE (-7)
 #define GACQ_ERR_INTERNAL (-8)
 #define GACQ_ERR_UNSUPPORTED (-9)
+/* Positive: the call succeeded and its results are valid, with a caveat.  gacq_search / gacq_search64 (the calls that wait for their
+ * results) return this when the call's tie-safe re-evaluation list was too small (GACQ_OPT_TIE_CAP): every ambiguous pair of the call
+ * kept its fp32 location.  The asynchronous device-buffer calls cannot report it: poll gacq_get_tie_stats()[2] after synchronising. */
+#define GACQ_WARN_TIE_LIST_FULL 1
 
 /* ---------------------------------------------------------------------------------------------
  * PRN chip generators (host only, no GPU needed).  `code` is the reference module name:

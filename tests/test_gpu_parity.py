@@ -588,7 +588,7 @@ def test_bench_measures_hbm_traffic_live_with_pmc_child_runs():
     assert agree["searches"] == 1024 * 32 and agree["peak_location_mismatches"] == 0 and agree["max_rel_metric_error"] < 1e-5, agree
     # round 4: the complex128 leg is one fused kernel per search with its own roofline entry, the fp32 engine timed in the same loop
     rr = ref["roofline"]
-    assert rr["kernel"] == "fused4k_c128_kernel" and rr["peak"] == 78.6 and 0.05 < rr["frac"] < 1.0 and rr["avg_kernel_ms"] <= ref["ms_per_step"], rr
+    assert rr["kernel"] == "fused4k_c128_kernel" and rr["peak"] == 78.6 and 0.05 < rr["frac"] < 1.0 and rr["avg_kernel_ms"] <= 1.02 * ref["ms_per_step"], rr      # (the events are taken in a short pass after the timed loop: same rate within the clock drift)
     assert ref["value"] > 1.5e11 and ref["f32_same_loop"]["seconds_timed"] >= 1.0, ref
     assert abs(ref["f32_over_f64"] - ref["f32_same_loop"]["value"] / ref["value"]) < 1e-9
     # round 4: the rows either side of the FFT search, the live stream ceilings and the tie-safe counters are in the driver-visible line

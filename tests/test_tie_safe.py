@@ -120,11 +120,24 @@ def test_full_list_keeps_the_fp32_answer_and_counts_it(fresh):
         assert st["rows_reevaluated"] == 0 and st["locations_changed"] == 0 and st["kept_fp32"] == launch * 16 * 32, st
         for k in ("idx", "d_index", "metric"):
             assert (got[k] == plain[k]).all(), k
+    # the host-buffer call reports it: GACQ_WARN_TIE_LIST_FULL -> a TieListFull warning, results still the fp32 ones
+    from gnss_dsp_tools_amd import _native as nat
+    with pytest.warns(nat.TieListFull):
+        host = fresh.search_blocks(sig, xs[0], items, dop, 1)
+    assert len(host) == len(items)
+    assert fresh.tie_stats()["kept_fp32"] == 3 * 16 * 32 + 32
+    import warnings
+    fresh.set_option("tie_eps_ppb", 8000)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", nat.TieListFull)      # an ordinary call afterwards carries no stale warning
+        fresh.search_blocks(sig, xs[0], items, dop, 1)
+    fresh.set_option("tie_eps_ppb", 1000000000)
     # ... and a list that fits is used again right away
+    rows_before = fresh.tie_stats()["rows_reevaluated"]
     fresh.set_option("tie_cap", 16 * 32 * 40)
     _peaks(fresh.search_batch_dev(sig, xd, items, dop, 1))
     st = fresh.tie_stats()
-    assert st["rows_reevaluated"] == 16 * 32 * 40 and st["kept_fp32"] == 3 * 16 * 32, st
+    assert st["rows_reevaluated"] - rows_before == 16 * 32 * 40 and st["kept_fp32"] == 3 * 16 * 32 + 32, st
 
 
 @pytest.mark.parametrize("name,items,ds,B,E", [("gps-l1", list(range(1, 13)), [-3000.0, 3000.0, 250.0], 2, 6),
