@@ -919,9 +919,6 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float
   }
 }
 
-#ifndef GACQ_F4K_PF
-#define GACQ_F4K_PF 0     // experiment: 1 = the batch kernel issues the next item's code-spectrum loads right after the magnitudes
-#endif
 #ifndef GACQ_PRE4K
 #define GACQ_PRE4K 13     // batch kernel: pass-1 powers in registers (1) + pass-2 powers from the LDS table (4) + rising wave priorities (8)
 #endif
@@ -1041,9 +1038,8 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_fused4k_kernel(const float2*
   // SCAN (latency path): a workgroup has only 1-4 rows, so every load it waits for is on the critical path of the whole search.
   // The first item's code spectrum is fetched under the forward transform, the next item's under the current inverse transform
   // (the registers come from giving up the resident twiddle powers: PREA is off in this instantiation).
-  constexpr bool PF2 = !SCAN && GACQ_F4K_PF == 2;      // experiment: prefetch a whole row ahead (registers from PREA = false)
-  v2 cn[SCAN || PF2 ? kR : 1];
-  if (SCAN || PF2) {
+  v2 cn[SCAN ? kR : 1];
+  if (SCAN) {
     const __amdgpu_buffer_rsrc_t c0 = row_rsrc(C + (long)items[p0] * kLdsN);
 #pragma unroll
     for (int jp = 0; jp < kR / 2; jp++) ld_pair(c0, lane_off, jp, cn[2 * jp], cn[2 * jp + 1]);
@@ -1069,22 +1065,13 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_fused4k_kernel(const float2*
   const float inv_n = 1.0f / (float)kLdsN;
   v2 pwa[PREA ? 15 : 1];
   if (PREA) make_powers(reinterpret_cast<v2(&)[15]>(pwa), v2{wa.x, -wa.y});      // conjugate: inverse transform
-  constexpr bool PF = !SCAN && GACQ_F4K_PF == 1;
-  v2 v[kR];
-  if (PF) {
-    const __amdgpu_buffer_rsrc_t cres = row_rsrc(C + (long)items[p0] * kLdsN);
-#pragma unroll
-    for (int jp = 0; jp < kR / 2; jp++) ld_pair(cres, lane_off, jp, v[2 * jp], v[2 * jp + 1]);
-  }
   for (int p = p0; p < p1; p++) {
     if (PREA && (GACQ_PRE4K & 8)) F4K_PRIO(GACQ_F4K_P4);
     // keep the (remaining) twiddle powers out of the loop-invariant set
     if (PREA) asm volatile("" : "+v"(wb.x), "+v"(wb.y));
     else asm volatile("" : "+v"(wa.x), "+v"(wa.y), "+v"(wb.x), "+v"(wb.y));
-    if (PF) {
-#pragma unroll
-      for (int jj = 0; jj < kR; jj++) v[jj] = cmul(v[jj], xr[jj]);
-    } else if (SCAN || PF2) {
+    v2 v[kR];
+    if (SCAN) {
 #pragma unroll
       for (int jj = 0; jj < kR; jj++) v[jj] = cmul(cn[jj], xr[jj]);
       if (p + 1 < p1) {
@@ -1106,18 +1093,7 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_fused4k_kernel(const float2*
 #pragma unroll
     for (int k = 0; k < kR; k++) {
       const v2 r = v[rev16(k)];
-#ifdef GACQ_ABL_NOSQRT                                               // ablation build (wrong results): what the 16 quarter-rate square roots cost
-      m[k] = norm2(r);
-#else
       m[k] = __builtin_amdgcn_sqrtf(norm2(r));                      // np.absolute(ifft(...)) * N
-#endif
-    }
-    if (PF && p + 1 < p1) {                             // v is dead: the next item's operands travel under the peak search and the barrier
-#pragma unroll
-      for (int k = 0; k < kR; k++) asm volatile("" :: "v"(m[k]));
-      const __amdgpu_buffer_rsrc_t cres = row_rsrc(C + (long)items[p + 1] * kLdsN);
-#pragma unroll
-      for (int jp = 0; jp < kR / 2; jp++) ld_pair(cres, lane_off, jp, v[2 * jp], v[2 * jp + 1]);
     }
     float sum_f = m[0];
 #pragma unroll
@@ -1128,8 +1104,7 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_fused4k_kernel(const float2*
     const unsigned wmax = __builtin_bit_cast(unsigned, wmaxf * inv_n);
     const float wsum = wave_add_f32(sum_f * inv_n);
     if ((t & 63) == 0) { s_peak[t >> 6] = __builtin_bit_cast(float, wmax); s_idx[t >> 6] = (int)widx; s_sum[t >> 6] = (double)wsum; }
-    if (PF) lds_barrier();   // (does not drain the vector-memory counter: the prefetch stays in flight)
-    else __syncthreads();   // also orders this item's exchange-2 reads before the next item's exchange-1 writes
+    __syncthreads();   // also orders this item's exchange-2 reads before the next item's exchange-1 writes
     if (t == 0) {
       RowRec r;
       combine_tagged(kBlock / 64, [&](int w) { return s_peak[w]; }, [&](int w) { return s_idx[w]; }, tie_scale, r.peak, r.idx);
@@ -1264,7 +1239,7 @@ int lds_fused4k_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch,
     hipLaunchKernelGGL((lds_fused4k_kernel<2, false, true>), grid, dim3(kBlock), 0, ctx->stream, x, nsamp, spectra, d_items, d_freq, tab, tw, rows,
                        nepoch, nitems, D, pch, nchunk, by_epoch, arrivals, peaks, normalised, tie_scale);
   else
-    hipLaunchKernelGGL((lds_fused4k_kernel<4, GACQ_F4K_PF != 2, false>), grid, dim3(kBlock), 0, ctx->stream, x, nsamp, spectra, d_items, d_freq, tab, tw, rows,
+    hipLaunchKernelGGL((lds_fused4k_kernel<4, true, false>), grid, dim3(kBlock), 0, ctx->stream, x, nsamp, spectra, d_items, d_freq, tab, tw, rows,
                        nepoch, nitems, D, pch, nchunk, by_epoch, (unsigned*)nullptr, (gacq_peak*)nullptr, 0, tie_scale);
   GACQ_HIP(ctx, hipGetLastError());
   return GACQ_OK;

@@ -474,10 +474,6 @@ __device__ __forceinline__ void reader_tile(const v2 (&v)[4], const v2 (&vp)[4],
 #pragma unroll
   for (int kk = 0; kk < 4; kk++) {
     const v2 s = v[kk] + vp[kk], d = v[kk] - vp[kk];      // slot 0: s = 2 v0 against a cosine column of 1/2, d = 0
-#ifdef GACQ_ABL_NOMFMA                                    // ablation builds only (tools/build_variant.sh): results are garbage
-    aRe[kk] += s.x; aIm[kk] += s.y; bRe[kk] += d.x; bIm[kk] += d.y;
-    continue;
-#endif
     aRe = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[kk], s.x, aRe, 0, 0, 0);
     aIm = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[kk], s.y, aIm, 0, 0, 0);
     bRe = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[kk], d.x, bRe, 0, 0, 0);
@@ -653,10 +649,6 @@ __global__ __launch_bounds__(PfaReader<M>::RW * 64, MODE == 2 ? 3 : 4) void pfa_
         n1 = min(n1, n1 + (unsigned)S::N);
         n2 = min(n2, n2 - (unsigned)S::N);
         if (i == 0) m2 = (gq == 0) ? 0.f : m2;                   // u = 0 has no partner: a zero at lag(0), which z(0) >= 0 already holds
-#ifdef GACQ_ABL_NOSCAN                                           // ablation builds only: results are garbage
-        ks.second += m1 + m2 + __uint_as_float(n1 ^ n2);
-        return;
-#endif
         ks.add(m1, n1);
         ks.add(m2, n2);
         if (MODE == 1) sum_f += m1 + m2;
@@ -668,10 +660,6 @@ __global__ __launch_bounds__(PfaReader<M>::RW * 64, MODE == 2 ? 3 : 4) void pfa_
     top.peak = (MODE == 0) ? __builtin_amdgcn_sqrtf(p) * inv_n : p;
     top.second = (MODE == 0) ? __builtin_amdgcn_sqrtf(fmaxf(ks.second, 0.f)) * inv_n : ks.second;
     top.idx = S::N - 1 - (int)(unsigned)(ks.key & 0xffffffffu);
-#ifdef GACQ_ABL_NOREDUCE                                         // ablation builds only: results are garbage
-    if (top.peak == 1.2345f) partial[g * G::RCH + chunk].peak = top.second;
-    continue;
-#endif
     reduce_and_store_nw<G::RW>(top, (double)sum_f, partial, g * G::RCH + chunk, tie_scale, (int)(g & 1));
   }
 }
