@@ -76,14 +76,16 @@ __device__ __forceinline__ void wave_first_max(const float (&m)[kR], unsigned ba
   // plain way in a wave-uniform branch.  tie_scale == 1 degenerates to the equality compare.
   const float thr = wmaxf * tie_scale;
   unsigned long long seen = 0, dup = 0;
-  widx = 0xffffffffu;
+  unsigned kk = 0;
 #pragma unroll
-  for (int k = kR - 1; k >= 0; k--) {                                            // descending: the last assignment is the smallest k
+  for (int k = kR - 1; k >= 0; k--) {
     const unsigned long long mk = __builtin_amdgcn_ballot_w64(m[k] >= thr);
     dup |= seen & mk;
     seen |= mk;
-    if (mk) widx = kstride * k + base + mult * (unsigned)__builtin_ctzll(mk);
+    if (mk) kk = (unsigned)k;
   }
+  // exactly one entry passed (one k with a non-empty mask, one lane in it): `seen` is that lane's bit
+  widx = kstride * kk + base + mult * (unsigned)__builtin_ctzll(seen);
   if ((dup | (seen & (seen - 1))) != 0) {
     widx = 0xffffffffu;
 #pragma unroll
