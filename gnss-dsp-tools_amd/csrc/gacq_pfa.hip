@@ -20,8 +20,8 @@
 // Layouts in HBM (all "rows" are one k1 of one forward / correlation row):
 //   spectrum rows X, C : Lg(ka,kb,kc) = ka * (Nb*9) + Nb * kc + kb                 (M contiguous, rows M apart)
 //   column rows A, Z'  : Lz(a,b,c)    = c * SEG + 11 b + a,  SEG = 11 Nb rounded up to 16 (whole 128-byte lines; A rows: SEG = 11 Nb)
-//   row k1 of either holds slot k' = 27^-1... : the DFT-31 runs on slots u with n1 = (M mod 31) u, its output k' is stored in /
-//   loaded from row (M^-1 k') mod 31 -- compile-time register permutations.
+//   rows of either: the DFT-31 runs on slots u with n1 = (M mod 31) u, and its output k' is stored in / loaded from row
+//   (M^-1 k') mod 31 (M^-1 = 23 for M = 1980, 15 for M = 990) -- compile-time register permutations.
 //
 // The DFT-31 of the inverse outer kernel also exists on the matrix pipe (v_mfma_f32_16x16x4_f32, exact fp32): the conjugate-symmetric
 // form A_u = v0 + sum cos(2 pi u k/31) s_k, B_u = sum sin(2 pi u k/31) d_k is two real 16 x 16 matrices applied to 16 columns at a time.
