@@ -196,3 +196,10 @@ def test_new_entry_points_fail_loudly_without_crashing():
     for name, num in nat.OPTIONS.items():
         assert re.search(r"#define GACQ_OPT_%s %d\b" % (name.upper(), num), hdr), name
     assert re.search(r"#define GACQ_NOPTS %d\b" % len(nat.OPTIONS), hdr)
+    # the one positive return code (a warning, not an error) and its Python mirror
+    assert re.search(r"#define GACQ_WARN_TIE_LIST_FULL %d\b" % nat.WARN_TIE_LIST_FULL, hdr) and nat.WARN_TIE_LIST_FULL > 0
+    assert nat.check_search(0) == 0
+    with pytest.warns(nat.TieListFull):
+        assert nat.check_search(nat.WARN_TIE_LIST_FULL) == nat.WARN_TIE_LIST_FULL
+    with pytest.raises(nat.GacqError):
+        nat.check_search(-1)
