@@ -35,7 +35,9 @@ extern "C" {
 #define GACQ_ERR_UNSUPPORTED (-9)
 /* Positive: the call succeeded and its results are valid, with a caveat.  gacq_search / gacq_search64 (the calls that wait for their
  * results) return this when the call's tie-safe re-evaluation list was too small (GACQ_OPT_TIE_CAP): every ambiguous pair of the call
- * kept its fp32 location.  The asynchronous device-buffer calls cannot report it: poll gacq_get_tie_stats()[2] after synchronising. */
+ * kept its fp32 location.  The asynchronous device-buffer calls cannot report it (an overflow of theirs is reported by the next
+ * gacq_search / gacq_search64 on the same context, or poll gacq_get_tie_stats()[2] after synchronising); gacq_search_batch and the
+ * gacq_group_* calls do not return it either. */
 #define GACQ_WARN_TIE_LIST_FULL 1
 
 /* ---------------------------------------------------------------------------------------------
