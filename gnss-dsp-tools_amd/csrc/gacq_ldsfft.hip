@@ -125,6 +125,9 @@ __device__ __forceinline__ v2 lds_ld1(const v2& x) { const v2 r = x; GACQ_UNPAIR
 #define GACQ_F4K_P0 -1      // at the first radix-16 pass (sweeps only)
 #endif
 #define F4K_PRIO(n) do { if ((n) >= 0) asm volatile("s_setprio %0" :: "n"(n) : "memory"); } while (0)
+#ifndef GACQ_CORR_PRE
+#define GACQ_CORR_PRE 12     // lds_correlate_kernel: 4 = pass-2 powers from an LDS table, 8 = rising priorities (both: -2.5 % at B = 10 / 80)
+#endif
 // (The same levels in lds_inner_correlate_kernel -- engine 4's writer, store-bound -- and in lds_correlate_kernel with B = 10 measured within
 // the run-to-run noise, 0-2 %: not applied there.)
 template <bool INV, int PRE = 0>
@@ -823,6 +826,16 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float
   const int p0 = (int)(j % (unsigned)nchunk) * pch;
   const int p1 = min(P, p0 + pch);
   v2 wa = ld2(tw + t), wb = ld2(tw + 16 * (t & 15));
+  // as in lds_fused4k_kernel: the pass-2 twiddle powers of the inverse transform from a 1.9 KB LDS table built once per workgroup with
+  // apply_powers' product tree (bit-identical records), and rising wave priorities through the row (GACQ_CORR_PRE: 4 | 8)
+  constexpr int kCorrPre = PRETW ? 0 : GACQ_CORR_PRE;
+  __shared__ v2 s_tw2[(kCorrPre & 4) ? 15 * 16 : 1];
+  if ((kCorrPre & 4) && t < 16) {
+    v2 pw[15];
+    make_powers(pw, v2{wb.x, -wb.y});
+#pragma unroll
+    for (int k = 0; k < 15; k++) s_tw2[16 * k + t] = pw[k];
+  }
   v2 pwa[PRETW ? 15 : 1], pwb[PRETW ? 15 : 1];
   if (PRETW) {
     wa.y = -wa.y;                      // inverse transform: conjugate twiddles
@@ -854,6 +867,7 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float
     }
     for (int b = 0; b < nb; b++) {
       if (OPAQUE) asm volatile("" : "+v"(wa.x), "+v"(wa.y), "+v"(wb.x), "+v"(wb.y));
+      if (kCorrPre & 8) F4K_PRIO(GACQ_F4K_P4);
       v2 v[kR];
       // all loads are issued before the first asm op: the machine scheduler does not move loads across inline asm, so
       // an interleaved load/cmul loop would wait for every load separately
@@ -881,7 +895,7 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float
       }
       if (!B1 && b > 0) __syncthreads();   // previous transform's exchange-2 reads are complete
       if (PRETW) fft4096<true, 3>(v, lds, wa, wb, reinterpret_cast<const v2(*)[15]>(pwa), reinterpret_cast<const v2(*)[15]>(pwb));
-      else fft4096<true>(v, lds, wa, wb);
+      else fft4096<true, kCorrPre>(v, lds, wa, wb, nullptr, nullptr, -1, s_tw2 + ((kCorrPre & 4) ? (t & 15) : 0));
       if (B1) {
         // magnitudes straight from the transform output; lane holds lags t + 256 k.  The 1/N of ifft is a power of two: it is
         // applied once to the reduced values below instead of to all 16 magnitudes.

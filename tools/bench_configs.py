@@ -26,6 +26,7 @@ CASES = {
     "cfg2_gps_l1": ("gps-l1", list(range(1, 33)), [-5000.0, 5000.0, 250.0], 1, 64),
     "cfg2_gps_l1_e1": ("gps-l1", list(range(1, 33)), [-5000.0, 5000.0, 250.0], 1, 1),
     "gps_l1_ms10": ("gps-l1", list(range(1, 33)), [-10000.0, 10000.0, 100.0], 10, 4),
+    "gps_l1_cli_ms80": ("gps-l1", list(range(1, 33)), [-7000.0, 7000.0, 200.0], 80, 1),      # acquire-gps-l1.py's own defaults (--time 80)
     "cfg3_e1b": ("galileo-e1b", list(range(1, 37)), [-4000.0, 4000.0, 125.0], 8, 1),
     "cfg4_l5i": ("gps-l5i", list(range(1, 33)), [-7000.0, 7000.0, 200.0], 1, 1),
     "cfg4_b2ad_b1": ("beidou-b2ad", list(range(1, 64)), [-7000.0, 7000.0, 200.0], None, 1),   # engine-level B=1
