@@ -1321,6 +1321,11 @@ int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const i
   // items per workgroup: keep >= ~2048 workgroups in flight (256 CUs x 4 resident x 2), at most 8 per group
   const long rows_total = (long)nepoch * nitems * D;
   int pch = (int)std::max<long>(1, std::min<long>(8, rows_total / 2048));
+  // B > 1: nothing is shared between a workgroup's items (every item walks the unit's B forward-spectrum rows again), but the
+  // workgroups of a unit that run side by side on its XCD walk them TOGETHER and share them in that L2: as few items per workgroup as
+  // still give it ~8 rows (B = 10, 800 units: 8 -> 1 item per workgroup 1.32 -> 1.23 ms; B = 80: 1 item 0.92 ms, 8 items 1.56 ms --
+  // profiles/r05_engine3_writer_wave_priority_sweep.log)
+  if (!(B == 1 && F == 1)) pch = std::min(pch, std::max(1, (8 + B - 1) / B));
   if (ctx->opt[GACQ_OPT_LDS_PCH] >= 1) pch = (int)ctx->opt[GACQ_OPT_LDS_PCH];
   pch = std::min(pch, nitems);
   const int nchunk = (nitems + pch - 1) / pch;
