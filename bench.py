@@ -1024,18 +1024,23 @@ def run(args, env):
         except Exception as exc:
             roofline["stream_ceiling"] = {"error": repr(exc)[:200]}
     # what the dominant kernel must at least move through HBM per launch (inputs once, outputs once): the yardstick for `traffic`
-    dom_job = next(j for j in jobs if j["label"] == dj["signal"])
-    rec_bytes = 16.0 * E_total * dj["P"] * dj["D_local"]
-    spectra = float(S * dj["P"] * dj["N"])
-    x_rows = float(S) * E_total * dj["F"] * dj["D_local"] * dj["B"] * dj["N"]            # forward spectra [E][F][D][B][N]
-    x_samples = float(S) * E_total * dom_job["xs"].shape[1]
-    if dk["bound"] == "hbm":
-        extra = (x_rows + spectra) if dstage == "lds_correlate" else (rec_bytes if dstage == "mag_peak" else 0.0)
-        roofline["compulsory_bytes_per_launch"] = (work_launch + extra / dk["launches_per_step"])
-    elif dj["fused_forward"]:
-        roofline["compulsory_bytes_per_launch"] = (x_samples + spectra + rec_bytes) / dk["launches_per_step"]
-    else:
-        roofline["compulsory_bytes_per_launch"] = (x_rows + spectra + rec_bytes) / dk["launches_per_step"]
+    # The PMC passes below average over EVERY launch of that kernel in a step, so the yardstick does too: jobs of the step that run the
+    # same kernel on the same FFT length (config 4: L5I and B2aD) are pooled, compulsory bytes per step over launches per step.
+    def compulsory_step(pj):
+        job_ = next(j for j in jobs if j["label"] == pj["signal"])
+        k_ = pj["stages"][dstage]
+        rec_ = 16.0 * E_total * pj["P"] * pj["D_local"]
+        spectra_ = float(S * pj["P"] * pj["N"])
+        x_rows_ = float(S) * E_total * pj["F"] * pj["D_local"] * pj["B"] * pj["N"]       # forward spectra [E][F][D][B][N]
+        x_samples_ = float(S) * E_total * job_["xs"].shape[1]
+        if k_["bound"] == "hbm":
+            return k_["work_per_step"] + ((x_rows_ + spectra_) if dstage == "lds_correlate" else (rec_ if dstage == "mag_peak" else 0.0))
+        return (x_samples_ if pj["fused_forward"] else x_rows_) + spectra_ + rec_
+    pool = [pj for pj in per_job if pj["engine"] == dj["engine"] and pj["N"] == dj["N"] and dstage in pj["stages"]
+            and pj["fused_forward"] == dj["fused_forward"]]
+    roofline["compulsory_bytes_per_launch"] = sum(compulsory_step(pj) for pj in pool) / sum(pj["stages"][dstage]["launches_per_step"] for pj in pool)
+    if len(pool) > 1:
+        roofline["compulsory_pooled_over"] = [pj["signal"] for pj in pool]
     # Measured HBM traffic of the dominant kernel: rocprofv3 --pmc wraps a command, so rank 0 of a single-GPU run re-runs this
     # very command line (3 steps, no baselines) under it, one counter group per child run, and reads the kernel's FETCH_SIZE /
     # WRITE_SIZE (KiB; FETCH_SIZE doubled: on gfx950 it counts half of a wide coalesced read -- MI355X_MICROARCH.md, HBM

@@ -107,8 +107,8 @@ int gacq_use_null_stream(gacq_ctx* ctx);
  *     runs as ONE fused kernel (fp64 transform resident in LDS, GACQ_OPT_FUSED_C128); every other shape as the five-stage pipeline
  *     on rocFFT's double-precision transforms.  Never chosen by auto. */
 int gacq_set_engine(gacq_ctx* ctx, int engine);
-/* Upper bound for the library-owned correlation workspace in bytes (default 4 GiB).  A search whose forward spectra
- * for one epoch exceed it is cut into Doppler slices that fit; the slices are merged in grid order with strict '>'
+/* Upper bound for the library-owned correlation workspace in bytes (default 32 GiB of the part's 288 GB; allocated as searches need
+ * it).  A search whose forward spectra for one epoch exceed it is cut into Doppler slices that fit; the slices are merged in grid order with strict '>'
  * (acquire-gps-l1.py:36-39), so the result is the one of a single scan. */
 int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes);
 /* Tuning switches of the launch path.  They are ctx state set through this call; nothing in the library reads the

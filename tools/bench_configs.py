@@ -27,6 +27,12 @@ CASES = {
     "cfg2_gps_l1_e1": ("gps-l1", list(range(1, 33)), [-5000.0, 5000.0, 250.0], 1, 1),
     "gps_l1_ms10": ("gps-l1", list(range(1, 33)), [-10000.0, 10000.0, 100.0], 10, 4),
     "gps_l1_cli_ms80": ("gps-l1", list(range(1, 33)), [-7000.0, 7000.0, 200.0], 80, 1),      # acquire-gps-l1.py's own defaults (--time 80)
+    # the other scripts at their own command-line defaults (--time 80: B = 80, E1B B = 80 // 4 - 1 = 19 with its 50 Hz grid)
+    "gps_l5i_cli": ("gps-l5i", list(range(1, 33)), [-7000.0, 7000.0, 200.0], 80, 1),
+    "b1i_cli": ("beidou-b1i", list(range(1, 64)), [-7000.0, 7000.0, 200.0], 80, 1),
+    "glonass_cli": ("glonass-l1", list(range(-7, 8)), [-7000.0, 7000.0, 200.0], 80, 1),
+    "e1b_cli": ("galileo-e1b", list(range(1, 51)), [-9000.0, 9000.0, 50.0], 19, 1),
+    "b2ad_cli": ("beidou-b2ad", list(range(1, 64)), [-7000.0, 7000.0, 200.0], 80, 1),
     "cfg3_e1b": ("galileo-e1b", list(range(1, 37)), [-4000.0, 4000.0, 125.0], 8, 1),
     "cfg4_l5i": ("gps-l5i", list(range(1, 33)), [-7000.0, 7000.0, 200.0], 1, 1),
     "cfg4_b2ad_b1": ("beidou-b2ad", list(range(1, 64)), [-7000.0, 7000.0, 200.0], None, 1),   # engine-level B=1
