@@ -31,7 +31,7 @@ CASES = {
     "gps_l5i_cli": ("gps-l5i", list(range(1, 33)), [-7000.0, 7000.0, 200.0], 80, 1),
     "b1i_cli": ("beidou-b1i", list(range(1, 64)), [-7000.0, 7000.0, 200.0], 80, 1),
     "glonass_cli": ("glonass-l1", list(range(-7, 8)), [-7000.0, 7000.0, 200.0], 80, 1),
-    "e1b_cli": ("galileo-e1b", list(range(1, 51)), [-9000.0, 9000.0, 50.0], 19, 1),
+    "e1b_cli": ("galileo-e1b", list(range(1, 51)), [-9000.0, 9000.0, 50.0], 80, 1),
     "b2ad_cli": ("beidou-b2ad", list(range(1, 64)), [-7000.0, 7000.0, 200.0], 80, 1),
     "cfg3_e1b": ("galileo-e1b", list(range(1, 37)), [-4000.0, 4000.0, 125.0], 8, 1),
     "cfg4_l5i": ("gps-l5i", list(range(1, 33)), [-7000.0, 7000.0, 200.0], 1, 1),
