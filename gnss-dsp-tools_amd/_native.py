@@ -148,6 +148,7 @@ SYMBOLS = {
     "gacq_reset_stage_times": (ctypes.c_int, [ctypes.c_void_p]),
     "gacq_stage_name": (ctypes.c_char_p, [ctypes.c_int]),
     "gacq_debug_nco_indices": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_double, c_int_p]),
+    "gacq_debug_fft_plans": (ctypes.c_int, [ctypes.c_void_p]),
     "gacq_debug_row": (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_double,
                                       ctypes.c_double, ctypes.c_int, c_float_p]),
 }

@@ -157,6 +157,10 @@ class Engine:
         nat.check(nat.lib.gacq_get_tie_stats(self._ctx, v), self._ctx)
         return {"ambiguous_pairs": v[0], "rows_reevaluated": v[1], "kept_fp32": v[2], "locations_changed": v[3]}
 
+    def fft_plans(self):
+        """gacq_debug_fft_plans: rocFFT plans this context has created (0 on the default engines' path, code spectra included)."""
+        return nat.check(nat.lib.gacq_debug_fft_plans(self._ctx), self._ctx)
+
     def stream_probe(self, kind, nbytes=2 << 30, reps=10):
         """gacq_stream_probe: GB/s a tuned streaming kernel reaches on this device; kind "fill", "read" or "copy" (read + write bytes)."""
         v = ctypes.c_double()

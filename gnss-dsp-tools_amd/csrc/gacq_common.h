@@ -162,7 +162,7 @@ void stage_end(gacq_ctx* ctx);
 
 // LDS-resident FFT engine (gacq_ldsfft.hip): supported lengths and the two launches.
 bool lds_supported(int N);
-int lds_prepare_spectra(gacq_ctx* ctx, const float2* natural, float2* perm, int nprn, int N);
+int lds_code_spectra(gacq_ctx* ctx, const float2* replica_rows, float2* perm, int nprn, int N);      // code spectra in the LDS engines' layout: the replicas through their own forward transform
 // X[row][k] = conj(FFT_N(x_window * nco))   rows = ((e*F + f)*D + d)*B + b
 int lds_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n, int N, const double* d_freq,
                 int FD, int B, const float2* tab, float2* X);
@@ -224,6 +224,7 @@ int pfa_inverse_reduce(gacq_ctx* ctx, const float2* Z, RowRec* rows, long g0, lo
 int pfa_debug_nco(gacq_ctx* ctx, int N, int n, const double* d_freq, int* d_idx);
 
 // tie-safe re-evaluation (gacq_tiesafe.hip)
+int tie_code_spectra64(gacq_ctx* ctx, double2* rows, int nrows, int N);      // gacq_tiesafe.hip: complex128 forward transforms of nrows rows, no rocFFT
 bool tie_supported(int N);                       // prime factors of N in {2, 3, 5, 7, 11, 13, 31}: every FFT length of the reference's scripts
 float tie_scale_of(const gacq_ctx* ctx);            // 1 - eps from GACQ_OPT_TIE_EPS_PPB
 int tie_prepare(gacq_sig* sig);                  // complex128 code spectra on first use

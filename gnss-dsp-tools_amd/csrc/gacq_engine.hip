@@ -626,6 +626,53 @@ static int validate_desc(gacq_ctx* ctx, const gacq_sigdesc* d) {
   return GACQ_OK;
 }
 
+// the replicas as complex rows, zero-extended to N when padded (acquire-beidou-b1i.py:24), on the device
+static int upload_replica_rows(gacq_sig* s, float2* dst) {
+  gacq_ctx* ctx = s->ctx;
+  std::vector<float2> host((size_t)s->nprn * s->N, make_float2(0.f, 0.f));
+  for (int p = 0; p < s->nprn; p++)
+    for (int i = 0; i < s->desc.n; i++) host[(size_t)p * s->N + i].x = s->replica[(size_t)p * s->desc.n + i];
+  GACQ_HIP(ctx, hipMemcpyAsync(dst, host.data(), sizeof(float2) * host.size(), hipMemcpyHostToDevice, ctx->stream));
+  GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));      // `host` lives on this frame
+  return GACQ_OK;
+}
+
+// Code spectra in NATURAL order by rocFFT (c = fft.fft(c), acquire-gps-l1.py:24): what the rocFFT pipeline (engine 1) multiplies with and what
+// gacq_signal_spectrum hands out.  Built on first use: creating a rocFFT plan for a new length costs 0.5-2 s per process (runtime-compiled
+// kernels), and the default engines never need one -- their code spectra come out of their own forward transforms (build_signal).
+static int natural_spectra(gacq_sig* s) {
+  if (s->spectra) return GACQ_OK;
+  gacq_ctx* ctx = s->ctx;
+  const size_t bytes = sizeof(float2) * (size_t)s->nprn * s->N;
+  float2* buf = nullptr;
+  if (hipMalloc((void**)&buf, bytes) != hipSuccess) return set_error(ctx, GACQ_ERR_HIP, "hipMalloc of %zu bytes for code spectra failed", bytes);
+  int rc = upload_replica_rows(s, buf);
+  if (rc == GACQ_OK) rc = fft_exec(ctx, s->N, s->nprn, false, buf);
+  if (rc == GACQ_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "code spectrum FFT failed");
+  if (rc != GACQ_OK) { (void)hipFree(buf); return rc; }
+  s->spectra = buf;
+  return GACQ_OK;
+}
+
+// ... and in the [k1][k2] order of the Cooley-Tukey form of engine 3 with rocFFT inner transforms (GACQ_OPT_FUSED_INNER = 0): on first use
+static int ct_spectra(gacq_sig* s) {
+  if (s->spectra_r31) return GACQ_OK;
+  gacq_ctx* ctx = s->ctx;
+  const size_t bytes = sizeof(float2) * (size_t)s->nprn * s->N;
+  float2 *buf = nullptr, *tmp = nullptr;
+  if (hipMalloc((void**)&buf, bytes) != hipSuccess || hipMalloc((void**)&tmp, bytes) != hipSuccess) {
+    if (buf) (void)hipFree(buf);
+    return set_error(ctx, GACQ_ERR_HIP, "hipMalloc for radix-31 spectra failed");
+  }
+  int rc = upload_replica_rows(s, tmp);
+  if (rc == GACQ_OK) rc = split_forward(ctx, tmp, 0, s->nprn, s->N, s->N, nullptr, 1, 1, nullptr, buf, false);
+  if (rc == GACQ_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "split-engine code spectrum failed");
+  (void)hipFree(tmp);
+  if (rc != GACQ_OK) { (void)hipFree(buf); return rc; }
+  s->spectra_r31 = buf;
+  return GACQ_OK;
+}
+
 static int build_signal(gacq_ctx* ctx, const gacq_sigdesc* desc, const std::vector<float>& replicas, int nprn, gacq_sig** out) {
   GACQ_DEVICE(ctx);
   gacq_sig* s = new gacq_sig();
@@ -635,27 +682,17 @@ static int build_signal(gacq_ctx* ctx, const gacq_sigdesc* desc, const std::vect
   s->N = desc->pad ? 2 * desc->n : desc->n;
   s->replica = replicas;
   const size_t bytes = sizeof(float2) * (size_t)nprn * s->N;
-  if (hipMalloc((void**)&s->spectra, bytes) != hipSuccess) {
-    delete s;
-    return set_error(ctx, GACQ_ERR_HIP, "hipMalloc of %zu bytes for code spectra failed", bytes);
-  }
-  // complex replica, zero-extended to N when padded (acquire-beidou-b1i.py:24)
-  std::vector<float2> host((size_t)nprn * s->N, make_float2(0.f, 0.f));
-  for (int p = 0; p < nprn; p++)
-    for (int i = 0; i < desc->n; i++) host[(size_t)p * s->N + i].x = replicas[(size_t)p * desc->n + i];
   int rc = GACQ_OK;
-  if (hipMemcpyAsync(s->spectra, host.data(), bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-    rc = set_error(ctx, GACQ_ERR_HIP, "replica upload failed");
-  if (rc == GACQ_OK) rc = fft_exec(ctx, s->N, nprn, false, s->spectra);     // c = fft.fft(c)   acquire-gps-l1.py:24
+  // Every LDS-resident / split engine keeps the code spectra in the order ITS forward transform produces: the replicas go through
+  // that transform (no rocFFT plan is created here; natural_spectra() / ct_spectra() make the rocFFT-based forms when something asks).
+  const bool own = split_supported(s->N) || lds_supported(s->N);
+  float2* tmp = nullptr;
+  if (own) {
+    if (hipMalloc((void**)&tmp, bytes) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "hipMalloc of %zu bytes for the replicas failed", bytes);
+    if (rc == GACQ_OK) rc = upload_replica_rows(s, tmp);
+  }
   if (rc == GACQ_OK && split_supported(s->N)) {
-    // the radix-31 engine keeps spectra in [k1][k2] order: transform the (still natural-order) replica with it
-    float2* tmp = nullptr;
-    if (hipMalloc((void**)&s->spectra_r31, bytes) != hipSuccess || hipMalloc((void**)&tmp, bytes) != hipSuccess)
-      rc = set_error(ctx, GACQ_ERR_HIP, "hipMalloc for radix-31 spectra failed");
-    if (rc == GACQ_OK && hipMemcpyAsync(tmp, host.data(), bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-      rc = set_error(ctx, GACQ_ERR_HIP, "replica upload failed");
-    if (rc == GACQ_OK) rc = split_forward(ctx, tmp, 0, nprn, s->N, s->N, nullptr, 1, 1, nullptr, s->spectra_r31, false);
-    if (rc == GACQ_OK && s->N / split_radix(s->N) == 4096) {
+    if (s->N / split_radix(s->N) == 4096) {
       // split engine with LDS inner transforms (N = R*4096): code spectra as R lane-pair rows per item
       if (hipMalloc((void**)&s->spectra_split, bytes) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "hipMalloc for split/LDS spectra failed");
       if (rc == GACQ_OK) rc = split_forward(ctx, tmp, 0, nprn, s->N, s->N, nullptr, 1, 1, nullptr, s->spectra_split, false, false);
@@ -666,15 +703,15 @@ static int build_signal(gacq_ctx* ctx, const gacq_sigdesc* desc, const std::vect
       if (hipMalloc((void**)&s->spectra_pfa, bytes) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "hipMalloc for prime-factor spectra failed");
       if (rc == GACQ_OK) rc = pfa_forward(ctx, tmp, 0, nprn, s->N, s->N, nullptr, 1, 1, nullptr, s->spectra_pfa, false);
     }
-    if (rc == GACQ_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "split-engine code spectrum failed");
-    if (tmp) (void)hipFree(tmp);
   }
   if (rc == GACQ_OK && lds_supported(s->N)) {
     if (hipMalloc((void**)&s->spectra_lds, bytes) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "hipMalloc for LDS-layout spectra failed");
-    else rc = lds_prepare_spectra(ctx, s->spectra, s->spectra_lds, nprn, s->N);
+    else rc = lds_code_spectra(ctx, tmp, s->spectra_lds, nprn, s->N);
   }
-  if (rc == GACQ_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "code spectrum FFT failed");
-  if (rc != GACQ_OK) { (void)hipFree(s->spectra); if (s->spectra_lds) (void)hipFree(s->spectra_lds); if (s->spectra_r31) (void)hipFree(s->spectra_r31); if (s->spectra_pfa) (void)hipFree(s->spectra_pfa); if (s->spectra_split) (void)hipFree(s->spectra_split); delete s; return rc; }
+  if (rc == GACQ_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "code spectrum transform failed");
+  if (tmp) (void)hipFree(tmp);
+  if (rc == GACQ_OK && !own) rc = natural_spectra(s);      // lengths only the rocFFT pipeline serves
+  if (rc != GACQ_OK) { if (s->spectra) (void)hipFree(s->spectra); if (s->spectra_lds) (void)hipFree(s->spectra_lds); if (s->spectra_pfa) (void)hipFree(s->spectra_pfa); if (s->spectra_split) (void)hipFree(s->spectra_split); delete s; return rc; }
   *out = s;
   return GACQ_OK;
 }
@@ -733,6 +770,7 @@ int gacq_signal_spectrum(gacq_sig* sig, int item, float* out_iq) {
   gacq_ctx* ctx = sig->ctx;
   GACQ_DEVICE(ctx);
   GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  { const int rcs = natural_spectra(sig); if (rcs != GACQ_OK) return rcs; }
   GACQ_HIP(ctx, hipMemcpy(out_iq, sig->spectra + (size_t)item * sig->N, sizeof(float2) * sig->N, hipMemcpyDeviceToHost));
   return GACQ_OK;
 }
@@ -878,6 +916,8 @@ int launch_search(gacq_sig* sig, XSrc xs, const float2* d_x, size_t nsamp, int n
   const bool use_pfa = use_split && !use_split_lds && pfa_supported(N) && ctx->opt[GACQ_OPT_FUSED_INNER] != 0;
   if (ctx->engine == 3 && !split_supported(N))
     return set_error(ctx, GACQ_ERR_UNSUPPORTED, "engine 3 (split with rocFFT inner transforms) does not support N=%d", N);
+  // the forms that multiply with rocFFT-made code spectra build them now, on first use (natural order / Cooley-Tukey [k1][k2] order)
+  if (!use_lds && !use_split_lds && !use_pfa && (rc = use_split ? ct_spectra(sig) : natural_spectra(sig)) != GACQ_OK) return rc;
 
   // tie-safe locations: the reducers tag rows whose runner-up lag is within eps of the maximum, best_doppler_kernel lists the
   // (epoch, item) pairs it cannot decide and gacq_tiesafe.hip re-evaluates their candidate rows in complex128
@@ -1356,6 +1396,11 @@ int gacq_search64(gacq_sig* sig, const double* x_iq, size_t nsamp, const int* it
   GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   rc = gacq_finalize(&sig->desc, (const gacq_peak*)ctx->pin_peaks.p, 1, nullptr, nitems, dopplers, nd, out);
   return rc != GACQ_OK ? rc : tie_list_full_warning(ctx);
+}
+
+int gacq_debug_fft_plans(gacq_ctx* ctx) {
+  if (!ctx) return set_error(nullptr, GACQ_ERR_BAD_ARG, "gacq_debug_fft_plans: bad argument");
+  return (int)ctx->plans.size();
 }
 
 int gacq_debug_nco_indices(gacq_sig* sig, int kernel, double doppler, double bias_hz, int* idx_out) {

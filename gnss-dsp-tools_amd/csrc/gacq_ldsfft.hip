@@ -190,7 +190,10 @@ __device__ __forceinline__ void ld_pair(__amdgpu_buffer_rsrc_t r, unsigned lane_
 // ---- forward: one workgroup per (e, f, d, b) row -------------------------------------------------
 // DUMP (test hook gacq_debug_nco_indices): the index expression below, on the same frequency table, is stored as int32 into X
 // (reinterpreted) and the kernel returns; x is not read.
-template <bool DUMP>
+// PLAIN (code spectra, once per signal): row r of x is transformed as it is -- no carrier wipe-off, no conjugation -- so the code
+// spectra come out of the same transform, in the same layout, as the forward spectra they are multiplied with (c = fft.fft(c),
+// acquire-gps-l1.py:24), and building a signal needs no rocFFT plan.
+template <bool DUMP, bool PLAIN = false>
 __global__ __launch_bounds__(kBlock) void lds_forward_kernel(const float2* __restrict__ x, size_t epoch_stride,
                                                               float2* __restrict__ X, const double* __restrict__ freq,
                                                               const float2* __restrict__ nco_tab,
@@ -202,12 +205,13 @@ __global__ __launch_bounds__(kBlock) void lds_forward_kernel(const float2* __res
   const unsigned r2 = row / (unsigned)B;
   const int fd = (int)(r2 % (unsigned)FD);
   const long e = r2 / (unsigned)FD;
-  const double f = freq[fd];
+  const double f = PLAIN ? 0.0 : freq[fd];
   const float2* src = x + e * epoch_stride + (size_t)b * n;
   v2 v[kR], w[kR];
 #pragma unroll
   for (int j = 0; j < kR; j++) {
     const int i = t + 256 * j;
+    if (PLAIN) { v[j] = ld2(src + i); continue; }
     // table NCO, index in fp64 exactly as numpy: floor((0 + f*i)*1024) mod 1024   (gnsstools/nco.py:6-9)
     const int k = nco_index(f, (int)i);
     if (DUMP) { reinterpret_cast<int*>(X)[row * (long)kLdsN + i] = k; continue; }
@@ -216,15 +220,18 @@ __global__ __launch_bounds__(kBlock) void lds_forward_kernel(const float2* __res
   }
   if (DUMP) return;
   const v2 twa = ld2(tw + t), twb = ld2(tw + 16 * (t & 15));
+  if (!PLAIN) {
 #pragma unroll
-  for (int j = 0; j < kR; j++) v[j] = cmul(v[j], w[j]);
+    for (int j = 0; j < kR; j++) v[j] = cmul(v[j], w[j]);
+  }
   fft4096<false>(v, lds, twa, twb);
   float2* dst = X + row * (long)kLdsN;
+  const float cs = PLAIN ? 1.f : -1.f;
 #pragma unroll
   for (int jp = 0; jp < kR / 2; jp++) {
     const v2 a = v[rev16(2 * jp)], b = v[rev16(2 * jp + 1)];
-    // store conj(FFT) in the lane-pair layout: np.conj(fft.fft(b))  acquire-gps-l1.py:32
-    *reinterpret_cast<float4*>(dst + jp * 512 + 2 * t) = make_float4(a.x, -a.y, b.x, -b.y);
+    // store conj(FFT) in the lane-pair layout: np.conj(fft.fft(b))  acquire-gps-l1.py:32   (PLAIN: the transform itself)
+    *reinterpret_cast<float4*>(dst + jp * 512 + 2 * t) = make_float4(a.x, cs * a.y, b.x, cs * b.y);
   }
 }
 
@@ -444,7 +451,7 @@ __device__ __forceinline__ void big_reduce_store(char* smem, float peak, unsigne
 }
 
 // forward: one workgroup per (e, f, d, b) row; output conj(FFT) in the physical lane-pair layout, 1 KiB per wave and store
-template <bool DUMP>
+template <bool DUMP, bool PLAIN = false>      // PLAIN: code spectra, see lds_forward_kernel
 __global__ __launch_bounds__(kBigThreads) void lds16k_forward_kernel(const float2* __restrict__ x, size_t epoch_stride,
                                                                       float2* __restrict__ X, const double* __restrict__ freq,
                                                                       const float2* __restrict__ nco_tab,
@@ -457,12 +464,13 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_forward_kernel(const float
   const unsigned r2 = row / (unsigned)B;
   const int fd = (int)(r2 % (unsigned)FD);
   const long e = r2 / (unsigned)FD;
-  const double f = freq[fd];
+  const double f = PLAIN ? 0.0 : freq[fd];
   const float2* src = x + e * epoch_stride + (size_t)b * n;
   v2 v[kR], w[kR];
 #pragma unroll
   for (int j = 0; j < kR; j++) {
     const int i = t + 1024 * j;
+    if (PLAIN) { v[j] = ld2(src + i); continue; }
     const int k = nco_index(f, (int)i);   // gnsstools/nco.py:6-9
     if (DUMP) { reinterpret_cast<int*>(X)[row * (long)kBig + i] = k; continue; }
     v[j] = ld2(src + i);
@@ -470,28 +478,18 @@ __global__ __launch_bounds__(kBigThreads) void lds16k_forward_kernel(const float
   }
   if (DUMP) return;
   const Tw16k tw = tw16k_load(twn, false);
+  if (!PLAIN) {
 #pragma unroll
-  for (int j = 0; j < kR; j++) v[j] = cmul(v[j], w[j]);
+    for (int j = 0; j < kR; j++) v[j] = cmul(v[j], w[j]);
+  }
   fft16k_fwd(v, lds, tw);
   float2* dst = X + row * (long)kBig;
+  const float cs = PLAIN ? 1.f : -1.f;
 #pragma unroll
   for (int jp = 0; jp < kR / 2; jp++) {
     const v2 a = v[2 * jp], c = v[2 * jp + 1];
-    // np.conj(fft.fft(b))  acquire-beidou-b1i.py:32
-    *reinterpret_cast<float4*>(dst + jp * 2048 + 2 * t) = make_float4(a.x, -a.y, c.x, -c.y);
-  }
-}
-
-// natural order -> physical lane-pair layout for the code spectra (once per signal)
-__global__ __launch_bounds__(kBigThreads) void lds16k_permute_kernel(const float2* __restrict__ nat, float2* __restrict__ perm) {
-  const long row = blockIdx.x;
-  const int t = threadIdx.x;
-  const float2* src = nat + row * kBig + (t >> 6) + 16 * (t & 63);
-  float2* dst = perm + row * kBig;
-#pragma unroll
-  for (int jp = 0; jp < kR / 2; jp++) {
-    const float2 a = src[1024 * (2 * jp)], b = src[1024 * (2 * jp + 1)];
-    *reinterpret_cast<float4*>(dst + jp * 2048 + 2 * t) = make_float4(a.x, a.y, b.x, b.y);
+    // np.conj(fft.fft(b))  acquire-beidou-b1i.py:32   (PLAIN: the transform itself)
+    *reinterpret_cast<float4*>(dst + jp * 2048 + 2 * t) = make_float4(a.x, cs * a.y, c.x, cs * c.y);
   }
 }
 
@@ -778,19 +776,6 @@ __global__ __launch_bounds__(kBlock, 4) void lds_inner_correlate_kernel(const fl
       }
     }
     __syncthreads();                           // exchange-2 reads done before the next item's exchange-1 writes
-  }
-}
-
-// natural -> lane-pair layout for the code spectra (once per signal)
-__global__ __launch_bounds__(kBlock) void lds_permute_kernel(const float2* __restrict__ nat, float2* __restrict__ perm) {
-  const long row = blockIdx.x;
-  const int t = threadIdx.x;
-  const float2* src = nat + row * kLdsN;
-  float2* dst = perm + row * kLdsN;
-#pragma unroll
-  for (int jp = 0; jp < kR / 2; jp++) {
-    const float2 a = src[t + 256 * (2 * jp)], b = src[t + 256 * (2 * jp + 1)];
-    *reinterpret_cast<float4*>(dst + jp * 512 + 2 * t) = make_float4(a.x, a.y, b.x, b.y);
   }
 }
 
@@ -1164,14 +1149,24 @@ extern "C" int gacq_debug_phase16(unsigned long long* out128, int reset) {
 }
 #endif
 
-int lds_prepare_spectra(gacq_ctx* ctx, const float2* natural, float2* perm, int nprn, int N) {
+// code spectra straight from the (complex, zero-extended) replica rows with the engine's own forward transform: no rocFFT plan
+int lds_code_spectra(gacq_ctx* ctx, const float2* replica_rows, float2* perm, int nprn, int N) {
   if (!lds_supported(N)) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "LDS FFT engine: N=%d not supported", N);
   if (N == kBig) {
-    hipLaunchKernelGGL(lds16k_permute_kernel, dim3((unsigned)nprn), dim3(kBigThreads), 0, ctx->stream, natural, perm);
+    const float2* twn;
+    int rcb = twiddle_cache(ctx, "W16384_lo", kBig, 1024, &twn);
+    if (rcb != GACQ_OK) return rcb;
+    GACQ_HIP(ctx, hipFuncSetAttribute((const void*)lds16k_forward_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes));
+    hipLaunchKernelGGL((lds16k_forward_kernel<false, true>), dim3((unsigned)nprn), dim3(kBigThreads), kBigLdsBytes, ctx->stream, replica_rows,
+                       (size_t)kBig, perm, (const double*)nullptr, (const float2*)nullptr, twn, kBig, 1, 1);
     GACQ_HIP(ctx, hipGetLastError());
     return GACQ_OK;
   }
-  hipLaunchKernelGGL(lds_permute_kernel, dim3((unsigned)nprn), dim3(kBlock), 0, ctx->stream, natural, perm);
+  const float2* tw;
+  int rc = twiddle_table(ctx, &tw);
+  if (rc != GACQ_OK) return rc;
+  hipLaunchKernelGGL((lds_forward_kernel<false, true>), dim3((unsigned)nprn), dim3(kBlock), 0, ctx->stream, replica_rows, (size_t)kLdsN, perm,
+                     (const double*)nullptr, (const float2*)nullptr, tw, kLdsN, 1, 1);
   GACQ_HIP(ctx, hipGetLastError());
   return GACQ_OK;
 }

@@ -494,6 +494,16 @@ __global__ __launch_bounds__(256) void tie_resolve_kernel(TieLists tl, gacq_peak
   }
 }
 
+// forward transform of one row per workgroup, in place (through a scratch row); see tie_code_spectra64
+__global__ __launch_bounds__(kTieThreads) void code_spectra64_kernel(double2* __restrict__ rows, double2* __restrict__ scratch,
+                                                                      const double2* __restrict__ WN, int N, Radices rad) {
+  double2* a = rows + (size_t)blockIdx.x * N;
+  double2* b = scratch + (size_t)blockIdx.x * N;
+  const double2* r = fft_row(a, b, WN, N, rad);
+  if (r != a)
+    for (int i = threadIdx.x; i < N; i += kTieThreads) a[i] = r[i];
+}
+
 bool factorise(int N, Radices& rad) {
   rad.count = 0;
   for (int r : {8, 4, 2, 3, 5, 7, 11, 13, 31}) {
@@ -513,6 +523,42 @@ namespace gacq {
 bool tie_supported(int N) {
   Radices rad;
   return factorise(N, rad);
+}
+
+// W_N^k, k < N, in fp64 (device-side sincospi), cached per context
+static int twiddles64(gacq_ctx* ctx, int N, const double2** out) {
+  const std::string key = "W64_" + std::to_string(N);
+  auto wt = ctx->tables.find(key);
+  if (wt == ctx->tables.end()) {
+    DevBuf b;
+    GACQ_HIP(ctx, hipMalloc(&b.p, sizeof(double2) * (size_t)N));
+    b.cap = sizeof(double2) * (size_t)N;
+    hipLaunchKernelGGL(twiddle64_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, (double2*)b.p, N);
+    GACQ_HIP(ctx, hipGetLastError());
+    wt = ctx->tables.emplace(key, b).first;
+  }
+  *out = (const double2*)wt->second.p;
+  return GACQ_OK;
+}
+
+// The complex128 code spectra c = fft.fft(c) (acquire-gps-l1.py:24) with the library's own transform: rows[p] holds the zero-extended
+// replica on entry and its spectrum, natural order, on return.  One workgroup per row, the Stockham passes of the re-evaluation kernel.
+// GACQ_ERR_UNSUPPORTED for lengths it does not factor (the caller then falls back to rocFFT's double-precision transform).  Why not
+// rocFFT for all of them: creating its plan for a new length costs 0.5-1.7 s (runtime-compiled kernels, nothing cached across processes)
+// -- per PROCESS, i.e. per run of an acquire-*.py replacement -- for a transform that is executed once.
+int tie_code_spectra64(gacq_ctx* ctx, double2* rows, int nrows, int N) {
+  Radices rad;
+  if (!factorise(N, rad)) return GACQ_ERR_UNSUPPORTED;
+  const double2* WN;
+  int rc = twiddles64(ctx, N, &WN);
+  if (rc != GACQ_OK) return rc;
+  double2* scratch = nullptr;
+  GACQ_HIP(ctx, hipMalloc((void**)&scratch, sizeof(double2) * (size_t)nrows * N));
+  hipLaunchKernelGGL(code_spectra64_kernel, dim3((unsigned)nrows), dim3(kTieThreads), 0, ctx->stream, rows, scratch, WN, N, rad);
+  const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(scratch);
+  if (e1 != hipSuccess || e2 != hipSuccess) return set_error(ctx, GACQ_ERR_HIP, "complex128 code spectra: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+  return GACQ_OK;
 }
 
 // What the re-evaluation may allocate next to the search's own workspaces: an eighth of the workspace limit the caller has set
@@ -607,17 +653,8 @@ int tie_resolve(gacq_sig* sig, const TieLists& tl, const gacq_peak* guesses, XSr
     p = it->second.p;
   }
   const double2* tab64 = (const double2*)p;
-  const std::string key = "W64_" + std::to_string(N);
-  auto wt = ctx->tables.find(key);
-  if (wt == ctx->tables.end()) {
-    DevBuf b;
-    GACQ_HIP(ctx, hipMalloc(&b.p, sizeof(double2) * (size_t)N));
-    b.cap = sizeof(double2) * (size_t)N;
-    hipLaunchKernelGGL(twiddle64_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, (double2*)b.p, N);
-    GACQ_HIP(ctx, hipGetLastError());
-    wt = ctx->tables.emplace(key, b).first;
-  }
-  const double2* WN = (const double2*)wt->second.p;
+  const double2* WN;
+  if ((rc = twiddles64(ctx, N, &WN)) != GACQ_OK) return rc;
   const int Rs = (N == 4 * gacq::f64::kN) ? 4 : ((N == 16 * gacq::f64::kN) ? 16 : 0);
   const size_t split_bytes = (size_t)tl.cap * B * ((size_t)N * (sizeof(double) + sizeof(double2)) + 64);
   // B > 1: the blocks of a listed row are evaluated side by side by B workgroups when their per-block magnitude rows

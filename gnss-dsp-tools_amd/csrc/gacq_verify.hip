@@ -258,7 +258,10 @@ int verify_spectra(gacq_sig* s) {
     for (int i = 0; i < s->desc.n; i++) host[(size_t)p * s->N + i].x = (double)s->replica[(size_t)p * s->desc.n + i];
   GACQ_HIP(ctx, hipMalloc((void**)&s->spectra64, sizeof(double2) * count));
   GACQ_HIP(ctx, hipMemcpyAsync(s->spectra64, host.data(), sizeof(double2) * count, hipMemcpyHostToDevice, ctx->stream));
-  int rc = fft_exec(ctx, s->N, s->nprn, false, s->spectra64, true);          // c = fft.fft(c)   acquire-gps-l1.py:24
+  // c = fft.fft(c)   acquire-gps-l1.py:24 -- with the library's own complex128 transform where it factors the length (every length of the
+  // reference's scripts), so that the default path never pays for a rocFFT plan; rocFFT's double-precision transform otherwise
+  int rc = tie_code_spectra64(ctx, s->spectra64, s->nprn, s->N);
+  if (rc == GACQ_ERR_UNSUPPORTED) rc = fft_exec(ctx, s->N, s->nprn, false, s->spectra64, true);
   if (rc != GACQ_OK) return rc;
   GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return GACQ_OK;

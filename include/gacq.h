@@ -361,6 +361,11 @@ int gacq_debug_row(gacq_sig* sig, const float* x_iq, size_t nsamp, int item, dou
  *         4 lds16k_fused_kernel, 5 pfa_outer_forward_kernel.  GACQ_ERR_UNSUPPORTED when that kernel does not serve the signal's N. */
 int gacq_debug_nco_indices(gacq_sig* sig, int kernel, double doppler, double bias_hz, int* idx_out);
 
+/* Number of rocFFT plans the context has created so far (a plan for a new length costs 0.5-2 s per process: runtime-compiled kernels).
+ * The default engines create none -- code spectra included -- for every FFT length of the reference's scripts; the rocFFT pipeline
+ * (engine 1), engine 5 outside N = 4096, GACQ_OPT_FUSED_INNER = 0 and gacq_signal_spectrum do, on first use.  Negative: error. */
+int gacq_debug_fft_plans(gacq_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -733,6 +733,34 @@ def test_radix31_code_spectrum_is_a_permutation_of_the_natural_one(engine):
         assert float(a[0]) == pytest.approx(float(b[0]), rel=5e-6)
 
 
+def test_default_engines_create_no_rocfft_plan_code_spectra_included():
+    """What every run of an acquire-*.py replacement pays once per process: building the signal (code spectra) and the first
+    search.  A rocFFT plan for a new length costs 0.5-2 s (runtime-compiled kernels); the default engines -- LDS-resident 4096 /
+    16384, split 65536 / 81920, prime-factor 61380 -- take their code spectra from their own forward transforms and the
+    tie-safe complex128 spectra from the library's own Stockham transform, so a fresh context gets through signal build and
+    search without one.  The rocFFT pipeline (engine 1) and gacq_signal_spectrum make theirs on first use, and agree with the
+    default engine's records."""
+    from gnss_dsp_tools_amd import acquire, signals, synth
+    for name, items, ds, ms in (("gps-l1", [1, 5, 9], [-1000.0, 1000.0, 500.0], 2), ("beidou-b1i", [1, 2], [-500.0, 500.0, 500.0], 2),
+                                ("galileo-e1b", [1, 2], [-250.0, 250.0, 250.0], 8), ("gps-l5i", [1, 2], [-200.0, 200.0, 200.0], 1),
+                                ("gps-l1cd", [1], [-100.0, 100.0, 100.0], 10)):
+        sig = signals.get(name)
+        x = synth.make_iq(sig, ms, 99, synth.default_sats(items))
+        eng = acquire.Engine(0)
+        try:
+            assert eng.tie_stats()["ambiguous_pairs"] == 0 and eng.fft_plans() == 0
+            got = eng.search_all(sig, x, items, ds, ms)                      # tie-safe locations on (default): complex128 spectra built too
+            assert eng.fft_plans() == 0, (name, eng.fft_plans())
+            spec = eng._plan(sig, items)[0].spectrum(items[0])               # natural-order spectrum: rocFFT, on first use
+            assert eng.fft_plans() >= 1 and np.isfinite(spec).all() and abs(spec).max() > 0
+            eng.set_engine(1)
+            ref = eng.search_all(sig, x, items, ds, ms)
+            for a, b in zip(got, ref):
+                assert a[1] == b[1] and a[2] == b[2] and float(a[0]) == pytest.approx(float(b[0]), rel=5e-6), (name, a, b)
+        finally:
+            eng.close()
+
+
 SPLIT_LDS_CASES = ["cfg3_e1b_subset", "cfg3_e1c_subset", "e1b_ms12", "cfg5_b1i_ms10", "b2i_ms2", "cfg5_glonass_l1", "glonass_l2",
                    "gps_l1cd", "bds_b1cp", "gps_l2cm", "bds_b1cd", "gps_l1cp"]
 
