@@ -21,10 +21,36 @@ if _tuning:
 # One HIP runtime per process: when torch is (or will be) in the process its bundled
 # libamdhip64/librocfft (same SONAMEs as /opt/rocm's) must be the ones that get bound, so it
 # is imported before libgacq.so is dlopen'ed.  Device buffers are torch tensors anyway.
-try:
-    import torch  # noqa: F401
-except Exception:  # pragma: no cover - torch is part of the image; C-only users do not need it
-    torch = None
+# A program that never touches a device tensor -- the command-line shim, a stub around search() on numpy samples -- can skip that
+# (importing torch is ~0.8 s, most of such a run): it defines GACQ_NO_TORCH = True in its __main__ module before importing the package.
+# libgacq.so then binds /opt/rocm's runtime through its rpath, and the entry points that take torch tensors refuse to run (require_torch).
+NO_TORCH = bool(getattr(sys.modules.get("__main__"), "GACQ_NO_TORCH", False)) and "torch" not in sys.modules
+torch = None
+if not NO_TORCH:
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is part of the image; C-only users do not need it
+        torch = None
+
+
+if NO_TORCH:
+    # ... and nothing else in the process may bring torch (a second HIP runtime) in afterwards
+    import importlib.abc
+
+    class _NoTorchLater(importlib.abc.MetaPathFinder):
+        def find_spec(self, name, path, target=None):
+            if name == "torch" or name.startswith("torch."):
+                raise ImportError("this process loaded libgacq.so without torch (GACQ_NO_TORCH in __main__): torch and the device-tensor "
+                                  "entry points of the package are not available in it")
+            return None
+
+    sys.meta_path.insert(0, _NoTorchLater())
+
+
+def require_torch():
+    """For the device-tensor entry points (raises in a GACQ_NO_TORCH process, see above)."""
+    import torch as _t
+    return _t
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -149,6 +175,8 @@ SYMBOLS = {
     "gacq_stage_name": (ctypes.c_char_p, [ctypes.c_int]),
     "gacq_debug_nco_indices": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_double, c_int_p]),
     "gacq_debug_fft_plans": (ctypes.c_int, [ctypes.c_void_p]),
+    "gacq_acquire_int8": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_double, ctypes.c_double, c_double_p, ctypes.c_int,
+                                         ctypes.c_size_t, c_int_p, ctypes.c_int, c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_void_p]),
     "gacq_debug_row": (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_double,
                                       ctypes.c_double, ctypes.c_int, c_float_p]),
 }

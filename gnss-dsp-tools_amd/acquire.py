@@ -134,7 +134,7 @@ class Engine:
 
     def use_torch_stream(self, device=None):
         """Order the engine's launches with torch work (incl. RCCL collectives) on torch's current stream."""
-        import torch
+        torch = nat.require_torch()
         self.set_stream(torch.cuda.current_stream(device).cuda_stream)
 
     def set_option(self, option, value):
@@ -336,7 +336,7 @@ class Engine:
     def search_family_batch_dev(self, names, x_dev, items, dopplers, blocks, out=None):
         """Device-resident, batched form of search_family: x_dev [nepoch, nsamp] complex64 on the GPU -> peaks tensor
         [nepoch, sum(len(items_k)), 2] (gacq_peak records, signals concatenated in order).  Asynchronous."""
-        import torch
+        torch = nat.require_torch()
         base, fam, lists = self._family(names, items)
         if fam is None:
             return torch.empty((x_dev.shape[0], 0, 2), dtype=torch.float64, device=x_dev.device)
@@ -361,7 +361,7 @@ class Engine:
         """x_dev: torch complex64 (or complex128: searched unrounded where it matters, gacq_search_batch_dev64) CUDA tensor
         [nepoch, nsamp]; returns a torch tensor [nepoch, nitems, 2] of float64 whose 16-byte rows are gacq_peak records (view with
         PEAK_DTYPE on the host).  Asynchronous on the engine's stream."""
-        import torch
+        torch = nat.require_torch()
         sig = _signals.get(name) if isinstance(name, str) else name
         if not (x_dev.is_cuda and x_dev.dtype in (torch.complex64, torch.complex128) and x_dev.dim() == 2 and x_dev.is_contiguous()):
             raise ValueError("x_dev must be a contiguous 2-D complex64 (or complex128) CUDA tensor")
@@ -415,11 +415,31 @@ class Engine:
     def finalize(self, name, items, peaks, dopplers, shard_d0=None):
         return finalize(name, items, peaks, dopplers, shard_d0)
 
+    # -- the main program of an acquire script in one call, no torch (acquire-gps-l1.py:78-108) --------------
+    def acquire_int8(self, name, iq_int8, fs, coffset, ms_pad, items, dopplers, blocks):
+        """gacq_acquire_int8: iq_int8 = numpy int8 [n, 2] / flat interleaved block at fs (host memory); front-end to ms_pad ms at the
+        signal's rate and search of `items` over `dopplers`, all on the device -> the reference's (metric, code, doppler) tuples."""
+        sig = _signals.get(name) if isinstance(name, str) else name
+        if len(items) == 0:
+            return []
+        iq = np.ascontiguousarray(iq_int8, dtype=np.int8).reshape(-1)
+        n_in = iq.size // 2
+        n_out = int(ms_pad) * int(round(sig.fs * 0.001))
+        taps = firwin_hann(161, sig.fir_cutoff / (fs / 2))
+        s, idx, bias = self._plan(sig, items)
+        dopplers = np.ascontiguousarray(dopplers, dtype=np.float64)
+        res = (nat.Result * len(idx))()
+        nat.check_search(nat.lib.gacq_acquire_int8(
+            s._h, iq.ctypes.data_as(ctypes.c_void_p), n_in, float(fs), float(coffset), taps.ctypes.data_as(nat.c_double_p), len(taps), n_out,
+            idx.ctypes.data_as(nat.c_int_p), len(idx), dopplers.ctypes.data_as(nat.c_double_p) if len(dopplers) else None, len(dopplers),
+            bias.ctypes.data_as(nat.c_double_p) if bias is not None else None, max(int(blocks), 0), res), self._ctx)
+        return _as_tuples(res)
+
     # -- front-end on the GPU (acquire-gps-l1.py:87-96) ---------------------------------------------------
     def frontend_dev(self, name, iq_int8, fs, coffset, ms_pad):
         """iq_int8: numpy int8 array [n, 2] (or flat interleaved) or a torch int8 CUDA tensor; returns a torch complex64
         CUDA tensor with ms_pad ms of samples at the signal's internal rate, ready for search_batch_dev."""
-        import torch
+        torch = nat.require_torch()
         sig = _signals.get(name) if isinstance(name, str) else name
         if not torch.is_tensor(iq_int8):
             iq_int8 = torch.from_numpy(np.array(iq_int8, dtype=np.int8, copy=True)).to("cuda:%d" % self.device)
@@ -439,7 +459,7 @@ class Engine:
         """nco.mix(x, -coffset/fs, 0) on the GPU (gacq_mix_int8_dev; gnsstools/nco.py:30-41): int8 I/Q (numpy [n, 2] / flat, or a torch
         int8 CUDA tensor) -> torch complex64 CUDA tensor at the same rate, the input of the device-resident long-code search and
         correlators (longcode.search_*, tracking.correlate_batch accept it as x)."""
-        import torch
+        torch = nat.require_torch()
         if not torch.is_tensor(iq_int8):
             iq_int8 = torch.from_numpy(np.array(iq_int8, dtype=np.int8, copy=True)).to("cuda:%d" % self.device)
         # the kernel runs on the context's stream: make that torch's current stream, so that the caching allocator cannot hand the
@@ -455,7 +475,7 @@ class Engine:
     def merge_peaks_dev(self, gathered, shard_d0, out=None):
         """gathered: torch float64 CUDA tensor [nshard, ..., 2] of gacq_peak records (all_gather output);
         returns the merged [..., 2] tensor with global Doppler indices (device-side, asynchronous)."""
-        import torch
+        torch = nat.require_torch()
         nshard = gathered.shape[0]
         n = int(gathered[0].numel() // 2)
         if out is None:
@@ -470,7 +490,7 @@ class Engine:
         """gacq_merge_peaks_tiesafe_dev: merge_peaks_dev for searches that run with tie-safe locations (the default) -- shard
         winners within eps of the best one are re-evaluated in complex128 on this GPU before the scan decides.  name / x_dev /
         items / blocks are those of the sharded search, `dopplers` its FULL grid."""
-        import torch
+        torch = nat.require_torch()
         sig = _signals.get(name) if isinstance(name, str) else name
         if _signal is not None:
             s, idx, bias = _signal, np.array([_signal._index[i] for i in items], dtype=np.int32), None

@@ -8,7 +8,12 @@ runs on the GPU (acquire.Engine.search_all replaces the multiprocessing.Pool ove
 import argparse
 import sys
 
-from . import acquire, codes, frontend, signals
+LONGCODE = {"gps-l2cl": 40, "glonass-l1-p": 80, "glonass-l2-p": 80}        # default --time (acquire-gps-l2cl.py:57)
+# Run as a program, the FFT searches need no device tensor (gacq_acquire_int8): the package is then loaded without torch, whose import
+# alone (~0.8 s) would be most of the run (_native.py).  The long-code commands hand device tensors around and keep it.
+GACQ_NO_TORCH = __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in LONGCODE)
+
+from . import acquire, codes, frontend, signals  # noqa: E402
 
 
 def build_parser(sig):
@@ -58,27 +63,19 @@ def run(name, argv, out=sys.stdout):
     if len(raw) != 2 * n:
         raise SystemExit("input file too short: need %d complex int8 samples" % n)     # gnsstools/io.py:5-6 returns None here
     import numpy as np
-    import torch
     eng = acquire.Engine(args.device)
     try:
-        # file bytes -> GPU once; front-end and search stay device-resident
-        eng.use_torch_stream()
+        # file bytes -> GPU once; front-end and search stay device-resident (gacq_acquire_int8: nothing on this path imports torch,
+        # which alone would be most of the run's wall time)
         iq = np.frombuffer(raw, dtype=np.int8)
-        x_dev = eng.frontend_dev(sig, iq, args.sample_rate, args.carrier_offset, ms_pad)
         dop = acquire.doppler_grid(doppler_search)
-        blocks = max(sig.blocks(ms), 0)
-        peaks = eng.search_batch_dev(sig, x_dev.view(1, -1), items, dop, blocks)
-        torch.cuda.synchronize()
-        results = acquire.finalize(sig, items, peaks.cpu().numpy().view(acquire.PEAK_DTYPE).reshape(len(items)), dop)
+        results = eng.acquire_int8(sig, iq, args.sample_rate, args.carrier_offset, ms_pad, items, dop, max(sig.blocks(ms), 0))
     finally:
         eng.close()
     lines = [acquire.format_result(sig, it, r) for it, r in zip(items, results)]
     for line in lines:
         print(line, file=out)
     return lines
-
-
-LONGCODE = {"gps-l2cl": 40, "glonass-l1-p": 80, "glonass-l2-p": 80}        # default --time (acquire-gps-l2cl.py:57)
 
 
 def run_longcode(name, argv, out=sys.stdout):

@@ -80,6 +80,7 @@ struct gacq_ctx {
   int tie_cap = 0;                     // list capacity the `tie` buffer was laid out for
   long opt[GACQ_NOPTS] = {1, 1, -1, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 1, 8000, 0, 1, 0};   // gacq_set_option values (defaults documented in include/gacq.h)
   gacq::DevBuf pin_x, pin_peaks;       // pinned host staging for the host-buffer entry point (gacq_search)
+  gacq::DevBuf acq_in, acq_x;          // gacq_acquire_int8: the raw int8 block and its front-end output on the device
   gacq::DevBuf pin_tie;                // pinned host word the listing kernels set when the re-evaluation list is full (GACQ_WARN_TIE_LIST_FULL)
   gacq::DevBuf bar_x;                  // fine-grained device memory the host writes directly through the PCIe BAR (small gacq_search inputs)
   gacq::DevBuf bar_s;                  // the same for the correlator specs of gacq_correlate_batch_dev

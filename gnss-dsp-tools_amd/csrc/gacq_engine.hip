@@ -524,7 +524,7 @@ void gacq_destroy(gacq_ctx* ctx) {
     if (kv.second.work) (void)hipFree(kv.second.work);
   }
   for (auto& ev : ctx->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-  DevBuf* bufs[] = {&ctx->tab, &ctx->xstage, &ctx->x32, &ctx->X, &ctx->Y, &ctx->rows, &ctx->freq, &ctx->fset, &ctx->items, &ctx->out_peaks, &ctx->d0, &ctx->partial, &ctx->fe_a, &ctx->fe_b, &ctx->fe_taps, &ctx->chunk_peaks, &ctx->arrivals, &ctx->tie, &ctx->tie_scratch, &ctx->tie_q, &ctx->tie_split, &ctx->tie_done2};
+  DevBuf* bufs[] = {&ctx->tab, &ctx->xstage, &ctx->x32, &ctx->X, &ctx->Y, &ctx->rows, &ctx->freq, &ctx->fset, &ctx->items, &ctx->out_peaks, &ctx->d0, &ctx->partial, &ctx->fe_a, &ctx->fe_b, &ctx->fe_taps, &ctx->chunk_peaks, &ctx->arrivals, &ctx->tie, &ctx->tie_scratch, &ctx->tie_q, &ctx->tie_split, &ctx->tie_done2, &ctx->acq_in, &ctx->acq_x};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   if (ctx->pin_x.p) (void)hipHostFree(ctx->pin_x.p);
   if (ctx->pin_peaks.p) (void)hipHostFree(ctx->pin_peaks.p);
@@ -1392,6 +1392,38 @@ int gacq_search64(gacq_sig* sig, const double* x_iq, size_t nsamp, const int* it
   if ((rc = ensure(ctx, ctx->xstage, sizeof(double2) * need)) != GACQ_OK) return rc;
   GACQ_HIP(ctx, hipMemcpyAsync(ctx->xstage.p, x_iq, sizeof(double2) * need, hipMemcpyHostToDevice, ctx->stream));
   rc = gacq_search_batch_dev64(sig, ctx->xstage.p, need, 1, items, nitems, dopplers, nd, item_bias_hz, blocks, ctx->pin_peaks.p);
+  if (rc != GACQ_OK) return rc;
+  GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  rc = gacq_finalize(&sig->desc, (const gacq_peak*)ctx->pin_peaks.p, 1, nullptr, nitems, dopplers, nd, out);
+  return rc != GACQ_OK ? rc : tie_list_full_warning(ctx);
+}
+
+// The whole main program of an acquire script in one call, from host memory, without a device-memory framework on the caller's side:
+// the int8 block goes up, the front-end (gacq_frontend_dev) and the search (gacq_search_batch_dev) run on it where it lies, the results
+// come back.  Synchronous.
+int gacq_acquire_int8(gacq_sig* sig, const int8_t* iq_int8, size_t nsamp_in, double fs_in, double carrier_offset_hz, const double* taps,
+                      int ntaps, size_t nsamp_out, const int* items, int nitems, const double* dopplers, int nd, const double* item_bias_hz,
+                      int blocks, gacq_result* out) {
+  if (!sig || !iq_int8 || !taps || nsamp_in == 0 || nsamp_out == 0 || !(fs_in > 0.0) || !std::isfinite(carrier_offset_hz))
+    return set_error(sig ? sig->ctx : nullptr, GACQ_ERR_BAD_ARG, "gacq_acquire_int8: bad argument");
+  gacq_ctx* ctx = sig->ctx;
+  // argument checks of the search against the front-end's output length (short input -> GACQ_ERR_SHORT_INPUT before anything is launched)
+  static const float dummy = 0.f;
+  int rc = check_search_args(sig, &dummy, nsamp_out, 1, items, nitems, dopplers, nd, blocks, out);
+  if (rc != GACQ_OK) return rc;
+  GACQ_DEVICE(ctx);
+  if ((rc = ensure(ctx, ctx->acq_in, 2 * nsamp_in)) != GACQ_OK) return rc;
+  if ((rc = ensure(ctx, ctx->acq_x, sizeof(float2) * nsamp_out)) != GACQ_OK) return rc;
+  if ((rc = ensure_pinned(ctx, ctx->pin_peaks, sizeof(gacq_peak) * std::max(1, nitems))) != GACQ_OK) return rc;
+  GACQ_HIP(ctx, hipMemcpyAsync(ctx->acq_in.p, iq_int8, 2 * nsamp_in, hipMemcpyHostToDevice, ctx->stream));
+  rc = gacq_frontend_dev(ctx, ctx->acq_in.p, nsamp_in, fs_in, carrier_offset_hz, taps, ntaps, sig->desc.fs, nsamp_out, ctx->acq_x.p);
+  if (rc != GACQ_OK) return rc;
+  if (nd == 0 || blocks == 0 || nitems == 0) {
+    GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int p = 0; p < nitems; p++) { out[p].metric = 0.0; out[p].code_chips = 0.0; out[p].doppler_hz = 0.0; out[p].idx = -1; out[p].d_index = -1; }
+    return GACQ_OK;
+  }
+  rc = gacq_search_batch_dev(sig, ctx->acq_x.p, nsamp_out, 1, items, nitems, dopplers, nd, item_bias_hz, blocks, ctx->pin_peaks.p);
   if (rc != GACQ_OK) return rc;
   GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   rc = gacq_finalize(&sig->desc, (const gacq_peak*)ctx->pin_peaks.p, 1, nullptr, nitems, dopplers, nd, out);

@@ -294,6 +294,15 @@ int gacq_firwin_hann(int ntaps, double cutoff_norm, double* taps);
 int gacq_frontend_dev(gacq_ctx* ctx, const void* d_iq_int8, size_t nsamp_in, double fs_in, double carrier_offset_hz,
                       const double* taps, int ntaps, double fs_out, size_t nsamp_out, void* d_out);
 
+/* The main program of an acquire script in one call (acquire-gps-l1.py:78-108: read block, mix / filter / resample, search every item):
+ * iq_int8 = nsamp_in interleaved signed 8-bit I/Q samples at fs_in in HOST memory; the block is uploaded, gacq_frontend_dev produces
+ * nsamp_out samples at the signal's internal rate on the device and gacq_search_batch_dev searches them there; out[nitems] as
+ * gacq_search.  For callers without a device-memory framework (the command-line shim runs on it: no torch import on its path).
+ * Synchronous; GACQ_WARN_TIE_LIST_FULL as gacq_search. */
+int gacq_acquire_int8(gacq_sig* sig, const int8_t* iq_int8, size_t nsamp_in, double fs_in, double carrier_offset_hz, const double* taps,
+                      int ntaps, size_t nsamp_out, const int* items, int nitems, const double* dopplers, int nd,
+                      const double* item_bias_hz, int blocks, gacq_result* out);
+
 /* ---------------------------------------------------------------------------------------------
  * Time-domain long-code searches (SURVEY.md section 8f "next #3"): acquire-gps-l2cl.py:15-30,
  * acquire-glonass-l1-p.py / -l2-p.py:15-33.  For candidate k:

@@ -64,6 +64,25 @@ def test_cli_lines_match_reference_stdout(gold):
     assert sum(m == r for m, r in zip(lines, gold["stdout_lines"])) >= len(lines) - 1
 
 
+def test_cli_as_a_program_loads_without_torch():
+    """Run as a program (one process per recording, like the reference's scripts) the FFT-search commands need no device tensor
+    (gacq_acquire_int8), so the package is loaded without torch -- its import alone would be most of the run's wall time -- and
+    refuses to let it in later; the long-code commands keep it."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    probe = ("import sys, runpy\nsys.argv = ['cli'] + %r\n"
+             "try:\n    runpy.run_module('gnss_dsp_tools_amd.cli', run_name='__main__', alter_sys=True)\nexcept SystemExit:\n    pass\n"
+             "from gnss_dsp_tools_amd import _native as nat\nprint('NO_TORCH', nat.NO_TORCH, 'torch' in sys.modules)\n"
+             "try:\n    import torch\n    print('torch came in')\nexcept ImportError as e:\n    print('refused:', str(e)[:40])\n")
+    out = subprocess.run([sys.executable, "-c", probe % (["--help"],)], capture_output=True, text=True, cwd=root, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "NO_TORCH True False" in out.stdout and "refused: this process loaded libgacq.so without" in out.stdout, out.stdout[-500:]
+    out = subprocess.run([sys.executable, "-c", probe % (["gps-l2cl", "--help"],)], capture_output=True, text=True, cwd=root, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "NO_TORCH False True" in out.stdout and "torch came in" in out.stdout, out.stdout[-500:]
+
+
 def test_native_firwin_matches_scipy():
     import scipy.signal
     from gnss_dsp_tools_amd import acquire
