@@ -191,6 +191,8 @@ def test_new_entry_points_fail_loudly_without_crashing():
     assert lib.gacq_set_option(None, 0, 1) == -1 and lib.gacq_get_option(None, 0, None) == -1
     assert lib.gacq_debug_nco_indices(None, 1, 0.0, 0.0, None) == -1
     assert lib.gacq_longcode_search_int8(None, None, 0, 1.0, 0.0, b"gps.l2cl", 1, 0.0, None, 1, 1, 1, None) == -1
+    assert lib.gacq_debug_fft_plans(None) == -1
+    assert lib.gacq_acquire_int8(None, None, 0, 1.0, 0.0, None, 0, 0, None, 0, None, 0, None, 0, None) == -1
     assert set(nat.OPTIONS.values()) == set(range(len(nat.OPTIONS)))          # GACQ_OPT_* numbering is dense
     hdr = open(os.path.join(ROOT, "include", "gacq.h")).read()
     for name, num in nat.OPTIONS.items():
