@@ -122,6 +122,7 @@ struct gacq_sig {
   float2* spectra_pfa = nullptr;   // same in the prime-factor engine's order (only when pfa_supported(N))
   float2* spectra_split = nullptr; // split engine with LDS inner transforms: R lane-pair rows per item (N = R*4096)
   float2* spectra_lds = nullptr;   // same in the LDS engine's lane-pair layout (only when lds_supported(N))
+  float2* spectra_lds32 = nullptr; // N = 16384 only: the order of the radix-32 form of the transform (GACQ_OPT_LDS_VARIANT = 32, gacq_lds16k.hip)
   double2* spectra64 = nullptr;    // complex128 code spectra of the verification engine (engine 5), built on first use
   std::vector<float> replica;      // host copy of the +-1 replicas [nprn][n] (source of spectra64)
 };
@@ -163,7 +164,7 @@ void stage_end(gacq_ctx* ctx);
 
 // LDS-resident FFT engine (gacq_ldsfft.hip): supported lengths and the two launches.
 bool lds_supported(int N);
-int lds_code_spectra(gacq_ctx* ctx, const float2* replica_rows, float2* perm, int nprn, int N);      // code spectra in the LDS engines' layout: the replicas through their own forward transform
+int lds_code_spectra(gacq_ctx* ctx, const float2* replica_rows, float2* perm, int nprn, int N, bool radix32 = false);      // code spectra in the LDS engines' layout: the replicas through their own forward transform
 // X[row][k] = conj(FFT_N(x_window * nco))   rows = ((e*F + f)*D + d)*B + b
 int lds_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n, int N, const double* d_freq,
                 int FD, int B, const float2* tab, float2* X);
@@ -183,6 +184,16 @@ int lds_fused4k_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch,
 bool lds_search1_supported(const gacq_ctx* ctx, int N, int B, int F, long units, int nitems);
 int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const int* d_items, const int* d_fset,
                   int nepoch, int nitems, int F, int D, int B, int N, RowRec* rows, float tie_scale, float* q_out = nullptr);
+
+// N = 16384 as 32 x 32 x 16 in one 512-thread workgroup (gacq_lds16k.hip): the launches behind the lds_* entry points above
+int r32_code_spectra(gacq_ctx* ctx, const float2* replica_rows, float2* perm, int nprn);
+int r32_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n, const double* d_freq, int FD, int B, const float2* tab,
+                float2* X);
+int r32_fused_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n, const float2* spectra, const int* d_items,
+                     const int* d_fset, const double* d_freq, const float2* tab, int nitems, int D, int B, RowRec* rows, float tie_scale);
+int r32_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const int* d_items, const int* d_fset, int nepoch, int nitems,
+                  int F, int D, int B, RowRec* rows, float tie_scale, float* q_out);
+int r32_debug_nco(gacq_ctx* ctx, int n, const double* d_freq, bool fused, int* d_idx);
 
 // test hook (gacq_debug_nco_indices): the forward kernel's own NCO index expression for one row, d_idx[N]; fused: the
 // one-kernel N = 16384 search

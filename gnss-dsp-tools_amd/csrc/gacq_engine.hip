@@ -707,11 +707,15 @@ static int build_signal(gacq_ctx* ctx, const gacq_sigdesc* desc, const std::vect
   if (rc == GACQ_OK && lds_supported(s->N)) {
     if (hipMalloc((void**)&s->spectra_lds, bytes) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "hipMalloc for LDS-layout spectra failed");
     else rc = lds_code_spectra(ctx, tmp, s->spectra_lds, nprn, s->N);
+    if (rc == GACQ_OK && s->N == 16384) {      // the radix-32 form of the N = 16384 transform has its own spectrum order (GACQ_OPT_LDS_VARIANT = 32)
+      if (hipMalloc((void**)&s->spectra_lds32, bytes) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "hipMalloc for LDS-layout spectra failed");
+      else rc = lds_code_spectra(ctx, tmp, s->spectra_lds32, nprn, s->N, true);
+    }
   }
   if (rc == GACQ_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "code spectrum transform failed");
   if (tmp) (void)hipFree(tmp);
   if (rc == GACQ_OK && !own) rc = natural_spectra(s);      // lengths only the rocFFT pipeline serves
-  if (rc != GACQ_OK) { if (s->spectra) (void)hipFree(s->spectra); if (s->spectra_lds) (void)hipFree(s->spectra_lds); if (s->spectra_pfa) (void)hipFree(s->spectra_pfa); if (s->spectra_split) (void)hipFree(s->spectra_split); delete s; return rc; }
+  if (rc != GACQ_OK) { if (s->spectra) (void)hipFree(s->spectra); if (s->spectra_lds) (void)hipFree(s->spectra_lds); if (s->spectra_lds32) (void)hipFree(s->spectra_lds32); if (s->spectra_pfa) (void)hipFree(s->spectra_pfa); if (s->spectra_split) (void)hipFree(s->spectra_split); delete s; return rc; }
   *out = s;
   return GACQ_OK;
 }
@@ -756,6 +760,7 @@ void gacq_signal_destroy(gacq_sig* sig) {
   (void)hipStreamSynchronize(sig->ctx->stream);
   if (sig->spectra) (void)hipFree(sig->spectra);
   if (sig->spectra_lds) (void)hipFree(sig->spectra_lds);
+  if (sig->spectra_lds32) (void)hipFree(sig->spectra_lds32);
   if (sig->spectra_r31) (void)hipFree(sig->spectra_r31);
   if (sig->spectra_pfa) (void)hipFree(sig->spectra_pfa);
   if (sig->spectra_split) (void)hipFree(sig->spectra_split);
@@ -946,6 +951,7 @@ int launch_search(gacq_sig* sig, XSrc xs, const float2* d_x, size_t nsamp, int n
   if ((rc = ensure(ctx, ctx->rows, sizeof(RowRec) * (size_t)Ec * P * D)) != GACQ_OK) return rc;
 
   const int chunksN = (N + kBlock * 8 - 1) / (kBlock * 8);
+  const float2* lds_spectra = (N == 16384 && ctx->opt[GACQ_OPT_LDS_VARIANT] == 32) ? sig->spectra_lds32 : sig->spectra_lds;
   for (int e0 = 0; e0 < nepoch; e0 += Ec) {
     const int ne = std::min(Ec, nepoch - e0);
     const float2* xe = d_x + (size_t)e0 * nsamp;
@@ -954,7 +960,7 @@ int launch_search(gacq_sig* sig, XSrc xs, const float2* d_x, size_t nsamp, int n
     const long rows_x = (long)ne * F * D * B;
     if (fused16k) {
       stage_begin(ctx, 6);
-      rc = lds_fused_search(ctx, xe, nsamp, ne, n, N, sig->spectra_lds, (const int*)ctx->items.p, (const int*)ctx->fset.p,
+      rc = lds_fused_search(ctx, xe, nsamp, ne, n, N, lds_spectra, (const int*)ctx->items.p, (const int*)ctx->fset.p,
                             (const double*)ctx->freq.p, (const float2*)ctx->tab.p, P, D, B, rows, tscale);
       stage_end(ctx);
       if (rc != GACQ_OK) return rc;
@@ -971,7 +977,7 @@ int launch_search(gacq_sig* sig, XSrc xs, const float2* d_x, size_t nsamp, int n
       stage_end(ctx);
       if (rc != GACQ_OK) return rc;
       stage_begin(ctx, 6);
-      rc = lds_correlate(ctx, X, sig->spectra_lds, (const int*)ctx->items.p, (const int*)ctx->fset.p, ne, P, F, D, B, N, rows, tscale, d_qrow);
+      rc = lds_correlate(ctx, X, lds_spectra, (const int*)ctx->items.p, (const int*)ctx->fset.p, ne, P, F, D, B, N, rows, tscale, d_qrow);
       stage_end(ctx);
       if (rc != GACQ_OK) return rc;
     } else {

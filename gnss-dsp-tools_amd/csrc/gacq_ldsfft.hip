@@ -16,6 +16,7 @@
 // writes with row pitch 257 (odd) so that the 16 lanes of a ds_write_b64 group hit 16 distinct bank pairs.
 #include "gacq_common.h"
 #include "gacq_cplx.h"
+#include "gacq_ldsutil.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -55,53 +56,6 @@ __device__ __forceinline__ void apply_table(v2 (&v)[kR], const v2 (&pw)[15]) {
 #pragma unroll
   for (int k = 1; k < kR; k++) v[rev16(k)] = cmul(v[rev16(k)], pw[k - 1]);
 }
-
-// (max, first argmax) of the 16 x 64 magnitudes a wave holds; lane l of the wave holds lag base + mult * l + kstride * k in
-// m[k], with kstride > 63 * mult so that lags grow with k first.  The maximum is found first -- per lane with max3, over the
-// wave on DPP -- and only then located: for every k one v_cmp against the wave-uniform maximum gives a lane mask in SGPRs; the
-// smallest k with a non-empty mask and its lowest lane are the smallest lag attaining the maximum (np.argmax returns the first
-// maximum, acquire-gps-l1.py:34).  24 VALU instructions instead of the 47 of a running (value, index) pair per lane; the
-// bookkeeping runs on the scalar unit.  Magnitudes are >= 0, so their bit patterns order like the values.
-__device__ __forceinline__ void wave_first_max(const float (&m)[kR], unsigned base, unsigned mult, unsigned kstride, float tie_scale,
-                                               float& wmaxf, unsigned& widx) {
-  float lmax = __builtin_fmaxf(__builtin_fmaxf(m[0], m[1]), m[2]);
-#pragma unroll
-  for (int k = 3; k + 1 < kR; k += 2) lmax = __builtin_fmaxf(__builtin_fmaxf(lmax, m[k]), m[k + 1]);
-  lmax = __builtin_fmaxf(lmax, m[kR - 1]);
-  wmaxf = __builtin_bit_cast(float, wave_max_u32(__builtin_bit_cast(unsigned, lmax)));
-  // Tie-safe locations: the compare runs against thr = (1 - eps) * maximum instead of the maximum itself.  When exactly one entry
-  // passes -- all but about one row in 10^4 -- it is the maximum and its mask is its location; the masks of all k are folded on the
-  // scalar unit (seen: lanes with an entry, dup: lanes with two) to tell.  Otherwise the row is tagged ambiguous (kTieBit; the
-  // Doppler scan decides whether it matters and has it re-evaluated in complex128) and the exact first maximum is located the
-  // plain way in a wave-uniform branch.  tie_scale == 1 degenerates to the equality compare.
-  const float thr = wmaxf * tie_scale;
-  unsigned long long seen = 0, dup = 0;
-  unsigned kk = 0;
-#pragma unroll
-  for (int k = kR - 1; k >= 0; k--) {
-    const unsigned long long mk = __builtin_amdgcn_ballot_w64(m[k] >= thr);
-    dup |= seen & mk;
-    seen |= mk;
-    if (mk) kk = (unsigned)k;
-  }
-  // exactly one entry passed (one k with a non-empty mask, one lane in it): `seen` is that lane's bit
-  widx = kstride * kk + base + mult * (unsigned)__builtin_ctzll(seen);
-  if ((dup | (seen & (seen - 1))) != 0) {
-    widx = 0xffffffffu;
-#pragma unroll
-    for (int k = kR - 1; k >= 0; k--) {
-      const unsigned long long mk = __builtin_amdgcn_ballot_w64(m[k] == wmaxf);
-      if (mk) widx = kstride * k + base + mult * (unsigned)__builtin_ctzll(mk);
-    }
-    widx |= (unsigned)kTieBit;
-  }
-}
-
-// LDS accesses of the exchanges, one per instruction (GACQ_UNPAIR, gacq_cplx.h): LDS_LD for every read; LDS_ST1 for the writes of the
-// 16384-point transforms (the 4096-point ones are faster with their writes left to the compiler's ds_write2_b64 pairing)
-__device__ __forceinline__ v2 lds_ld1(const v2& x) { const v2 r = x; GACQ_UNPAIR(); return r; }
-#define LDS_LD(x) lds_ld1(x)
-#define LDS_ST1(dst, val) do { (dst) = (val); GACQ_UNPAIR(); } while (0)
 
 // Length-4096 transform of the 16 values per lane. In: v[j] = x[t + 256 j]; out: v[rev16(k2)] = X[t + 256 k2].
 // wa = W_4096^t, wb = W_256^(t & 15) (forward values; conjugated here when INV).
@@ -168,14 +122,11 @@ __device__ __forceinline__ void fft4096(v2 (&v)[kR], v2* lds, v2 wa, v2 wb, cons
   dft16<INV>(v);
 }
 
-__device__ __forceinline__ v2 ld2(const float2* p) { return *reinterpret_cast<const v2*>(p); }
 
 // Lane-pair layout used for X and C_p inside this engine: natural index i = t + 256 j (t = lane, j = 0..15)
 // is stored at (j>>1)*512 + 2 t + (j&1), so one lane's values for j = 2jp, 2jp+1 are 16 contiguous bytes and
 // a wave reads/writes 1 KiB per instruction.  Rows are fetched with buffer loads: the row base lives in an
 // SGPR resource, the lane offset (16 t) in one VGPR, the piece offset in an SGPR -- no VALU address math.
-typedef float f4 __attribute__((ext_vector_type(4)));
-typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const float2* row) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, kLdsN * (int)sizeof(float2), 0x00020000);
@@ -262,10 +213,6 @@ constexpr int kBigThreads = 1024;
 constexpr int kRegion = 1056;                               // complex elements per wave region
 constexpr int kBigScratch = 16 * kRegion * (int)sizeof(v2); // byte offset of the cross-wave reduction scratch
 constexpr int kBigLdsBytes = kBigScratch + 256;
-
-// workgroup barrier that does not drain the vector-memory counter: an LDS-DMA in flight survives it (__syncthreads() would
-// wait for vmcnt(0) first).  lgkmcnt(0): this wave's LDS stores have been performed before the others are released.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Phase timing of lds16k_correlate_kernel (diagnostic builds only, -DGACQ_PHASE_TIMING16; tools/phase_timing16.py): lane 0 of every
 // wave accumulates the shader-clock cycles between marks into gacq_phase16[wave][phase] (read back with gacq_debug_phase16).
@@ -416,8 +363,6 @@ __device__ __forceinline__ void ld_pair_big(__amdgpu_buffer_rsrc_t r, unsigned l
 
 // LDS-DMA of one spectrum row into the wave's own region: 8 x 1 KiB, lane l's 16 bytes of piece jp land at
 // region + 1024 jp + 16 l -- no VGPRs are tied up while the row is in flight.
-typedef __attribute__((address_space(1))) const void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
 __device__ __forceinline__ void dma_row(const float2* __restrict__ row, v2* reg) {
   const char* src = reinterpret_cast<const char*>(row) + (size_t)threadIdx.x * 16;
 #pragma unroll
@@ -1138,6 +1083,10 @@ namespace gacq {
 
 bool lds_supported(int N) { return N == kLdsN || N == kBig; }
 
+// N = 16384: the radix-16 form of this file unless GACQ_OPT_LDS_VARIANT = 32 selects the radix-32 form of gacq_lds16k.hip (same time,
+// fewer instructions, fewer waves: the in-run A/B of bench.py)
+static bool radix16_16k(const gacq_ctx* ctx) { return ctx->opt[GACQ_OPT_LDS_VARIANT] != 32; }
+
 #ifdef GACQ_PHASE_TIMING16
 extern "C" int gacq_debug_phase16(unsigned long long* out128, int reset) {
   if (hipMemcpyFromSymbol(out128, HIP_SYMBOL(gacq_phase16), sizeof(unsigned long long) * 128) != hipSuccess) return GACQ_ERR_HIP;
@@ -1150,8 +1099,9 @@ extern "C" int gacq_debug_phase16(unsigned long long* out128, int reset) {
 #endif
 
 // code spectra straight from the (complex, zero-extended) replica rows with the engine's own forward transform: no rocFFT plan
-int lds_code_spectra(gacq_ctx* ctx, const float2* replica_rows, float2* perm, int nprn, int N) {
+int lds_code_spectra(gacq_ctx* ctx, const float2* replica_rows, float2* perm, int nprn, int N, bool radix32) {
   if (!lds_supported(N)) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "LDS FFT engine: N=%d not supported", N);
+  if (N == kBig && radix32) return r32_code_spectra(ctx, replica_rows, perm, nprn);
   if (N == kBig) {
     const float2* twn;
     int rcb = twiddle_cache(ctx, "W16384_lo", kBig, 1024, &twn);
@@ -1174,6 +1124,7 @@ int lds_code_spectra(gacq_ctx* ctx, const float2* replica_rows, float2* perm, in
 int lds_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n, int N, const double* d_freq, int FD,
                 int B, const float2* tab, float2* X) {
   if (!lds_supported(N)) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "LDS FFT engine: N=%d not supported", N);
+  if (N == kBig && !radix16_16k(ctx)) return r32_forward(ctx, x, nsamp, nepoch, n, d_freq, FD, B, tab, X);
   if (N == kBig) {
     const float2* twn;
     int rcb = twiddle_cache(ctx, "W16384_lo", kBig, 1024, &twn);
@@ -1198,6 +1149,7 @@ bool lds_fused_supported(const gacq_ctx* ctx, int N, int P, int F) { return N ==
 int lds_fused_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n, int N, const float2* spectra, const int* d_items,
                      const int* d_fset, const double* d_freq, const float2* tab, int nitems, int D, int B, RowRec* rows, float tie_scale) {
   if (N != kBig) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "fused LDS search: N=%d not supported", N);
+  if (!radix16_16k(ctx)) return r32_fused_search(ctx, x, nsamp, nepoch, n, spectra, d_items, d_fset, d_freq, tab, nitems, D, B, rows, tie_scale);
   const float2* twn;
   int rc = twiddle_cache(ctx, "W16384_lo", kBig, 1024, &twn);
   if (rc != GACQ_OK) return rc;
@@ -1258,6 +1210,7 @@ int lds_fused4k_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch,
 
 int lds_debug_nco(gacq_ctx* ctx, int N, int n, const double* d_freq, bool fused, int* d_idx) {
   if (!lds_supported(N) || (fused && N != kBig)) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "NCO index dump: no %sLDS forward kernel for N=%d", fused ? "fused " : "", N);
+  if (N == kBig && !radix16_16k(ctx)) return r32_debug_nco(ctx, n, d_freq, fused, d_idx);
   if (N == kBig && fused) {
     int rc = ensure(ctx, ctx->fset, sizeof(int));
     if (rc != GACQ_OK) return rc;
@@ -1283,6 +1236,7 @@ int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const i
                   int nitems, int F, int D, int B, int N, RowRec* rows, float tie_scale, float* q_out) {
   if (q_out && (nepoch != 1 || nitems != 1 || D != 1)) return set_error(ctx, GACQ_ERR_BAD_ARG, "LDS FFT engine: a row dump takes exactly one row");
   if (!lds_supported(N)) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "LDS FFT engine: N=%d not supported", N);
+  if (N == kBig && !radix16_16k(ctx)) return r32_correlate(ctx, X, spectra, d_items, d_fset, nepoch, nitems, F, D, B, rows, tie_scale, q_out);
   if (N == kBig) {
     const float2* twn;
     int rcb = twiddle_cache(ctx, "W16384_lo", kBig, 1024, &twn);

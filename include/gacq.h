@@ -117,7 +117,10 @@ int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes);
                                 /*     in-place inner inverse transforms; gacq_pfa.hip); 0 = Cooley-Tukey form with rocFFT inner transforms    */
                                 /*     (other arithmetic: the cross-check)                                                                     */
 #define GACQ_OPT_FUSED_16K 1    /* [1] N = 16384 with one carrier per item: forward + correlate in one kernel           */
-#define GACQ_OPT_LDS_VARIANT 2  /* retired (round 3): the build carries one instantiation of lds_correlate_kernel; accepted, ignored   */
+#define GACQ_OPT_LDS_VARIANT 2  /* [-1] N = 16384: 32 = the radix-32 form of the one-workgroup transform (512 threads x 32 points, two       */
+                                /*     exchanges; gacq_lds16k.hip) instead of the radix-16 form (1024 x 16, three exchanges).  Same results to */
+                                /*     fp32 rounding, same time, 13 % fewer VALU instructions at half the waves (the in-run A/B of bench.py);  */
+                                /*     every other value: radix-16 form                                                                        */
 #define GACQ_OPT_LDS_PCH 3      /* [0 = auto] items per workgroup of the LDS correlate kernels                          */
 #define GACQ_OPT_SPLIT_PCH 4    /* [0 = auto] (epoch, item) rows per workgroup of the split engines' inner kernels      */
 #define GACQ_OPT_SPLIT_TEAMS 5  /* retired (round 5): belonged to the Stockham inner kernel the prime-factor engine replaced; accepted, ignored */

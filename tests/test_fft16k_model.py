@@ -15,3 +15,14 @@ def test_fft16k_layouts_compute_the_dft_and_are_bank_conflict_free():
     ferr, ierr, conflicts = m.run()
     assert ferr < 1e-12 and ierr < 1e-12, (ferr, ierr)
     assert len(conflicts) == 12 and all(v == 0 for v in conflicts.values()), conflicts
+
+
+def test_radix32_fft16k_layouts_compute_the_dft_and_are_bank_conflict_free():
+    """The radix-32 form (gacq_lds16k.hip, GACQ_OPT_LDS_VARIANT = 32): 512 threads x 32 points, 32 x 32 x 16, two exchanges."""
+    spec = importlib.util.spec_from_file_location("model_fft16k_r32", os.path.join(ROOT, "tools", "model_fft16k_r32.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    ferr, ierr, conflicts = m.run()
+    assert ferr < 1e-12 and ierr < 1e-12, (ferr, ierr)
+    assert len(conflicts) == 8 and all(v == 0 for v in conflicts.values()), conflicts
+    assert m.staged_row_conflicts() <= 32 * m.S * 8           # the LDS-DMA landing area of the last wave ends inside its own regions

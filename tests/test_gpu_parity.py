@@ -165,9 +165,11 @@ def test_batched_device_path_equals_single_searches(engine):
         engine.set_engine(0)
 
 
-def test_glonass_fused_16k_kernel_equals_two_kernel_path(engine):
+@pytest.mark.parametrize("variant", [-1, 32], ids=["radix16", "radix32"])
+def test_glonass_fused_16k_kernel_equals_two_kernel_path(engine, variant):
     """One carrier per item (FDMA channels): forward + correlate run in one kernel without the X buffer.  Same arithmetic
-    in the same order, so the peak records must be bit-identical to the forward-kernel + correlate-kernel path."""
+    in the same order, so the peak records must be bit-identical to the forward-kernel + correlate-kernel path -- in both forms of the
+    N = 16384 transform."""
     import os
     import torch
     from gnss_dsp_tools_amd import acquire, signals, synth
@@ -178,6 +180,7 @@ def test_glonass_fused_16k_kernel_equals_two_kernel_path(engine):
     xs = synth.make_epochs(sig, B, 99, synth.default_sats(items), 2)
     xd = torch.from_numpy(xs).to("cuda:0")
     try:
+        engine.set_option("lds_variant", variant)
         engine.set_profiling(True)
         engine.reset_stage_times()
         fused = engine.search_batch_dev(sig, xd, items, dop, B)
@@ -192,6 +195,7 @@ def test_glonass_fused_16k_kernel_equals_two_kernel_path(engine):
         assert engine.stage_times()["mix_nco"][1] == 1
     finally:
         engine.set_option("fused_16k", 1)
+        engine.set_option("lds_variant", -1)
         engine.set_profiling(False)
     assert fused.tobytes() == plain.tobytes()
 
@@ -768,17 +772,43 @@ SPLIT_LDS_CASES = ["cfg3_e1b_subset", "cfg3_e1c_subset", "e1b_ms12", "cfg5_b1i_m
 LDS16K_CASES = ["cfg5_b1i_ms10", "b2i_ms2", "cfg5_glonass_l1", "glonass_l2"]
 
 
+@pytest.mark.parametrize("variant", [-1, 32], ids=["radix16", "radix32"])
 @pytest.mark.parametrize("cid", LDS16K_CASES)
-def test_single_workgroup_16384_engine_matches_reference_golden(engine, golden_cases, cid):
-    """N = 16384 through engine 2: the whole transform in one 1024-thread workgroup (4 x 4096 in LDS)."""
+def test_single_workgroup_16384_engine_matches_reference_golden(engine, golden_cases, cid, variant):
+    """N = 16384 through engine 2: the whole transform in one workgroup -- 1024 threads x 16 points (16 x 16 x 16 x 4, the default) or
+    512 threads x 32 points (32 x 32 x 16, option lds_variant = 32: gacq_lds16k.hip)."""
     case = golden_cases[cid]
     x = case_iq(case)
     engine.set_engine(2)
+    engine.set_option("lds_variant", variant)
     try:
         got = engine.search_all(case["script"], x, case["items"], case["doppler_search"], case["ms"])
     finally:
+        engine.set_option("lds_variant", -1)
         engine.set_engine(0)
     _assert_results(got, case["results"], case)
+
+
+def test_radix32_16384_rows_match_the_radix16_rows(engine):
+    """Both forms of the N = 16384 transform compute the same magnitude row (different butterfly order: equal to fp32 rounding, the peak
+    on the same lag), for a raw-metric padded signal and a biased-carrier one."""
+    from gnss_dsp_tools_amd import signals, synth
+    for name, item in (("beidou-b1i", 12), ("glonass-l1", -3)):
+        sig = signals.get(name)
+        B = 3
+        x = synth.make_iq(sig, B, 5, synth.default_sats([item]))
+        rows = {}
+        for variant in (-1, 32):
+            engine.set_engine(2)
+            engine.set_option("lds_variant", variant)
+            try:
+                rows[variant] = engine.debug_row(sig, x, item, 1250.0, B)
+            finally:
+                engine.set_option("lds_variant", -1)
+                engine.set_engine(0)
+        a, b = rows[-1], rows[32]
+        assert int(np.argmax(a)) == int(np.argmax(b))
+        assert np.abs(a - b).max() <= 2e-6 * np.abs(a).max(), (name, np.abs(a - b).max(), np.abs(a).max())
 
 
 @pytest.mark.parametrize("cid", SPLIT_LDS_CASES)
@@ -1099,12 +1129,18 @@ def test_device_nco_indices_are_bit_exact(engine, golden_nco):
         sig = signals.get(script)
         s = engine.signal(sig, [0] if sig.bias_hz else [1])
         for k in kernels:
-            idx = s.nco_indices(k, v["doppler"], v.get("bias", 0.0))
-            assert idx.dtype == np.int32 and len(idx) == v["n"]
-            assert [int(i) for i in idx[:16]] == v["head"] and [int(i) for i in idx[-16:]] == v["tail"], (script, k, v["doppler"])
-            assert hashlib.sha256(idx.tobytes()).hexdigest() == v["sha256"], (script, k, v["doppler"])
-            checked += 1
-    assert checked == 6 * 2 + 3 * 2 + 3 * 3 + 2 * 4 + 2 * 4 + 2 * 4
+            # the LDS forward (2) and fused (4) kernels of N = 16384 exist in two forms: radix-16 (default) and radix-32 (lds_variant = 32)
+            for variant in ((-1, 32) if v["n"] == 16384 and k in (2, 4) else (-1,)):
+                engine.set_option("lds_variant", variant)
+                try:
+                    idx = s.nco_indices(k, v["doppler"], v.get("bias", 0.0))
+                finally:
+                    engine.set_option("lds_variant", -1)
+                assert idx.dtype == np.int32 and len(idx) == v["n"]
+                assert [int(i) for i in idx[:16]] == v["head"] and [int(i) for i in idx[-16:]] == v["tail"], (script, k, v["doppler"], variant)
+                assert hashlib.sha256(idx.tobytes()).hexdigest() == v["sha256"], (script, k, v["doppler"], variant)
+                checked += 1
+    assert checked == 6 * 2 + 3 * 2 + 3 * 3 + 2 * 4 + 2 * 4 + 2 * 4 + 3 * 2 * 2
     with pytest.raises(nat.GacqError) as ei:             # no LDS forward kernel for N = 65536
         engine.signal("galileo-e1b", [1]).nco_indices(2, 125.0)
     assert ei.value.code == -9

@@ -11,7 +11,7 @@ CSRC=$ROOT/gnss-dsp-tools_amd/csrc; BUILD=$ROOT/gnss-dsp-tools_amd/build; OUT=$B
 ROCM=${ROCM:-/opt/rocm}
 mkdir -p "$OUT"
 OBJS=""
-for o in gacq_engine gacq_ldsfft gacq_split gacq_pfa gacq_frontend gacq_longcode gacq_tracking gacq_host gacq_verify gacq_tiesafe gacq_probe prn_codes; do
+for o in gacq_engine gacq_ldsfft gacq_lds16k gacq_split gacq_pfa gacq_frontend gacq_longcode gacq_tracking gacq_host gacq_verify gacq_tiesafe gacq_probe prn_codes; do
   use=$BUILD/$o.o
   for f in "$@"; do
     if [ "$(basename "$f" .hip)" = "$o" ]; then

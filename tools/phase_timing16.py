@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Where the waves of lds16k_correlate_kernel spend their cycles (diagnostic): needs a variant built with -DGACQ_PHASE_TIMING16,
-   tools/build_variant.sh timing16 -DGACQ_PHASE_TIMING16 gacq_ldsfft.hip ; python tools/variant.py timing16 tools/phase_timing16.py
+"""Where the waves of the N = 16384 correlate kernel spend their cycles (diagnostic): needs a variant built with -DGACQ_PHASE_TIMING16,
+   tools/build_variant.sh timing16 -DGACQ_PHASE_TIMING16 gacq_lds16k.hip ; python tools/variant.py timing16 tools/phase_timing16.py
+(radix-32 form, with lds_variant=32 on the command line; the radix-16 form: build gacq_ldsfft.hip with the flag instead)
 Prints shader-clock cycles per row, wave and phase (lane 0 of every wave, summed over all workgroups)."""
 import ctypes
 import os
@@ -14,8 +15,10 @@ import torch
 from gnss_dsp_tools_amd import _native as nat
 from gnss_dsp_tools_amd import acquire, signals, synth
 
-PHASES = ["item tail: reduction, C loads", "DMA wait + x read + C*x", "wave-private 1024-pt inverse (3 LDS round trips)", "barrier B", "gather + barrier A",
-          "DMA issue (next row)", "last radix-16 pass + magnitudes", ""]
+PHASES16 = ["item tail: reduction, C loads", "DMA wait + x read + C*x", "wave-private 1024-pt inverse (3 LDS round trips)", "barrier B", "gather + barrier A",
+            "DMA issue (next row)", "last radix-16 pass + magnitudes", ""]
+PHASES32 = ["item tail: reduction, C loads", "DMA wait + staged-row reads issued", "(unused)", "C*x + two DFT16 + transpose + table B + DFT32 + exchange stores",
+            "barrier 1", "gather + barrier 2", "DMA issue + table A + last DFT32 + magnitudes", ""]
 
 
 def main():
@@ -27,6 +30,7 @@ def main():
     for kv in sys.argv[1:]:
         k, v = kv.split("=")
         eng.set_option(k, int(v))
+    PHASES = PHASES32 if eng.get_option("lds_variant") == 32 else PHASES16
     sig = signals.get("beidou-b1i")
     items = list(range(1, 64))
     dop = acquire.doppler_grid([-10000.0, 10000.0, 100.0])
@@ -46,7 +50,8 @@ def main():
     a = np.array(list(buf), dtype=np.float64).reshape(16, 8) / rows
     print("cycles per row, by wave (rows) and phase (columns); wave w sits on SIMD (0,2,1,3)[w % 4]")
     print("wave " + " ".join("%8d" % i for i in range(7)) + "    total")
-    for w in range(16):
+    a = a[a.sum(1) > 0]
+    for w in range(len(a)):
         print("%4d " % w + " ".join("%8.0f" % a[w, i] for i in range(7)) + " %8.0f" % a[w].sum())
     print("mean " + " ".join("%8.0f" % a[:, i].mean() for i in range(7)) + " %8.0f" % a.sum(1).mean())
     for i, name in enumerate(PHASES[:7]):
