@@ -59,6 +59,70 @@ CONFIGS = {
 }
 
 
+class ClockSampler:
+    """Shader clock and socket power of the benchmark's GPU while a timed region runs: a thread reads the amdgpu sysfs files (the
+    starred level of pp_dpm_sclk = what rocm-smi prints as sclk, hwmon power1_input in microwatts) every 25 ms; no subprocess, no
+    runtime call.  The chip clocks to its power budget (MI355X_MICROARCH.md, DVFS), so a roofline priced at 2.4 GHz under-reads a kernel
+    that holds the part at its power limit: frac_at_measured_clock divides by the clock that was actually there."""
+
+    def __init__(self, dev_index):
+        import glob
+        self.sclk_path = self.power_path = None
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(dev_index)
+            want = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            pass
+        cards = []
+        for c in sorted(glob.glob("/sys/class/drm/card*/device")):
+            if os.path.exists(os.path.join(c, "pp_dpm_sclk")):
+                cards.append((os.path.basename(os.path.realpath(c)), c))
+        pick = [c for a, c in cards if want and a.lower() == want.lower()] or ([cards[0][1]] if len(cards) == 1 else [])
+        if pick:
+            self.sclk_path = os.path.join(pick[0], "pp_dpm_sclk")
+            pw = glob.glob(os.path.join(pick[0], "hwmon", "hwmon*", "power1_input")) + glob.glob(os.path.join(pick[0], "hwmon", "hwmon*", "power1_average"))
+            self.power_path = pw[0] if pw else None
+        self.samples, self._stop, self._thread = [], False, None
+
+    def _read(self):
+        mhz = watts = None
+        try:
+            for line in open(self.sclk_path).read().splitlines():
+                if line.rstrip().endswith("*"):
+                    mhz = float(line.split(":")[1].strip().split("M")[0])
+            if self.power_path:
+                watts = float(open(self.power_path).read()) * 1e-6
+        except Exception:
+            pass
+        return mhz, watts
+
+    def start(self):
+        if not self.sclk_path:
+            return self
+        import threading
+
+        def loop():
+            while not self._stop:
+                self.samples.append(self._read())
+                time.sleep(0.025)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop = True
+        if self._thread:
+            self._thread.join()
+        mhz = [m for m, _ in self.samples if m]
+        w = [x for _, x in self.samples if x]
+        if not mhz:
+            return None
+        return {"sclk_mhz_mean": float(np.mean(mhz)), "sclk_mhz_min": float(np.min(mhz)), "sclk_mhz_max": float(np.max(mhz)),
+                "power_w_mean": float(np.mean(w)) if w else None, "samples": len(mhz),
+                "source": "amdgpu sysfs (pp_dpm_sclk starred level, hwmon power1_input), one read per 25 ms during the sustained timed region"}
+
+
 def a_pipe_bytes(N, P, D, B, F=1):
     """Algorithmic bytes of ONE search under the stage-boundary model (SURVEY.md section 8d / BASELINE.md section 3):
     A_pipe = S*N*(4*D*B*F + P + 5*P*D*B) + 8*N*P*D*(B-1)."""
@@ -376,6 +440,43 @@ def reference_precision_other_configs(args, env, seconds=0.6):
 _STREAM_CEILINGS = {}
 
 
+def ab_n16384(args, env, rounds=4, reps=6):
+    """In-run A/B of the two forms of the one-workgroup N = 16384 transform (GACQ_OPT_LDS_VARIANT: radix-32, 512 threads x 32 points,
+    gacq_lds16k.hip, the default; 16 = radix-16, 1024 threads x 16 points) on config 5's two N = 16384 signals: same process, same engine
+    context, same resident samples, the option flipped between short bursts so that box, clocks and allocation are shared."""
+    from gnss_dsp_tools_amd import acquire
+    dev = env["dev"]
+    jobs = [j for j in build_jobs(CONFIGS[5], 1, dev) if j["sig"].nfft == 16384]
+    eng = acquire.Engine(env["local_rank"])
+    eng.use_torch_stream(dev)
+    ms = {}
+    try:
+        for variant in (16, -1):                 # first use: code spectra, workspaces
+            eng.set_option("lds_variant", variant)
+            for j in jobs:
+                eng.search_batch_dev(j["sig"], j["x"], j["flat"], j["dop"], j["B"])
+        torch.cuda.synchronize(dev)
+        for _ in range(rounds):
+            for variant in (16, -1):
+                eng.set_option("lds_variant", variant)
+                for j in jobs:
+                    eng.search_batch_dev(j["sig"], j["x"], j["flat"], j["dop"], j["B"])          # settle
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        eng.search_batch_dev(j["sig"], j["x"], j["flat"], j["dop"], j["B"])
+                    torch.cuda.synchronize(dev)
+                    ms.setdefault((j["label"], variant), []).append((time.perf_counter() - t0) / reps * 1e3)
+    finally:
+        eng.set_option("lds_variant", -1)
+        eng.close()
+    out = {"what": "ms per search of config 5's N = 16384 signals (B1I: 63 items x 200 bins x 10 blocks through forward + correlate kernels; "
+                   "GLONASS L1: 15 channels x 200 x 10 through the fused kernel), median of %d alternating bursts of %d calls" % (rounds, reps)}
+    for (label, variant), v in sorted(ms.items()):
+        out["%s_radix%d_ms" % (label.replace("-", "_"), 16 if variant == 16 else 32)] = float(np.median(v))
+    return out
+
+
 def stream_ceilings(eng):
     """GB/s a tuned streaming kernel reaches on THIS device, measured now (gacq_stream_probe: eight 16-byte non-temporal accesses in
     flight per lane, 1 GiB per launch, 8 timed launches per figure): fill (stores), read, copy (read + write bytes).  Cached per process."""
@@ -660,6 +761,16 @@ def main():
             out["next_rows"] = next_rows(args, env)
         except Exception as exc:
             out["next_rows"] = {"error": repr(exc)[:300]}
+        # in-run A/Bs of the levers this round claims or rules out, inside `roofline` so that they travel with the parsed line
+        ab = {}
+        try:
+            ab["n16384_transform"] = ab_n16384(args, env)
+        except Exception as exc:
+            ab["n16384_transform"] = {"error": repr(exc)[:300]}
+        ts = out.get("tie_safe") or {}
+        if "ms_per_step_with_tie_safe_off" in ts:
+            ab["tie_safe_locations"] = {"on_ms_per_step": out["ms_per_step"], "off_ms_per_step": ts["ms_per_step_with_tie_safe_off"]}
+        out["roofline"]["ab"] = ab
         out["bench_wall_s"] = time.perf_counter() - t_start
     if rank == 0:
         print(json.dumps(out))
@@ -887,10 +998,17 @@ def run(args, env):
         preroll["seconds"] = time.perf_counter() - t0
     run_steps(args.warmup)
     merged, dt = timed(args.steps)
+    plain_ratio = None
+    if use_dist and world == 1:
+        # launched by torch.distributed.run with one rank: the same K steps once more without the barrier / MAX-reduce bracket of the
+        # distributed contract -- the two must agree, or the launch path itself costs something
+        _, dt_plain = make_timed(run_steps, dev, False)(args.steps)
+        plain_ratio = dt_plain / dt
 
     # Second, longer timed region: the K-step region above can be a few milliseconds and sits in boost clocks; this one runs
     # the same steps for >= --sustained-s seconds so that DVFS cannot flatter the number (reported beside `value`).
     sustained = None
+    clocks = None
     if args.sustained_s > 0:
         k_sus, per_step = args.steps, dt / args.steps
         for _ in range(4):                               # the first estimate of the step time may be off: repeat until long enough
@@ -899,11 +1017,13 @@ def run(args, env):
                 kt = torch.tensor([k_sus], dtype=torch.int64, device=dev)
                 dist.all_reduce(kt, op=dist.ReduceOp.MAX)
                 k_sus = int(kt.item())
+            sampler = ClockSampler(local_rank).start() if rank == 0 else None
             _, dt_sus = timed(k_sus)
+            clocks = sampler.stop() if sampler else None
             per_step = dt_sus / k_sus
             if dt_sus >= args.sustained_s:
                 break
-        sustained = {"steps": k_sus, "seconds": dt_sus, "ms_per_step": dt_sus / k_sus * 1e3, "value": cells_step * k_sus / dt_sus}
+        sustained = {"steps": k_sus, "seconds": dt_sus, "ms_per_step": dt_sus / k_sus * 1e3, "value": cells_step * k_sus / dt_sus, "clocks": clocks}
 
     # ---- correctness of what was just computed (not timed) ----------------------------------------------------------
     # (a) every rank received `world` shards: one more step with the un-merged exchange buffer kept -- noise alone gives
@@ -949,6 +1069,7 @@ def run(args, env):
             ej.set_profiling(True)
             ej.reset_stage_times()
         pend = [None] * len(jobs)
+        t_prof = time.perf_counter()
         for _ in range(prof_steps):
             for ji, ((ej, shj), job) in enumerate(zip(prof, jobs)):
                 nxt = shj.search_jobs_async([job])
@@ -958,6 +1079,7 @@ def run(args, env):
         for pj_ in pend:
             pj_.wait()
     torch.cuda.synchronize(dev)
+    prof_ms_per_step = (time.perf_counter() - t_prof) / prof_steps * 1e3
     per_job = []
     for (ej, _), job in zip(prof, jobs):
         b = bounds_of(len(job["dop"]))
@@ -985,8 +1107,8 @@ def run(args, env):
     _, dj, dstage = max(cand, key=lambda c: c[0])
     dk = dj["stages"][dstage]
     work_launch = dk["work_per_step"] / dk["launches_per_step"]
-    kernel_name = {("lds", "lds_correlate", 4096): "lds_correlate_kernel", ("lds", "lds_correlate", 16384): "lds16k_correlate_kernel / lds16k_fused_kernel",
-                   ("lds", "mix_nco", 4096): "lds_forward_kernel", ("lds", "mix_nco", 16384): "lds16k_forward_kernel",
+    kernel_name = {("lds", "lds_correlate", 4096): "lds_correlate_kernel", ("lds", "lds_correlate", 16384): "r32_correlate_kernel / r32_fused_kernel",
+                   ("lds", "mix_nco", 4096): "lds_forward_kernel", ("lds", "mix_nco", 16384): "r32_forward_kernel",
                    ("split31", "lds_correlate"): "pfa_inner_corr_kernel", ("split_lds", "lds_correlate"): "lds_inner_correlate_kernel",
                    ("split31", "mag_peak"): "pfa_outer_inverse_kernel", ("split_lds", "mag_peak"): "split_outer_inverse_kernel",
                    ("split31", "mix_nco"): "pfa_outer_forward_kernel + pfa_inner_forward_kernel", ("split_lds", "mix_nco"): "split_outer_forward_kernel + lds_inner_forward_kernel"}
@@ -994,6 +1116,8 @@ def run(args, env):
     if dj["engine"] == "lds" and dstage == "lds_correlate":
         kname = {(4096, True): "lds_fused4k_kernel", (4096, False): "lds_correlate_kernel", (16384, True): "lds16k_fused_kernel",
                  (16384, False): "lds16k_correlate_kernel"}[(dj["N"], dj["fused_forward"])]
+        if dj["N"] == 16384 and "lds_variant=16" not in args.option:
+            kname = "r32_fused_kernel" if dj["fused_forward"] else "r32_correlate_kernel"
     if dk["bound"] == "valu":
         achieved = work_launch / (dk["avg_ms"] * 1e-3) / 1e12
         roofline = {"bound": "valu", "kernel": kname, "signal": dj["signal"], "achieved": achieved, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -1007,6 +1131,17 @@ def run(args, env):
                     "frac": achieved / HBM_PEAK_GBPS, "avg_kernel_ms": dk["avg_ms"], "alg_bytes_per_launch": work_launch,
                     "model": "bytes this kernel must move through HBM: its side of the split engine's one round trip (8 N per correlation "
                              "row), or x in + X out for the forward stage, over the kernel's HIP-event duration"}
+    # The kernel's HIP-event time comes from the profiling pass (one engine per job, events around every stage), `ms_per_step` from the
+    # timed region: two loops, so the pass carries its own wall-clock step time -- the kernel time of a step can only be read against
+    # THAT -- and the line also prices the dominant kernel against the timed region's step time, a bound that needs no second loop.
+    k_ms_step = dk["avg_ms"] * dk["launches_per_step"]
+    roofline["profiling_pass"] = {"steps": prof_steps, "ms_per_step": prof_ms_per_step, "dominant_kernel_ms_per_step": k_ms_step,
+                                  "kernel_time_within_its_own_step": bool(k_ms_step <= prof_ms_per_step * 1.0005)}
+    roofline["frac_floor_from_timed_step"] = roofline["frac"] * k_ms_step / max(k_ms_step, dt / args.steps * 1e3)
+    if clocks and clocks.get("sclk_mhz_mean"):
+        roofline["clocks"] = clocks
+        if dk["bound"] == "valu":      # the FP32 vector peak is 256 CUs x 4 SIMDs x 32 lanes x 2 (packed) x 2 flop x 2.4 GHz
+            roofline["frac_at_measured_clock"] = roofline["frac"] * 2400.0 / clocks["sclk_mhz_mean"]
     if dk["bound"] == "hbm":
         # `peak` stays the 8 TB/s of MI355X_MICROARCH.md; what a plain streaming kernel reaches on this part is lower and differs by
         # direction (tools/hbm_bandwidth.hip, profiles/r03_hbm_read_write_copy_bandwidth.log): 16-byte stores 4.2-4.7 TB/s, loads 6.5-7.1
@@ -1117,7 +1252,13 @@ def run(args, env):
         for _ in range(3):
             eng.search(sig, xh, 7, ds, ms)              # builds the 1-PRN signal (code spectrum, FFT plan) once
         t_one = median_call(lambda: eng.search(sig, xh, 7, ds, ms))
-        latency = {"search_all_32prn_us": t_all * 1e6, "search_1prn_us": t_one * 1e6,
+        # the same call with complex128 samples -- the dtype the reference's search() is handed (np.interp output,
+        # acquire-gps-l1.py:94-96) and what the drop-in wrapper passes on to gacq_search64
+        xh128 = xh.astype(np.complex128)
+        for _ in range(3):
+            eng.search_all(sig, xh128, items, ds, ms)
+        t_all128 = median_call(lambda: eng.search_all(sig, xh128, items, ds, ms))
+        latency = {"search_all_32prn_us": t_all * 1e6, "search_1prn_us": t_one * 1e6, "search_all_32prn_complex128_in_us": t_all128 * 1e6,
                    "cells_per_s_single_epoch_pcie_inclusive": P * D * N / t_all}
         eng.use_torch_stream(dev)
         # host-resident batches streamed through pinned double buffers (H2D of batch i+1 under the kernels of batch i)
@@ -1171,6 +1312,18 @@ def run(args, env):
                          "us_per_search": dt / args.steps / E_total * 1e6, "cell_blocks_per_s": cell_blocks_step * args.steps / dt,
                          "per_signal": per_job},
         }
+        if latency:
+            # SURVEY 8(d)'s primary figure: wall time of ONE search_all call from host memory (H2D of x + kernels + D2H of the results),
+            # median of 60 calls after warm-up
+            out["config"]["single_call_us"] = latency["search_all_32prn_us"]
+            out["config"]["single_call_cells_per_s"] = latency["cells_per_s_single_epoch_pcie_inclusive"]
+            out["config"]["single_call_complex128_in_us"] = latency["search_all_32prn_complex128_in_us"]
+        if plain_ratio is not None:
+            out["config"]["torchrun_of_one_over_plain_run"] = {"value_ratio": plain_ratio, "within_2_percent": bool(abs(plain_ratio - 1.0) <= 0.02)}
+        if use_dist:
+            out["config"]["collective_backend"] = dist.get_backend()
+            out["config"]["ranks_in_the_process_group"] = dist.get_world_size()
+            assert dist.get_world_size() == world and (args.gpus == world or world == 1), ("launched with --gpus %d, the process group has %d ranks" % (args.gpus, dist.get_world_size()))
         # tie-safe peak locations run inside every timed step (tagging in the row reductions, the ambiguity test in the Doppler scan, the
         # re-evaluation launches); the counters say how many pairs of this run needed the complex128 re-evaluation -- the bench's
         # epochs carry strong injected satellites, so usually none (tools/tie_census.py is the noise-only census)

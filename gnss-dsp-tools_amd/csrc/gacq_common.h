@@ -74,6 +74,10 @@ struct gacq_ctx {
   std::string err;
   int engine = 0;
   size_t ws_limit = (size_t)32 << 30;      // of 288 GB: a B = 80 search of engine 3 is 22 % faster in 64 GiB passes than in 4 GiB ones (r05_workspace_limit_sweep.log)
+  bool ws_explicit = false;                // the caller set the limit (gacq_set_workspace_limit): it is not second-guessed from the free memory
+  size_t ws_soft = 0;                      // what the device's free memory allows this context per buffer (0 = not looked yet); halved after a failed allocation
+  int ws_soft_nctx = 0;                    // contexts on the device when ws_soft was computed
+  bool alloc_failed = false;               // ensure() could not get its bytes: the search is retried in smaller passes
   std::map<std::pair<long, long>, gacq::FftPlan> plans;   // (N * 2 + inverse, batch)
   gacq::DevBuf tab, xstage, x32, X, Y, rows, freq, fset, items, out_peaks, d0, partial, fe_a, fe_b, fe_taps, chunk_peaks, arrivals;
   gacq::DevBuf tie, tie_scratch, tie_q, tie_split, tie_done2;   // tie-safe re-evaluation: counters + lists, complex128 row scratch, per-block magnitude rows
@@ -122,7 +126,7 @@ struct gacq_sig {
   float2* spectra_pfa = nullptr;   // same in the prime-factor engine's order (only when pfa_supported(N))
   float2* spectra_split = nullptr; // split engine with LDS inner transforms: R lane-pair rows per item (N = R*4096)
   float2* spectra_lds = nullptr;   // same in the LDS engine's lane-pair layout (only when lds_supported(N))
-  float2* spectra_lds32 = nullptr; // N = 16384 only: the order of the radix-32 form of the transform (GACQ_OPT_LDS_VARIANT = 32, gacq_lds16k.hip)
+  float2* spectra_lds16 = nullptr; // N = 16384 only: the order of the radix-16 form of the transform (GACQ_OPT_LDS_VARIANT = 16; spectra_lds holds the radix-32 form's, gacq_lds16k.hip)
   double2* spectra64 = nullptr;    // complex128 code spectra of the verification engine (engine 5), built on first use
   std::vector<float> replica;      // host copy of the +-1 replicas [nprn][n] (source of spectra64)
 };
@@ -148,6 +152,9 @@ __device__ __forceinline__ double2 ld_x(XSrc x, size_t i) {
 int set_error(gacq_ctx* ctx, int code, const char* fmt, ...);
 void ring_destroy(gacq_ctx* ctx);
 int ensure(gacq_ctx* ctx, DevBuf& b, size_t bytes);
+// bytes one forward-spectra / correlation-workspace buffer of this context may take: the workspace limit, and -- unless the caller set
+// that limit itself -- no more than its share of the device's free memory (two such buffers per context, every context on the device)
+size_t ws_budget(gacq_ctx* ctx);
 // latency path: host write through the PCIe BAR into fine-grained device memory / completion by watching pinned result records
 bool bar_write(gacq_ctx* ctx, DevBuf& b, const void* src, size_t bytes);
 bool watch_records(const volatile unsigned long long* words, size_t count, size_t stride, size_t at, unsigned long long sentinel, int timeout_us);
@@ -164,7 +171,7 @@ void stage_end(gacq_ctx* ctx);
 
 // LDS-resident FFT engine (gacq_ldsfft.hip): supported lengths and the two launches.
 bool lds_supported(int N);
-int lds_code_spectra(gacq_ctx* ctx, const float2* replica_rows, float2* perm, int nprn, int N, bool radix32 = false);      // code spectra in the LDS engines' layout: the replicas through their own forward transform
+int lds_code_spectra(gacq_ctx* ctx, const float2* replica_rows, float2* perm, int nprn, int N, bool radix16 = false);      // code spectra in the LDS engines' layout: the replicas through their own forward transform
 // X[row][k] = conj(FFT_N(x_window * nco))   rows = ((e*F + f)*D + d)*B + b
 int lds_forward(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, int n, int N, const double* d_freq,
                 int FD, int B, const float2* tab, float2* X);

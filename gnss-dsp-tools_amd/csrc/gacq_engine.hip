@@ -127,10 +127,39 @@ int ensure(gacq_ctx* ctx, DevBuf& b, size_t bytes) {
   if (hipMalloc(&b.p, want) != hipSuccess) {
     (void)hipGetLastError();
     want = bytes;
-    GACQ_HIP(ctx, hipMalloc(&b.p, want));
+    const hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      b.p = nullptr;
+      ctx->alloc_failed = true;            // search_batch_dev retries in smaller passes
+      return set_error(ctx, GACQ_ERR_HIP, "hipMalloc of %zu bytes failed: %s", want, hipGetErrorString(e));
+    }
   }
   b.cap = want;
   return GACQ_OK;
+}
+
+// contexts alive per device (gacq_create / gacq_destroy): they share its memory
+static std::atomic<int> g_ctx_on_device[64];
+
+size_t ws_budget(gacq_ctx* ctx) {
+  if (!ctx->ws_explicit) {
+    const int nctx = std::max(1, g_ctx_on_device[ctx->device & 63].load());
+    if (ctx->ws_soft == 0 || nctx > ctx->ws_soft_nctx) {
+      // A context holds up to two buffers of this size (forward spectra X, correlation workspace Y), each with 1/8 of headroom.  What is
+      // free now plus what this context already holds, a fifth of it left to everything else on the device, split evenly over the
+      // contexts: 102 GB for a lone context on an empty 288 GB part (the 32 GiB limit binds), 13 GB each for eight ranks sharing one.
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+        ctx->ws_soft = std::max<size_t>((size_t)64 << 20, (size_t)((double)(free_b + ctx->X.cap + ctx->Y.cap) * 0.8 / 2.25 / nctx));
+      else
+        ctx->ws_soft = ctx->ws_limit;
+      ctx->ws_soft_nctx = nctx;
+    }
+  } else if (ctx->ws_soft == 0) {
+    ctx->ws_soft = ctx->ws_limit;
+  }
+  return std::min(ctx->ws_limit, ctx->ws_soft);
 }
 
 int ensure_pinned(gacq_ctx* ctx, DevBuf& b, size_t bytes) {
@@ -495,6 +524,7 @@ int gacq_create(int device_id, gacq_ctx** out) {
     return set_error(nullptr, GACQ_ERR_HIP, "gacq_create: cannot create stream on device %d", device_id);
   }
   ctx->stream = ctx->own_stream;
+  g_ctx_on_device[device_id & 63]++;
   {
     hipDeviceProp_t prop;
     ctx->large_bar = hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.isLargeBar != 0;
@@ -515,6 +545,7 @@ int gacq_create(int device_id, gacq_ctx** out) {
 
 void gacq_destroy(gacq_ctx* ctx) {
   if (!ctx) return;
+  if (ctx->own_stream) g_ctx_on_device[ctx->device & 63]--;
   DeviceGuard device_guard_(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   ring_destroy(ctx);
@@ -558,6 +589,8 @@ int gacq_set_engine(gacq_ctx* ctx, int engine) {
 int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes) {
   if (!ctx || bytes < ((size_t)1 << 20)) return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_set_workspace_limit: need >= 1 MiB");
   ctx->ws_limit = bytes;
+  ctx->ws_explicit = true;
+  ctx->ws_soft = 0;
   return GACQ_OK;
 }
 
@@ -707,15 +740,15 @@ static int build_signal(gacq_ctx* ctx, const gacq_sigdesc* desc, const std::vect
   if (rc == GACQ_OK && lds_supported(s->N)) {
     if (hipMalloc((void**)&s->spectra_lds, bytes) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "hipMalloc for LDS-layout spectra failed");
     else rc = lds_code_spectra(ctx, tmp, s->spectra_lds, nprn, s->N);
-    if (rc == GACQ_OK && s->N == 16384) {      // the radix-32 form of the N = 16384 transform has its own spectrum order (GACQ_OPT_LDS_VARIANT = 32)
-      if (hipMalloc((void**)&s->spectra_lds32, bytes) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "hipMalloc for LDS-layout spectra failed");
-      else rc = lds_code_spectra(ctx, tmp, s->spectra_lds32, nprn, s->N, true);
+    if (rc == GACQ_OK && s->N == 16384) {      // the radix-16 form of the N = 16384 transform has its own spectrum order (GACQ_OPT_LDS_VARIANT = 16)
+      if (hipMalloc((void**)&s->spectra_lds16, bytes) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "hipMalloc for LDS-layout spectra failed");
+      else rc = lds_code_spectra(ctx, tmp, s->spectra_lds16, nprn, s->N, true);
     }
   }
   if (rc == GACQ_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "code spectrum transform failed");
   if (tmp) (void)hipFree(tmp);
   if (rc == GACQ_OK && !own) rc = natural_spectra(s);      // lengths only the rocFFT pipeline serves
-  if (rc != GACQ_OK) { if (s->spectra) (void)hipFree(s->spectra); if (s->spectra_lds) (void)hipFree(s->spectra_lds); if (s->spectra_lds32) (void)hipFree(s->spectra_lds32); if (s->spectra_pfa) (void)hipFree(s->spectra_pfa); if (s->spectra_split) (void)hipFree(s->spectra_split); delete s; return rc; }
+  if (rc != GACQ_OK) { if (s->spectra) (void)hipFree(s->spectra); if (s->spectra_lds) (void)hipFree(s->spectra_lds); if (s->spectra_lds16) (void)hipFree(s->spectra_lds16); if (s->spectra_pfa) (void)hipFree(s->spectra_pfa); if (s->spectra_split) (void)hipFree(s->spectra_split); delete s; return rc; }
   *out = s;
   return GACQ_OK;
 }
@@ -760,7 +793,7 @@ void gacq_signal_destroy(gacq_sig* sig) {
   (void)hipStreamSynchronize(sig->ctx->stream);
   if (sig->spectra) (void)hipFree(sig->spectra);
   if (sig->spectra_lds) (void)hipFree(sig->spectra_lds);
-  if (sig->spectra_lds32) (void)hipFree(sig->spectra_lds32);
+  if (sig->spectra_lds16) (void)hipFree(sig->spectra_lds16);
   if (sig->spectra_r31) (void)hipFree(sig->spectra_r31);
   if (sig->spectra_pfa) (void)hipFree(sig->spectra_pfa);
   if (sig->spectra_split) (void)hipFree(sig->spectra_split);
@@ -938,7 +971,7 @@ int launch_search(gacq_sig* sig, XSrc xs, const float2* d_x, size_t nsamp, int n
   // epochs per pass so that the forward-spectra buffer respects the workspace limit
   const bool fused16k = path.fused16k;      // one carrier per item: no forward-spectra buffer at all
   const size_t x_epoch_bytes = sizeof(float2) * (size_t)F * D * B * N;
-  int Ec = (int)std::max<size_t>(1, std::min<size_t>((size_t)nepoch, ctx->ws_limit / std::max<size_t>(1, x_epoch_bytes)));
+  int Ec = (int)std::max<size_t>(1, std::min<size_t>((size_t)nepoch, ws_budget(ctx) / std::max<size_t>(1, x_epoch_bytes)));
   const bool search1 = path.search1, fused4k = path.fused4k;
   if (fused16k || fused4k) Ec = nepoch;            // nothing but the 16-byte row records is buffered
   if (search1) {
@@ -951,7 +984,7 @@ int launch_search(gacq_sig* sig, XSrc xs, const float2* d_x, size_t nsamp, int n
   if ((rc = ensure(ctx, ctx->rows, sizeof(RowRec) * (size_t)Ec * P * D)) != GACQ_OK) return rc;
 
   const int chunksN = (N + kBlock * 8 - 1) / (kBlock * 8);
-  const float2* lds_spectra = (N == 16384 && ctx->opt[GACQ_OPT_LDS_VARIANT] == 32) ? sig->spectra_lds32 : sig->spectra_lds;
+  const float2* lds_spectra = (N == 16384 && ctx->opt[GACQ_OPT_LDS_VARIANT] == 16) ? sig->spectra_lds16 : sig->spectra_lds;
   for (int e0 = 0; e0 < nepoch; e0 += Ec) {
     const int ne = std::min(Ec, nepoch - e0);
     const float2* xe = d_x + (size_t)e0 * nsamp;
@@ -1008,7 +1041,13 @@ int launch_search(gacq_sig* sig, XSrc xs, const float2* d_x, size_t nsamp, int n
       const long groups = (long)ne * P * D;
       const int zpitch = use_pfa ? pfa_row_pitch(N) : 0;       // prime-factor engine: Z' rows are whole reader workgroups of 128-byte lines
       const size_t group_bytes = sizeof(float2) * (size_t)B * (zpitch ? (size_t)zpitch * R : (size_t)N);
-      long gc = (long)std::max<size_t>(1, std::min<size_t>((size_t)groups, ctx->ws_limit / group_bytes));
+      // One pass of Z' is at most 4 GiB, or eight items' worth where that is more (the writers share their forward-spectrum tiles
+      // over up to eight items of a pass: a B = 80 search of engine 3 holds 1.4 items in 4 GiB and runs 22 % slower for it).  Beyond
+      // that a bigger pass buys nothing (config 5's E1B, 5.24 GB of Z': 2.09-2.12 ms from 3 GiB to 32 GiB per pass, every point a
+      // fresh process, profiles/r06_e1b_pass_size_sweep.log) and has cost 25 % on one box (round 5's driver run: 2.42 against 1.93 ms
+      // in one 5.24 GB pass), so the workspace limit is the ceiling of a pass, not its size.
+      const size_t pass_cap = std::min(ws_budget(ctx), std::max<size_t>((size_t)4 << 30, 8 * group_bytes * (size_t)D));
+      long gc = (long)std::max<size_t>(1, std::min<size_t>((size_t)groups, pass_cap / group_bytes));
       gc = (groups + (groups + gc - 1) / gc - 1) / ((groups + gc - 1) / gc);       // equal passes instead of full ones and a sliver
       if ((rc = ensure(ctx, ctx->Y, group_bytes * gc)) != GACQ_OK) return rc;
       float2* Y = (float2*)ctx->Y.p;
@@ -1170,8 +1209,33 @@ __global__ void narrow_x_kernel(const double2* __restrict__ in, float2* __restri
   if (i < n) { const double2 v = in[i]; out[i] = make_float2((float)v.x, (float)v.y); }
 }
 
+static int search_batch_dev_once(gacq_sig* sig, XSrc xs, size_t nsamp, int nepoch, const int* items, int nitems,
+                                 const double* dopplers, int nd, const double* item_bias_hz, int blocks, void* d_out);
+
+// A search whose workspace could not be allocated (another context, a torch allocator or a co-resident rank took the memory the budget
+// was computed from) is run again in passes of half the size, down to 64 MiB: slower, never an error a caller has to handle by hand.
 static int search_batch_dev(gacq_sig* sig, XSrc xs, size_t nsamp, int nepoch, const int* items, int nitems,
                             const double* dopplers, int nd, const double* item_bias_hz, int blocks, void* d_out) {
+  for (;;) {
+    if (sig && sig->ctx) sig->ctx->alloc_failed = false;
+    const int rc = search_batch_dev_once(sig, xs, nsamp, nepoch, items, nitems, dopplers, nd, item_bias_hz, blocks, d_out);
+    if (rc == GACQ_OK || !sig || !sig->ctx || !sig->ctx->alloc_failed) return rc;
+    gacq_ctx* ctx = sig->ctx;
+    GACQ_DEVICE(ctx);
+    const size_t budget = ws_budget(ctx);
+    if (budget <= ((size_t)64 << 20)) return rc;
+    (void)hipDeviceSynchronize();
+    for (DevBuf* b : {&ctx->X, &ctx->Y}) {
+      if (b->p) (void)hipFree(b->p);
+      b->p = nullptr;
+      b->cap = 0;
+    }
+    ctx->ws_soft = budget / 2;
+  }
+}
+
+static int search_batch_dev_once(gacq_sig* sig, XSrc xs, size_t nsamp, int nepoch, const int* items, int nitems,
+                                 const double* dopplers, int nd, const double* item_bias_hz, int blocks, void* d_out) {
   int rc = check_search_args(sig, xs.p, nsamp, nepoch, items, nitems, dopplers, nd, blocks, d_out);
   if (rc != GACQ_OK) return rc;
   gacq_ctx* ctx = sig->ctx;
@@ -1203,8 +1267,8 @@ static int search_batch_dev(gacq_sig* sig, XSrc xs, size_t nsamp, int nepoch, co
   }
   const size_t bin_bytes = (ctx->engine == 5 ? sizeof(double2) : sizeof(float2)) * (size_t)F * blocks * sig->N;
   const bool no_x = lds_path(ctx, sig->N, nepoch, nitems, F, nd, blocks, false).no_forward_buffer();
-  if (!no_x && nd > 1 && bin_bytes * nd > ctx->ws_limit) {
-    const int Dc = (int)std::max<size_t>(1, ctx->ws_limit / bin_bytes);
+  if (!no_x && nd > 1 && bin_bytes * nd > ws_budget(ctx)) {
+    const int Dc = (int)std::max<size_t>(1, ws_budget(ctx) / bin_bytes);
     const int nch = (nd + Dc - 1) / Dc;
     const long n = (long)nepoch * nitems;
     if ((rc = ensure(ctx, ctx->chunk_peaks, sizeof(gacq_peak) * (size_t)nch * n)) != GACQ_OK) return rc;
@@ -1318,8 +1382,9 @@ static int tie_list_full_warning(gacq_ctx* ctx) {
   return GACQ_WARN_TIE_LIST_FULL;
 }
 
-int gacq_search(gacq_sig* sig, const float* x_iq, size_t nsamp, const int* items, int nitems, const double* dopplers,
-                int nd, const double* item_bias_hz, int blocks, gacq_result* out) {
+// One search from host memory, complex64 or (wide) complex128 samples: the body of gacq_search / gacq_search64
+static int search_host(gacq_sig* sig, const void* x_iq, bool wide, size_t nsamp, const int* items, int nitems, const double* dopplers,
+                       int nd, const double* item_bias_hz, int blocks, gacq_result* out) {
   int rc = check_search_args(sig, x_iq, nsamp, 1, items, nitems, dopplers, nd, blocks, out);
   if (rc != GACQ_OK) return rc;
   gacq_ctx* ctx = sig->ctx;
@@ -1332,8 +1397,8 @@ int gacq_search(gacq_sig* sig, const float* x_iq, size_t nsamp, const int* items
   GACQ_DEVICE(ctx);
   const size_t need = (size_t)(blocks + (sig->desc.pad ? 1 : 0)) * sig->desc.n;      // <= nsamp (check_search_args)
   const size_t take = need;
-  if ((rc = ensure_pinned(ctx, ctx->pin_peaks, sizeof(gacq_peak) * nitems)) != GACQ_OK) return rc;
-  const size_t xbytes = sizeof(float2) * need;
+  if ((rc = ensure_pinned(ctx, ctx->pin_peaks, sizeof(gacq_peak) * std::max(1, nitems))) != GACQ_OK) return rc;
+  const size_t xbytes = (wide ? sizeof(double2) : sizeof(float2)) * need;
   const void* d_x = nullptr;
   // Small inputs (a 1 ms GPS L1 block is 32 KB): written by the host straight into fine-grained device memory through the PCIe BAR
   // (a 32 KB pinned H2D costs ~7 us of latency in front of the kernels).  This call is synchronous, so the buffer is never
@@ -1342,7 +1407,7 @@ int gacq_search(gacq_sig* sig, const float* x_iq, size_t nsamp, const int* items
   if (!d_x) {
     // Staged path: small inputs go through a pinned staging buffer (one host memcpy, then a true async DMA); a pageable
     // hipMemcpyAsync stages internally and costs ~10 us more per call.  Large inputs are copied directly.
-    if ((rc = ensure(ctx, ctx->xstage, sizeof(float2) * take)) != GACQ_OK) return rc;
+    if ((rc = ensure(ctx, ctx->xstage, xbytes)) != GACQ_OK) return rc;
     const void* src = x_iq;
     if (xbytes <= kPinnedStageMax) {
       if ((rc = ensure_pinned(ctx, ctx->pin_x, xbytes)) != GACQ_OK) return rc;
@@ -1362,7 +1427,7 @@ int gacq_search(gacq_sig* sig, const float* x_iq, size_t nsamp, const int* items
   constexpr unsigned long long kSentinelBits = 0x7ff8dead0badbeefULL;      // a NaN payload no search produces
   if (watch)
     for (int p = 0; p < nitems; p++) { std::memcpy(&pk[p].metric, &kSentinelBits, 8); pk[p].idx = -2; pk[p].d_index = -2; }
-  rc = gacq_search_batch_dev(sig, d_x, take, 1, items, nitems, dopplers, nd, item_bias_hz, blocks, ctx->pin_peaks.p);
+  rc = search_batch_dev(sig, XSrc{d_x, wide ? 1 : 0}, take, 1, items, nitems, dopplers, nd, item_bias_hz, blocks, ctx->pin_peaks.p);
   if (rc != GACQ_OK) return rc;
   bool complete = false;
   if (watch) {
@@ -1383,25 +1448,16 @@ int gacq_search(gacq_sig* sig, const float* x_iq, size_t nsamp, const int* items
   return rc != GACQ_OK ? rc : tie_list_full_warning(ctx);
 }
 
+int gacq_search(gacq_sig* sig, const float* x_iq, size_t nsamp, const int* items, int nitems, const double* dopplers,
+                int nd, const double* item_bias_hz, int blocks, gacq_result* out) {
+  return search_host(sig, x_iq, false, nsamp, items, nitems, dopplers, nd, item_bias_hz, blocks, out);
+}
+
+// complex128 samples as the reference's search() receives them (np.interp output, acquire-gps-l1.py:94-96): the same call path as
+// gacq_search -- BAR upload of small inputs (a 1 ms GPS L1 block is 64 KB here), pinned staging, completion by watching the records
 int gacq_search64(gacq_sig* sig, const double* x_iq, size_t nsamp, const int* items, int nitems, const double* dopplers,
                   int nd, const double* item_bias_hz, int blocks, gacq_result* out) {
-  int rc = check_search_args(sig, x_iq, nsamp, 1, items, nitems, dopplers, nd, blocks, out);
-  if (rc != GACQ_OK) return rc;
-  gacq_ctx* ctx = sig->ctx;
-  if (nd == 0 || blocks == 0) {      // as gacq_search: the reference never looks at x here (acquire-gps-l1.py:25,40)
-    for (int p = 0; p < nitems; p++) { out[p].metric = 0.0; out[p].code_chips = 0.0; out[p].doppler_hz = 0.0; out[p].idx = -1; out[p].d_index = -1; }
-    return GACQ_OK;
-  }
-  GACQ_DEVICE(ctx);
-  const size_t need = (size_t)(blocks + (sig->desc.pad ? 1 : 0)) * sig->desc.n;      // <= nsamp (check_search_args)
-  if ((rc = ensure_pinned(ctx, ctx->pin_peaks, sizeof(gacq_peak) * nitems)) != GACQ_OK) return rc;
-  if ((rc = ensure(ctx, ctx->xstage, sizeof(double2) * need)) != GACQ_OK) return rc;
-  GACQ_HIP(ctx, hipMemcpyAsync(ctx->xstage.p, x_iq, sizeof(double2) * need, hipMemcpyHostToDevice, ctx->stream));
-  rc = gacq_search_batch_dev64(sig, ctx->xstage.p, need, 1, items, nitems, dopplers, nd, item_bias_hz, blocks, ctx->pin_peaks.p);
-  if (rc != GACQ_OK) return rc;
-  GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  rc = gacq_finalize(&sig->desc, (const gacq_peak*)ctx->pin_peaks.p, 1, nullptr, nitems, dopplers, nd, out);
-  return rc != GACQ_OK ? rc : tie_list_full_warning(ctx);
+  return search_host(sig, x_iq, true, nsamp, items, nitems, dopplers, nd, item_bias_hz, blocks, out);
 }
 
 // The whole main program of an acquire script in one call, from host memory, without a device-memory framework on the caller's side:

@@ -14,18 +14,19 @@
 //   N y[t + 512 j] in register j of thread t.  Spectra (X, C_p) live in memory in the order the forward transform produces them
 //   ("physical lane-pair layout": element (t', r) at (r >> 1) * 1024 + 2 t' + (r & 1)): 16-byte accesses, 1 KiB per wave and
 //   instruction, no reordering pass anywhere.
-// Why this shape, and what it measured (round 6, profiles/r06_16k_radix32_*): the radix-16 form (gacq_ldsfft.hip: 1024 threads x 16
-// points, 16 x 16 x 16 x 4, three exchanges) fills 16 waves x 128 registers with the code spectrum (32), the row (32) and the
-// accumulators (16), so its three sets of inter-pass twiddle powers are REBUILT per row (42 of a row's 237 complex products) and every
-// cheaper source (LDS or memory tables) cost more than it saved.  Eight waves x 256 registers hold the same row state (64 + 64 + 32)
-// plus half of the big twiddle set (table A, 32); the second set is small enough for LDS (table B, 4 KB, 16 distinct addresses per
-// read); one exchange and one twiddle set are gone with the fourth pass: 13 % fewer VALU instructions per row (SQ_INSTS_VALU 9.75e8
-// against 1.117e9 per B1I launch) and 2/3 of the LDS store traffic.  It runs the B1I / GLONASS searches of BASELINE config 5 in the
-// SAME time as the radix-16 form (3.00-3.05 / 1.63-1.68 ms against 2.99-3.05 / 1.64-1.69 ms, alternating in one process): with two
-// waves per SIMD instead of four the LDS round trips and the two workgroup barriers of a row are covered less (VALU pipes 61 % busy
-// against 77 %), which gives back what the shorter instruction stream saves.  Selected by GACQ_OPT_LDS_VARIANT = 32; the radix-16 form
-// stays the default.  tools/model_fft16k_r32.py checks the index algebra against numpy.fft and every access pattern for bank
-// conflicts (none; SQ_LDS_BANK_CONFLICT = 0 measured).
+// Why this shape, and what it measured (round 6, profiles/r06_16k_radix32_experiments.log): the radix-16 form (gacq_ldsfft.hip: 1024
+// threads x 16 points, 16 x 16 x 16 x 4, three exchanges) fills 16 waves x 128 registers with the code spectrum (32), the row (32) and
+// the accumulators (16), so its three sets of inter-pass twiddle powers are REBUILT per row (42 of a row's 237 complex products) and
+// every cheaper source (LDS or memory tables) cost more than it saved.  Eight waves x 256 registers hold the same row state
+// (64 + 64 + 32) plus half of the big twiddle set (table A, 32); the second set is small enough for LDS (table B, 4 KB, 16 distinct
+// addresses per read); one exchange and one twiddle set are gone with the fourth pass: 13 % fewer VALU instructions per row
+// (SQ_INSTS_VALU 9.75e8 against 1.117e9 per B1I launch) and 2/3 of the LDS store traffic.  What that buys is small -- config 5's B1I /
+// GLONASS searches 0-5 % / 0-2.5 % faster than the radix-16 form, alternating in one process on four boxes -- because with two waves per
+// SIMD instead of four the LDS round trips and the two workgroup barriers of a row are covered less (VALU pipes 61 % busy against 77 %):
+// one row in flight per CU is what the register file allows either way (row + code spectrum + accumulators = 320 KB of its 512), and
+// that, not the instruction count, is what paces a row.  The default since round 6; GACQ_OPT_LDS_VARIANT = 16 selects the radix-16
+// form.  tools/model_fft16k_r32.py checks the index algebra against numpy.fft and every access pattern for bank conflicts (none;
+// SQ_LDS_BANK_CONFLICT = 0 measured).
 #include "gacq_common.h"
 #include "gacq_cplx.h"
 #include "gacq_ldsutil.h"

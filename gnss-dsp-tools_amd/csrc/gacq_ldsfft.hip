@@ -1083,9 +1083,9 @@ namespace gacq {
 
 bool lds_supported(int N) { return N == kLdsN || N == kBig; }
 
-// N = 16384: the radix-16 form of this file unless GACQ_OPT_LDS_VARIANT = 32 selects the radix-32 form of gacq_lds16k.hip (same time,
-// fewer instructions, fewer waves: the in-run A/B of bench.py)
-static bool radix16_16k(const gacq_ctx* ctx) { return ctx->opt[GACQ_OPT_LDS_VARIANT] != 32; }
+// N = 16384: the radix-32 form of gacq_lds16k.hip unless GACQ_OPT_LDS_VARIANT = 16 selects the radix-16 form of this file (0-5 % slower
+// in the same process on every box measured, never faster: the in-run A/B of bench.py, roofline.ab.n16384_transform)
+static bool radix16_16k(const gacq_ctx* ctx) { return ctx->opt[GACQ_OPT_LDS_VARIANT] == 16; }
 
 #ifdef GACQ_PHASE_TIMING16
 extern "C" int gacq_debug_phase16(unsigned long long* out128, int reset) {
@@ -1099,9 +1099,9 @@ extern "C" int gacq_debug_phase16(unsigned long long* out128, int reset) {
 #endif
 
 // code spectra straight from the (complex, zero-extended) replica rows with the engine's own forward transform: no rocFFT plan
-int lds_code_spectra(gacq_ctx* ctx, const float2* replica_rows, float2* perm, int nprn, int N, bool radix32) {
+int lds_code_spectra(gacq_ctx* ctx, const float2* replica_rows, float2* perm, int nprn, int N, bool radix16) {
   if (!lds_supported(N)) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "LDS FFT engine: N=%d not supported", N);
-  if (N == kBig && radix32) return r32_code_spectra(ctx, replica_rows, perm, nprn);
+  if (N == kBig && !radix16) return r32_code_spectra(ctx, replica_rows, perm, nprn);
   if (N == kBig) {
     const float2* twn;
     int rcb = twiddle_cache(ctx, "W16384_lo", kBig, 1024, &twn);

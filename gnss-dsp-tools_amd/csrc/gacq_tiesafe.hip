@@ -569,7 +569,7 @@ int tie_code_spectra64(gacq_ctx* ctx, double2* rows, int nrows, int N) {
 // 768 MiB, beyond that the sequential forms (a few rows of scratch).
 size_t tie_budget(const gacq_ctx* ctx) {
   if (ctx->opt[GACQ_OPT_TIE_CAP] > 0) return (size_t)768 << 20;
-  return std::min<size_t>((size_t)256 << 20, std::max<size_t>((size_t)32 << 20, ctx->ws_limit / 8));
+  return std::min<size_t>((size_t)256 << 20, std::max<size_t>((size_t)32 << 20, std::min(ctx->ws_limit, ctx->ws_soft ? ctx->ws_soft : ctx->ws_limit) / 8));
 }
 
 int tie_capacity(const gacq_ctx* ctx, long nep, int N, int B) {

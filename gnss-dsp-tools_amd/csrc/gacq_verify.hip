@@ -256,14 +256,24 @@ int verify_spectra(gacq_sig* s) {
   std::vector<double2> host(count, make_double2(0.0, 0.0));
   for (int p = 0; p < s->nprn; p++)
     for (int i = 0; i < s->desc.n; i++) host[(size_t)p * s->N + i].x = (double)s->replica[(size_t)p * s->desc.n + i];
-  GACQ_HIP(ctx, hipMalloc((void**)&s->spectra64, sizeof(double2) * count));
-  GACQ_HIP(ctx, hipMemcpyAsync(s->spectra64, host.data(), sizeof(double2) * count, hipMemcpyHostToDevice, ctx->stream));
+  // built in a local buffer and published only once the transform has run: a failure (the transform's scratch, a rocFFT plan) must not
+  // leave untransformed replicas behind for the next call to take for code spectra
+  double2* buf = nullptr;
+  GACQ_HIP(ctx, hipMalloc((void**)&buf, sizeof(double2) * count));
+  int rc = GACQ_OK;
+  if (hipMemcpyAsync(buf, host.data(), sizeof(double2) * count, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+    rc = set_error(ctx, GACQ_ERR_HIP, "complex128 code spectra: upload of the replicas failed");
   // c = fft.fft(c)   acquire-gps-l1.py:24 -- with the library's own complex128 transform where it factors the length (every length of the
   // reference's scripts), so that the default path never pays for a rocFFT plan; rocFFT's double-precision transform otherwise
-  int rc = tie_code_spectra64(ctx, s->spectra64, s->nprn, s->N);
-  if (rc == GACQ_ERR_UNSUPPORTED) rc = fft_exec(ctx, s->N, s->nprn, false, s->spectra64, true);
-  if (rc != GACQ_OK) return rc;
-  GACQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (rc == GACQ_OK) rc = tie_code_spectra64(ctx, buf, s->nprn, s->N);
+  if (rc == GACQ_ERR_UNSUPPORTED) rc = fft_exec(ctx, s->N, s->nprn, false, buf, true);
+  if (rc == GACQ_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_error(ctx, GACQ_ERR_HIP, "complex128 code spectrum transform failed");
+  if (rc != GACQ_OK) {
+    (void)hipStreamSynchronize(ctx->stream);      // `host` is still being read by the copy
+    (void)hipFree(buf);
+    return rc;
+  }
+  s->spectra64 = buf;
   return GACQ_OK;
 }
 
@@ -301,7 +311,7 @@ int verify_search(gacq_sig* sig, XSrc d_x, size_t nsamp, int nepoch, int P, int 
     return GACQ_OK;
   }
   const size_t x_epoch_bytes = sizeof(double2) * (size_t)F * D * B * N;
-  const int Ec = (int)std::max<size_t>(1, std::min<size_t>((size_t)nepoch, ctx->ws_limit / std::max<size_t>(1, x_epoch_bytes)));
+  const int Ec = (int)std::max<size_t>(1, std::min<size_t>((size_t)nepoch, ws_budget(ctx) / std::max<size_t>(1, x_epoch_bytes)));
   if ((rc = ensure(ctx, ctx->X, x_epoch_bytes * Ec)) != GACQ_OK) return rc;
   if ((rc = ensure(ctx, ctx->rows, sizeof(RowRec64) * (size_t)Ec * P * D)) != GACQ_OK) return rc;
   const unsigned cols = (unsigned)((N + kBlock - 1) / kBlock);
@@ -317,7 +327,7 @@ int verify_search(gacq_sig* sig, XSrc d_x, size_t nsamp, int nepoch, int P, int 
     if ((rc = fft_exec(ctx, N, rows_x, false, X, true)) != GACQ_OK) return rc;
     const long groups = (long)ne * P * D;
     const size_t group_bytes = sizeof(double2) * (size_t)B * N;
-    long gc = (long)std::max<size_t>(1, std::min<size_t>((size_t)groups, ctx->ws_limit / group_bytes));
+    long gc = (long)std::max<size_t>(1, std::min<size_t>((size_t)groups, ws_budget(ctx) / group_bytes));
     gc = std::min<long>(gc, std::max<long>(1, ((1L << 31) - 1) / ((long)B * cols)));
     if ((rc = ensure(ctx, ctx->Y, group_bytes * gc)) != GACQ_OK) return rc;
     double2* Y = (double2*)ctx->Y.p;

@@ -107,9 +107,15 @@ int gacq_use_null_stream(gacq_ctx* ctx);
  *     runs as ONE fused kernel (fp64 transform resident in LDS, GACQ_OPT_FUSED_C128); every other shape as the five-stage pipeline
  *     on rocFFT's double-precision transforms.  Never chosen by auto. */
 int gacq_set_engine(gacq_ctx* ctx, int engine);
-/* Upper bound for the library-owned correlation workspace in bytes (default 32 GiB of the part's 288 GB; allocated as searches need
- * it).  A search whose forward spectra for one epoch exceed it is cut into Doppler slices that fit; the slices are merged in grid order with strict '>'
- * (acquire-gps-l1.py:36-39), so the result is the one of a single scan. */
+/* Upper bound in bytes for EACH of the two library-owned work buffers of a context -- the forward spectra and the correlation workspace;
+ * both are allocated as searches need them, with 1/8 of headroom, and kept, so a context can hold about 2.25 x this (default 32 GiB
+ * of the part's 288 GB).  A search whose forward spectra for one epoch exceed it is cut into Doppler slices that fit; the slices are
+ * merged in grid order with strict '>' (acquire-gps-l1.py:36-39), so the result is the one of a single scan.  Until this is called the
+ * library also keeps each buffer within the context's share of the device's FREE memory (80 % of it, split over the contexts alive on
+ * the device and their two buffers each), so that several contexts, ranks or a torch allocator sharing a device cannot over-commit it;
+ * a limit set here is taken as given.  Either way a search whose workspace cannot be allocated is re-run in passes of half the size
+ * (down to 64 MiB) before an error is returned.  One pass of the split engines' correlation workspace is at most 4 GiB or eight
+ * items' worth, whichever is more: the limit is the ceiling of a pass, not its size. */
 int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes);
 /* Tuning switches of the launch path.  They are ctx state set through this call; nothing in the library reads the
  * environment.  Defaults in brackets. */
@@ -117,10 +123,10 @@ int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes);
                                 /*     in-place inner inverse transforms; gacq_pfa.hip); 0 = Cooley-Tukey form with rocFFT inner transforms    */
                                 /*     (other arithmetic: the cross-check)                                                                     */
 #define GACQ_OPT_FUSED_16K 1    /* [1] N = 16384 with one carrier per item: forward + correlate in one kernel           */
-#define GACQ_OPT_LDS_VARIANT 2  /* [-1] N = 16384: 32 = the radix-32 form of the one-workgroup transform (512 threads x 32 points, two       */
-                                /*     exchanges; gacq_lds16k.hip) instead of the radix-16 form (1024 x 16, three exchanges).  Same results to */
-                                /*     fp32 rounding, same time, 13 % fewer VALU instructions at half the waves (the in-run A/B of bench.py);  */
-                                /*     every other value: radix-16 form                                                                        */
+#define GACQ_OPT_LDS_VARIANT 2  /* [-1] N = 16384: 16 = the radix-16 form of the one-workgroup transform (1024 threads x 16 points, three     */
+                                /*     exchanges; gacq_ldsfft.hip) instead of the radix-32 form (512 x 32, two exchanges; gacq_lds16k.hip).    */
+                                /*     Same results to fp32 rounding; the radix-32 form issues 13 % fewer VALU instructions at half the waves  */
+                                /*     and measures 0-5 % faster (the in-run A/B of bench.py); every other value: radix-32 form                */
 #define GACQ_OPT_LDS_PCH 3      /* [0 = auto] items per workgroup of the LDS correlate kernels                          */
 #define GACQ_OPT_SPLIT_PCH 4    /* [0 = auto] (epoch, item) rows per workgroup of the split engines' inner kernels      */
 #define GACQ_OPT_SPLIT_TEAMS 5  /* retired (round 5): belonged to the Stockham inner kernel the prime-factor engine replaced; accepted, ignored */

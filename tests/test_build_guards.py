@@ -48,10 +48,15 @@ def test_kernels_with_lds_separators_use_no_accumulator_registers_and_hot_kernel
     assert len(kernels) > 40, sorted(kernels)
     with_agprs = sorted(k for k, m in kernels.items() if m["agpr_count"])
     assert with_agprs and all("tie_recheck" in k for k in with_agprs), with_agprs
-    for fragment in ("lds_fused4k_kernelILi4ELb1ELb0", "lds16k_correlate_kernelILb0", "fused4k_c128_kernel", "lds_inner_correlate_kernel",
+    for fragment in ("lds_fused4k_kernelILi4ELb1ELb0", "lds16k_correlate_kernelILb0", "r32_correlate_kernelILb0", "r32_fused_kernelILb0", "fused4k_c128_kernel", "lds_inner_correlate_kernel",
                      "lds_correlate_kernelILi2E", "pfa_inner_corr_kernelILi1980ELi3E", "pfa_inner_corr_kernelILi990ELi2E",
                      "pfa_outer_inverse_kernelILi1980ELi0E", "pfa_outer_inverse_kernelILi990ELi2E", "pfa_outer_inverse_mfma_kernelILi1980ELi0E"):
         hit = [k for k in kernels if fragment in k]
         assert hit, fragment
         for k in hit:
+            if fragment.startswith("r32_correlate_kernel"):
+                # 256 registers: the record pointer (two dwords) is stored before the item loop and reloaded in the per-unit tail; nothing
+                # is spilled inside the row loop (checked in the ISA: both reloads sit at loop depth 2, once per B rows)
+                assert kernels[k]["private_segment_fixed_size"] <= 16 and kernels[k]["vgpr_spill_count"] <= 2, (k, kernels[k])
+                continue
             assert kernels[k]["private_segment_fixed_size"] == 0 and kernels[k]["vgpr_spill_count"] == 0, (k, kernels[k])

@@ -35,7 +35,7 @@ def test_oracle_integer_work_against_reference_goldens_on_the_gpu_box(name, requ
 
 def test_lds_kernel_rows_match_reference_rows(engine, golden_cases, golden_rows):
     """gacq_debug_row with engine 2 runs the LDS-resident kernels themselves (lds_forward_kernel + lds_correlate_kernel for N = 4096,
-    lds16k_forward_kernel + lds16k_correlate_kernel for N = 16384; no silent switch to the rocFFT pipeline any more): every lag of the
+    r32_forward_kernel + r32_correlate_kernel for N = 16384; no silent switch to the rocFFT pipeline any more): every lag of the
     accumulated magnitude row q against the reference's own row, not just (max, argmax, sum)."""
     from gnss_dsp_tools_amd import signals
     engine.set_engine(2)

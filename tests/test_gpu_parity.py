@@ -165,7 +165,7 @@ def test_batched_device_path_equals_single_searches(engine):
         engine.set_engine(0)
 
 
-@pytest.mark.parametrize("variant", [-1, 32], ids=["radix16", "radix32"])
+@pytest.mark.parametrize("variant", [16, -1], ids=["radix16", "radix32"])
 def test_glonass_fused_16k_kernel_equals_two_kernel_path(engine, variant):
     """One carrier per item (FDMA channels): forward + correlate run in one kernel without the X buffer.  Same arithmetic
     in the same order, so the peak records must be bit-identical to the forward-kernel + correlate-kernel path -- in both forms of the
@@ -772,11 +772,11 @@ SPLIT_LDS_CASES = ["cfg3_e1b_subset", "cfg3_e1c_subset", "e1b_ms12", "cfg5_b1i_m
 LDS16K_CASES = ["cfg5_b1i_ms10", "b2i_ms2", "cfg5_glonass_l1", "glonass_l2"]
 
 
-@pytest.mark.parametrize("variant", [-1, 32], ids=["radix16", "radix32"])
+@pytest.mark.parametrize("variant", [16, -1], ids=["radix16", "radix32"])
 @pytest.mark.parametrize("cid", LDS16K_CASES)
 def test_single_workgroup_16384_engine_matches_reference_golden(engine, golden_cases, cid, variant):
-    """N = 16384 through engine 2: the whole transform in one workgroup -- 1024 threads x 16 points (16 x 16 x 16 x 4, the default) or
-    512 threads x 32 points (32 x 32 x 16, option lds_variant = 32: gacq_lds16k.hip)."""
+    """N = 16384 through engine 2: the whole transform in one workgroup -- 512 threads x 32 points (32 x 32 x 16, gacq_lds16k.hip, the
+    default) or 1024 threads x 16 points (16 x 16 x 16 x 4, option lds_variant = 16)."""
     case = golden_cases[cid]
     x = case_iq(case)
     engine.set_engine(2)
@@ -798,7 +798,7 @@ def test_radix32_16384_rows_match_the_radix16_rows(engine):
         B = 3
         x = synth.make_iq(sig, B, 5, synth.default_sats([item]))
         rows = {}
-        for variant in (-1, 32):
+        for variant in (16, -1):
             engine.set_engine(2)
             engine.set_option("lds_variant", variant)
             try:
@@ -806,7 +806,7 @@ def test_radix32_16384_rows_match_the_radix16_rows(engine):
             finally:
                 engine.set_option("lds_variant", -1)
                 engine.set_engine(0)
-        a, b = rows[-1], rows[32]
+        a, b = rows[16], rows[-1]
         assert int(np.argmax(a)) == int(np.argmax(b))
         assert np.abs(a - b).max() <= 2e-6 * np.abs(a).max(), (name, np.abs(a - b).max(), np.abs(a).max())
 
@@ -1129,8 +1129,8 @@ def test_device_nco_indices_are_bit_exact(engine, golden_nco):
         sig = signals.get(script)
         s = engine.signal(sig, [0] if sig.bias_hz else [1])
         for k in kernels:
-            # the LDS forward (2) and fused (4) kernels of N = 16384 exist in two forms: radix-16 (default) and radix-32 (lds_variant = 32)
-            for variant in ((-1, 32) if v["n"] == 16384 and k in (2, 4) else (-1,)):
+            # the LDS forward (2) and fused (4) kernels of N = 16384 exist in two forms: radix-32 (default) and radix-16 (lds_variant = 16)
+            for variant in ((-1, 16) if v["n"] == 16384 and k in (2, 4) else (-1,)):
                 engine.set_option("lds_variant", variant)
                 try:
                     idx = s.nco_indices(k, v["doppler"], v.get("bias", 0.0))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where the waves of the N = 16384 correlate kernel spend their cycles (diagnostic): needs a variant built with -DGACQ_PHASE_TIMING16,
    tools/build_variant.sh timing16 -DGACQ_PHASE_TIMING16 gacq_lds16k.hip ; python tools/variant.py timing16 tools/phase_timing16.py
-(radix-32 form, with lds_variant=32 on the command line; the radix-16 form: build gacq_ldsfft.hip with the flag instead)
+(radix-32 form; the radix-16 form: build gacq_ldsfft.hip with the flag instead and pass lds_variant=16)
 Prints shader-clock cycles per row, wave and phase (lane 0 of every wave, summed over all workgroups)."""
 import ctypes
 import os
@@ -30,7 +30,7 @@ def main():
     for kv in sys.argv[1:]:
         k, v = kv.split("=")
         eng.set_option(k, int(v))
-    PHASES = PHASES32 if eng.get_option("lds_variant") == 32 else PHASES16
+    PHASES = PHASES16 if eng.get_option("lds_variant") == 16 else PHASES32
     sig = signals.get("beidou-b1i")
     items = list(range(1, 64))
     dop = acquire.doppler_grid([-10000.0, 10000.0, 100.0])
