@@ -79,7 +79,7 @@ struct gacq_ctx {
   int ws_soft_nctx = 0;                    // contexts on the device when ws_soft was computed
   bool alloc_failed = false;               // ensure() could not get its bytes: the search is retried in smaller passes
   std::map<std::pair<long, long>, gacq::FftPlan> plans;   // (N * 2 + inverse, batch)
-  gacq::DevBuf tab, xstage, x32, X, Y, rows, freq, fset, items, out_peaks, d0, partial, fe_a, fe_b, fe_taps, chunk_peaks, arrivals;
+  gacq::DevBuf tab, xstage, x32, X, Y, rows, freq, fset, items, out_peaks, d0, partial, fe_a, fe_b, fe_taps, chunk_peaks;
   gacq::DevBuf tie, tie_scratch, tie_q, tie_split, tie_done2;   // tie-safe re-evaluation: counters + lists, complex128 row scratch, per-block magnitude rows
   int tie_cap = 0;                     // list capacity the `tie` buffer was laid out for
   long opt[GACQ_NOPTS] = {1, 1, -1, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 1, 8000, 0, 1, 0};   // gacq_set_option values (defaults documented in include/gacq.h)
@@ -182,13 +182,8 @@ int lds_fused_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, i
                      const int* d_fset, const double* d_freq, const float2* tab, int nitems, int D, int B, RowRec* rows, float tie_scale);
 // N = 4096, B == 1, one carrier: forward + correlate in one kernel, no X buffer
 bool lds_fused4k_supported(const gacq_ctx* ctx, int N, int B, int F, long units);
-// arrivals != nullptr: single-launch search -- the Doppler scan runs inside the kernel (last workgroup of every item) and the peak
-// records go to `peaks`; arrivals = nepoch * nitems zeroed counters, left zeroed
 int lds_fused4k_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, const float2* spectra, const int* d_items,
-                       const double* d_freq, const float2* tab, int nitems, int D, RowRec* rows, float tie_scale, unsigned* arrivals = nullptr,
-                       gacq_peak* peaks = nullptr, int normalised = 0);
-// the single-launch form pays for small batches only (every workgroup resident at once)
-bool lds_search1_supported(const gacq_ctx* ctx, int N, int B, int F, long units, int nitems);
+                       const double* d_freq, const float2* tab, int nitems, int D, RowRec* rows, float tie_scale);
 int lds_correlate(gacq_ctx* ctx, const float2* X, const float2* spectra, const int* d_items, const int* d_fset,
                   int nepoch, int nitems, int F, int D, int B, int N, RowRec* rows, float tie_scale, float* q_out = nullptr);
 

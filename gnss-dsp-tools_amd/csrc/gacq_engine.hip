@@ -555,7 +555,7 @@ void gacq_destroy(gacq_ctx* ctx) {
     if (kv.second.work) (void)hipFree(kv.second.work);
   }
   for (auto& ev : ctx->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-  DevBuf* bufs[] = {&ctx->tab, &ctx->xstage, &ctx->x32, &ctx->X, &ctx->Y, &ctx->rows, &ctx->freq, &ctx->fset, &ctx->items, &ctx->out_peaks, &ctx->d0, &ctx->partial, &ctx->fe_a, &ctx->fe_b, &ctx->fe_taps, &ctx->chunk_peaks, &ctx->arrivals, &ctx->tie, &ctx->tie_scratch, &ctx->tie_q, &ctx->tie_split, &ctx->tie_done2, &ctx->acq_in, &ctx->acq_x};
+  DevBuf* bufs[] = {&ctx->tab, &ctx->xstage, &ctx->x32, &ctx->X, &ctx->Y, &ctx->rows, &ctx->freq, &ctx->fset, &ctx->items, &ctx->out_peaks, &ctx->d0, &ctx->partial, &ctx->fe_a, &ctx->fe_b, &ctx->fe_taps, &ctx->chunk_peaks, &ctx->tie, &ctx->tie_scratch, &ctx->tie_q, &ctx->tie_split, &ctx->tie_done2, &ctx->acq_in, &ctx->acq_x};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   if (ctx->pin_x.p) (void)hipHostFree(ctx->pin_x.p);
   if (ctx->pin_peaks.p) (void)hipHostFree(ctx->pin_peaks.p);
@@ -852,8 +852,7 @@ Grid make_grid(const gacq_sigdesc& d, int nitems, const double* dopplers, int nd
 struct LdsPath {
   bool use_lds = false;      // whole transform in one workgroup (engine 2, or auto where the length is supported)
   bool fused16k = false;     // N = 16384, one carrier per item: forward + correlate in one kernel
-  bool search1 = false;      // N = 4096, small batch: the whole search, Doppler scan included, in one launch
-  bool fused4k = false;      // N = 4096, B = 1, one carrier: forward + correlate in one kernel (search1 implies it)
+  bool fused4k = false;      // N = 4096, B = 1, one carrier: forward + correlate in one kernel
   bool no_forward_buffer() const { return fused16k || fused4k; }
 };
 LdsPath lds_path(const gacq_ctx* ctx, int N, int nepoch, int P, int F, int D, int B, bool row_dump) {
@@ -861,8 +860,7 @@ LdsPath lds_path(const gacq_ctx* ctx, int N, int nepoch, int P, int F, int D, in
   p.use_lds = (ctx->engine == 2) || (ctx->engine == 0 && lds_supported(N) && !row_dump);
   if (!p.use_lds || !lds_supported(N) || row_dump) return p;      // a row dump (engine 2) goes through the two-kernel path
   p.fused16k = lds_fused_supported(ctx, N, P, F);
-  p.search1 = !p.fused16k && lds_search1_supported(ctx, N, B, F, (long)nepoch * D, P);      // only with GACQ_OPT_TIE_SAFE off
-  p.fused4k = p.search1 || (!p.fused16k && lds_fused4k_supported(ctx, N, B, F, (long)nepoch * D));
+  p.fused4k = !p.fused16k && lds_fused4k_supported(ctx, N, B, F, (long)nepoch * D);
   return p;
 }
 
@@ -959,7 +957,7 @@ int launch_search(gacq_sig* sig, XSrc xs, const float2* d_x, size_t nsamp, int n
 
   // tie-safe locations: the reducers tag rows whose runner-up lag is within eps of the maximum, best_doppler_kernel lists the
   // (epoch, item) pairs it cannot decide and gacq_tiesafe.hip re-evaluates their candidate rows in complex128
-  const bool tie = ctx->opt[GACQ_OPT_TIE_SAFE] != 0 && !d_qrow && !path.search1 && tie_supported(N);
+  const bool tie = ctx->opt[GACQ_OPT_TIE_SAFE] != 0 && !d_qrow && tie_supported(N);
   const float tscale = tie ? tie_scale_of(ctx) : 1.0f;      // 1: only exact fp32 duplicates get tagged, and nobody looks
   TieLists tl{};
   gacq_peak* guesses = nullptr;
@@ -972,14 +970,8 @@ int launch_search(gacq_sig* sig, XSrc xs, const float2* d_x, size_t nsamp, int n
   const bool fused16k = path.fused16k;      // one carrier per item: no forward-spectra buffer at all
   const size_t x_epoch_bytes = sizeof(float2) * (size_t)F * D * B * N;
   int Ec = (int)std::max<size_t>(1, std::min<size_t>((size_t)nepoch, ws_budget(ctx) / std::max<size_t>(1, x_epoch_bytes)));
-  const bool search1 = path.search1, fused4k = path.fused4k;
+  const bool fused4k = path.fused4k;
   if (fused16k || fused4k) Ec = nepoch;            // nothing but the 16-byte row records is buffered
-  if (search1) {
-    // the kernel leaves its arrival counters zeroed -- unless a launch faulted or was aborted, and a grown buffer may come back at the
-    // old address with an unwritten tail: zeroed per launch (a 4-byte-per-item memset), never trusted
-    if ((rc = ensure(ctx, ctx->arrivals, sizeof(unsigned) * (size_t)nepoch * P)) != GACQ_OK) return rc;
-    GACQ_HIP(ctx, hipMemsetAsync(ctx->arrivals.p, 0, sizeof(unsigned) * (size_t)nepoch * P, st));
-  }
   if (!fused16k && !fused4k && (rc = ensure(ctx, ctx->X, x_epoch_bytes * Ec)) != GACQ_OK) return rc;
   if ((rc = ensure(ctx, ctx->rows, sizeof(RowRec) * (size_t)Ec * P * D)) != GACQ_OK) return rc;
 
@@ -1000,10 +992,9 @@ int launch_search(gacq_sig* sig, XSrc xs, const float2* d_x, size_t nsamp, int n
     } else if (fused4k) {
       stage_begin(ctx, 6);
       rc = lds_fused4k_search(ctx, xe, nsamp, ne, sig->spectra_lds, (const int*)ctx->items.p, (const double*)ctx->freq.p, (const float2*)ctx->tab.p, P, D, rows,
-                              tscale, search1 ? (unsigned*)ctx->arrivals.p : nullptr, search1 ? d_out + (size_t)e0 * P : nullptr, ds.metric_mode);
+                              tscale);
       stage_end(ctx);
       if (rc != GACQ_OK) return rc;
-      if (search1) continue;                       // the Doppler scan ran inside the kernel
     } else if (use_lds) {
       stage_begin(ctx, 0);
       rc = lds_forward(ctx, xe, nsamp, ne, n, N, (const double*)ctx->freq.p, F * D, B, (const float2*)ctx->tab.p, X);

@@ -29,6 +29,7 @@ struct Rccl {
   void* lib = nullptr;
   int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
   int (*CommDestroy)(void* comm) = nullptr;
+  int (*CommAbort)(void* comm) = nullptr;      // optional: tears a communicator down with collectives still queued (error paths)
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   int (*AllGather)(const void* sendbuff, void* recvbuff, size_t sendcount, int datatype, void* comm, hipStream_t stream) = nullptr;
@@ -45,6 +46,7 @@ Rccl* rccl_load() {
   if (!r.lib) return nullptr;
   r.CommInitAll = (decltype(r.CommInitAll))dlsym(r.lib, "ncclCommInitAll");
   r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+  r.CommAbort = (decltype(r.CommAbort))dlsym(r.lib, "ncclCommAbort");
   r.GroupStart = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
   r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
   r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
@@ -278,6 +280,8 @@ int gacq_group_set_exchange(gacq_group* g, int mode) {
     std::vector<void*> comm(G, nullptr);
     const int st = nc->CommInitAll(comm.data(), G, devs.data());
     if (st != 0) {
+      // whatever communicators the failed call did create are torn down: none is left behind half-initialised
+      for (void* cm : comm) if (cm) (void)(nc->CommAbort ? nc->CommAbort(cm) : nc->CommDestroy(cm));
       g->err = std::string("gacq_group_set_exchange: ncclCommInitAll failed: ") + nc->GetErrorString(st);
       return GACQ_ERR_HIP;
     }
@@ -368,7 +372,17 @@ int gacq_group_search_batch(gacq_gsig* s, const float* x_iq, size_t nsamp, int n
     }
     const int st2 = nc->GroupEnd();
     if (st != 0 || st2 != 0) {
-      g->err = std::string("gacq_group_search_batch: ncclAllGather failed: ") + nc->GetErrorString(st ? st : st2);
+      // Some members' streams may now hold a collective whose peers never joined: draining those streams (what fail() does next) would
+      // wait for ever.  The communicators are aborted -- queued collectives end -- and the group falls back to the host exchange; the
+      // caller sees the error and can call again.
+      for (void*& cm : g->comm) {
+        if (cm) (void)(nc->CommAbort ? nc->CommAbort(cm) : nc->CommDestroy(cm));
+        cm = nullptr;
+      }
+      g->comm.clear();
+      g->exchange = GACQ_EXCHANGE_HOST;
+      g->err = std::string("gacq_group_search_batch: ncclAllGather failed (communicators aborted, exchange back to GACQ_EXCHANGE_HOST): ") +
+               nc->GetErrorString(st ? st : st2);
       return GACQ_ERR_HIP;
     }
     // the merge (on the member that holds a slice: it has the samples) + the completion events of every member

@@ -869,56 +869,6 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_correlate_kernel(const float
 #define GACQ_PRE4K 13     // batch kernel: pass-1 powers in registers (1) + pass-2 powers from the LDS table (4) + rising wave priorities (8)
 #endif
 
-// ---- pieces of the single-launch search (lds_fused4k_kernel<.., SCAN>) ------------------------------------------------------------
-// Row records cross workgroups inside one launch: per-XCD L2s are not coherent and a CU's L1 is never refreshed, so both sides use
-// agent-scope accesses (global_store / global_load ... sc1: write-through, L1-bypassing) and the arrival counter is an agent-scope
-// atomic (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility": sc1 payload -> vmcnt(0) -> counter).
-__device__ __forceinline__ void store_rowrec_agent(RowRec* dst, const RowRec& r) {
-  unsigned long long lo, hi;
-  __builtin_memcpy(&lo, &r, 8);
-  __builtin_memcpy(&hi, reinterpret_cast<const char*>(&r) + 8, 8);
-  unsigned long long* d = reinterpret_cast<unsigned long long*>(dst);
-  __hip_atomic_store(d, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(d + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ RowRec load_rowrec_agent(const RowRec* src) {
-  const unsigned long long* s = reinterpret_cast<const unsigned long long*>(src);
-  const unsigned long long lo = __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned long long hi = __hip_atomic_load(s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  RowRec r;
-  __builtin_memcpy(&r, &lo, 8);
-  __builtin_memcpy(reinterpret_cast<char*>(&r) + 8, &hi, 8);
-  return r;
-}
-// One wave: lane l scans bins l, l + 64, ... in ascending order with strict '>', the 64 lane results are combined keeping the larger
-// metric and, on equal metrics, the lower bin -- best_doppler_kernel's rule (gacq_engine.hip), i.e. the serial scan of
-// acquire-gps-l1.py:36-39 (a row that never exceeds 0 reports idx = d_index = -1).
-__device__ __forceinline__ void scan_item_wave(const RowRec* rows, int D, int N, int normalised, gacq_peak* out, unsigned* arrivals) {
-  const int lane = threadIdx.x & 63;
-  double best = 0.0;
-  int bidx = -1, bd = 0x7fffffff;
-  for (int d = lane; d < D; d += 64) {
-    const RowRec r = load_rowrec_agent(rows + d);
-    const double m = normalised ? (double)r.peak / (r.sum / (double)N) : (double)r.peak;
-    if (m > best) { best = m; bidx = r.idx & kIdxMask; bd = d; }
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const double om = __shfl_down(best, off);
-    const int oi = __shfl_down(bidx, off);
-    const int od = __shfl_down(bd, off);
-    if (om > best || (om == best && od < bd)) { best = om; bidx = oi; bd = od; }
-  }
-  if (lane == 0) {
-    gacq_peak o;
-    o.metric = best;
-    o.idx = bidx;
-    o.d_index = bidx < 0 ? -1 : bd;
-    *out = o;
-    __hip_atomic_store(arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
-  }
-}
-
 // ---- N = 4096, one block, one carrier: forward + correlate in ONE kernel ---------------------------------------------------
 // Workgroup = (epoch, Doppler bin, chunk of pch items).  Prologue: load the x window, table-NCO mix (fp64 index as in
 // lds_forward_kernel), forward FFT, conjugate -- the spectrum never leaves the registers: the transform's output lane/register
@@ -930,19 +880,16 @@ __device__ __forceinline__ void scan_item_wave(const RowRec* rows, int D, int N,
 // lds_forward_kernel + lds_correlate_kernel: records are bit-identical (test_fused_4096_kernel_equals_two_kernel_path).
 // PREA: keep the 15 pass-1 twiddle powers of the inverse transform in registers for the whole item loop (30 VGPRs, 14 complex
 // products per row less); the maximum-first peak search freed exactly that much of the 128-register budget of 4 waves per SIMD.
-// SCAN (single-launch search for small batches: the host-buffer calls gacq_search / search()): the Doppler scan of
-// acquire-gps-l1.py:36-39 is done by the workgroup that completes an item's last Doppler bin instead of by a second kernel.  Row
-// records then go out as agent-scope (write-through) stores, a per-(epoch, item) arrival counter is bumped after they have been
-// acknowledged, and the workgroup that finds D - 1 earlier arrivals reads the item's D records back with agent-scope loads,
-// scans them in Doppler order with strict '>' and writes the 16-byte peak record (to pinned host memory for gacq_search).  The
-// counter is reset by that workgroup, so the buffer is all zero again when the kernel ends.
-template <int MINW, bool PREA, bool SCAN>
+// (Round 3's single-launch instantiation -- the Doppler scan by the workgroup that completes an item's last bin, records handed
+// over with agent-scope stores and an arrival counter -- measured slower than the three short launches it replaced (21.8 us of kernel
+// against 6.8 + 12.3 + 6.5 us whose launch latencies overlap, profiles/r03_single_search_latency.log) and had no hook for the tie-safe
+// re-evaluation; removed in round 6.)
+template <int MINW, bool PREA>
 __global__ __launch_bounds__(kBlock, MINW) void lds_fused4k_kernel(const float2* __restrict__ x, size_t epoch_stride,
                                                                     const float2* __restrict__ C, const int* __restrict__ items,
                                                                     const double* __restrict__ freq, const float2* __restrict__ nco_tab,
                                                                     const float2* __restrict__ tw, RowRec* __restrict__ rows, int E, int P,
-                                                                    int D, int pch, int nchunk, int by_epoch, unsigned* __restrict__ arrivals,
-                                                                    gacq_peak* __restrict__ peaks, int normalised, float tie_scale) {
+                                                                    int D, int pch, int nchunk, int by_epoch, float tie_scale) {
   __shared__ v2 lds[kLdsElems];
   __shared__ float s_peak[kBlock / 64];
   __shared__ int s_idx[kBlock / 64];
@@ -981,15 +928,6 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_fused4k_kernel(const float2*
   }
   v2 xr[kR];
   const unsigned lane_off = (unsigned)t * 16u;
-  // SCAN (latency path): a workgroup has only 1-4 rows, so every load it waits for is on the critical path of the whole search.
-  // The first item's code spectrum is fetched under the forward transform, the next item's under the current inverse transform
-  // (the registers come from giving up the resident twiddle powers: PREA is off in this instantiation).
-  v2 cn[SCAN ? kR : 1];
-  if (SCAN) {
-    const __amdgpu_buffer_rsrc_t c0 = row_rsrc(C + (long)items[p0] * kLdsN);
-#pragma unroll
-    for (int jp = 0; jp < kR / 2; jp++) ld_pair(c0, lane_off, jp, cn[2 * jp], cn[2 * jp + 1]);
-  }
   {
     const double f = freq[d];
     const float2* src = x + e * epoch_stride;
@@ -1017,21 +955,11 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_fused4k_kernel(const float2*
     if (PREA) asm volatile("" : "+v"(wb.x), "+v"(wb.y));
     else asm volatile("" : "+v"(wa.x), "+v"(wa.y), "+v"(wb.x), "+v"(wb.y));
     v2 v[kR];
-    if (SCAN) {
+    const __amdgpu_buffer_rsrc_t cres = row_rsrc(C + (long)items[p] * kLdsN);
 #pragma unroll
-      for (int jj = 0; jj < kR; jj++) v[jj] = cmul(cn[jj], xr[jj]);
-      if (p + 1 < p1) {
-        const __amdgpu_buffer_rsrc_t cnx = row_rsrc(C + (long)items[p + 1] * kLdsN);
+    for (int jp = 0; jp < kR / 2; jp++) ld_pair(cres, lane_off, jp, v[2 * jp], v[2 * jp + 1]);
 #pragma unroll
-        for (int jp = 0; jp < kR / 2; jp++) ld_pair(cnx, lane_off, jp, cn[2 * jp], cn[2 * jp + 1]);
-      }
-    } else {
-      const __amdgpu_buffer_rsrc_t cres = row_rsrc(C + (long)items[p] * kLdsN);
-#pragma unroll
-      for (int jp = 0; jp < kR / 2; jp++) ld_pair(cres, lane_off, jp, v[2 * jp], v[2 * jp + 1]);
-#pragma unroll
-      for (int jj = 0; jj < kR; jj++) v[jj] = cmul(v[jj], xr[jj]);
-    }
+    for (int jj = 0; jj < kR; jj++) v[jj] = cmul(v[jj], xr[jj]);
     if (PREA) fft4096<true, GACQ_PRE4K>(v, lds, wa, wb, reinterpret_cast<const v2(*)[15]>(pwa), nullptr, -1, s_tw2 + (t & 15));
     else fft4096<true>(v, lds, wa, wb);
     // lane t holds lags t + 256 k.  The 1/N of ifft is a power of two: applied once to the reduced values.
@@ -1055,22 +983,7 @@ __global__ __launch_bounds__(kBlock, MINW) void lds_fused4k_kernel(const float2*
       RowRec r;
       combine_tagged(kBlock / 64, [&](int w) { return s_peak[w]; }, [&](int w) { return s_idx[w]; }, tie_scale, r.peak, r.idx);
       r.sum = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3];
-      if (SCAN) store_rowrec_agent(rows + (e * P + p) * (long)D + d, r);
-      else rows[(e * P + p) * (long)D + d] = r;
-    }
-  }
-  if (SCAN && t < 64) {                                 // wave 0 (wave-uniform branch): the hand-over, once per workgroup
-    // all records of this workgroup were stored by lane 0 of this wave: once they have been written through, lane i counts
-    // the arrival for item p0 + i (one round trip for the whole chunk, not one per item)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int ni = p1 - p0;
-    unsigned earlier = 0;
-    if (t < ni) earlier = __hip_atomic_fetch_add(arrivals + e * P + p0 + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned long long last = __builtin_amdgcn_ballot_w64(t < ni && (int)earlier == D - 1);
-    while (last) {                                      // items whose last Doppler bin this workgroup completed
-      const int i = __builtin_ctzll(last);
-      last &= last - 1;
-      scan_item_wave(rows + (e * P + p0 + i) * (long)D, D, kLdsN, normalised, peaks + e * P + p0 + i, arrivals + e * P + p0 + i);
+      rows[(e * P + p) * (long)D + d] = r;
     }
   }
 }
@@ -1162,48 +1075,27 @@ int lds_fused_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, i
 
 // Worth it for batches only: with few (epoch, Doppler) units every workgroup's own forward transform sits on the critical path
 // (single epoch: 32 us fused against 19 us for the two kernels), with many it replaces a launch, 84 MB of X traffic and a tail.
-// Single-launch search: worth it while every workgroup can be resident at once with at most a handful of rows each (one epoch of
-// 32 items x 40 bins: 640 workgroups of 1 forward + 2 inverse transforms); beyond that the two-kernel path / the batch kernel win.
-bool lds_search1_supported(const gacq_ctx* ctx, int N, int B, int F, long units, int nitems) {
-  // the in-kernel Doppler scan has no re-evaluation hook: the single-launch form runs only with tie-safe locations switched off
-  return N == kLdsN && B == 1 && F == 1 && ctx->opt[GACQ_OPT_SEARCH1] != 0 && ctx->opt[GACQ_OPT_TIE_SAFE] == 0 && units <= 1024 &&
-         units * nitems <= 4096;
-}
-
 bool lds_fused4k_supported(const gacq_ctx* ctx, int N, int B, int F, long units) {
   return N == kLdsN && B == 1 && F == 1 && (ctx->opt[GACQ_OPT_FUSED_4K] >= 2 || (ctx->opt[GACQ_OPT_FUSED_4K] == 1 && units >= 1024));
 }
 
 int lds_fused4k_search(gacq_ctx* ctx, const float2* x, size_t nsamp, int nepoch, const float2* spectra, const int* d_items,
-                       const double* d_freq, const float2* tab, int nitems, int D, RowRec* rows, float tie_scale, unsigned* arrivals,
-                       gacq_peak* peaks, int normalised) {
+                       const double* d_freq, const float2* tab, int nitems, int D, RowRec* rows, float tie_scale) {
   const float2* tw;
   int rc = twiddle_table(ctx, &tw);
   if (rc != GACQ_OK) return rc;
   const long units = (long)nepoch * D;
-  int pch;
-  if (arrivals) {
-    // single-launch search (latency path): every workgroup should be resident at once (256 CUs x 4), each as short as possible
-    pch = 1;
-    while (pch < nitems && units * ((nitems + pch - 1) / pch) > 1024) pch++;
-  } else {
-    // one forward transform per workgroup: amortise it over up to 32 items while >= ~2048 workgroups remain
-    pch = 8;
-    while (pch < 32 && units * ((nitems + 2 * pch - 1) / (2 * pch)) >= 2048) pch *= 2;
-  }
+  // one forward transform per workgroup: amortise it over up to 32 items while >= ~2048 workgroups remain
+  int pch = 8;
+  while (pch < 32 && units * ((nitems + 2 * pch - 1) / (2 * pch)) >= 2048) pch *= 2;
   if (ctx->opt[GACQ_OPT_LDS_PCH] >= 1) pch = (int)ctx->opt[GACQ_OPT_LDS_PCH];
   pch = std::min(pch, nitems);
-  if (arrivals) pch = std::min(pch, 64);      // the hand-over counts one arrival per lane of wave 0
   const int nchunk = (nitems + pch - 1) / pch;
   const int by_epoch = nepoch >= 64 ? 1 : 0;
   const long units8 = by_epoch ? (long)((nepoch + 7) / 8) * D : (units + 7) / 8;      // units per XCD
   const dim3 grid((unsigned)(8 * units8 * nchunk));
-  if (arrivals)
-    hipLaunchKernelGGL((lds_fused4k_kernel<2, false, true>), grid, dim3(kBlock), 0, ctx->stream, x, nsamp, spectra, d_items, d_freq, tab, tw, rows,
-                       nepoch, nitems, D, pch, nchunk, by_epoch, arrivals, peaks, normalised, tie_scale);
-  else
-    hipLaunchKernelGGL((lds_fused4k_kernel<4, true, false>), grid, dim3(kBlock), 0, ctx->stream, x, nsamp, spectra, d_items, d_freq, tab, tw, rows,
-                       nepoch, nitems, D, pch, nchunk, by_epoch, (unsigned*)nullptr, (gacq_peak*)nullptr, 0, tie_scale);
+  hipLaunchKernelGGL((lds_fused4k_kernel<4, true>), grid, dim3(kBlock), 0, ctx->stream, x, nsamp, spectra, d_items, d_freq, tab, tw, rows,
+                     nepoch, nitems, D, pch, nchunk, by_epoch, tie_scale);
   GACQ_HIP(ctx, hipGetLastError());
   return GACQ_OK;
 }

@@ -138,10 +138,8 @@ int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes);
                                 /*     (the specialised kernels produce the same bits; this is the A/B and test switch)              */
 #define GACQ_OPT_LDS_UGROUP 9    /* [0 = auto, <= 64] N = 16384 correlate kernel: (epoch, Doppler) units a workgroup walks with one item's  */
                                 /*     code spectrum held in registers (round 4: item-major order; the spectrum is fetched once per group)  */
-#define GACQ_OPT_SEARCH1 10       /* [0] N = 4096, B = 1, one carrier, small batches (<= 4096 rows): the whole search -- mix, forward        */
-                                /*     transform, correlation, Doppler scan -- in ONE kernel launch.  Off by default: measured slower      */
-                                /*     than the three short launches for one epoch (21.8 us of kernel against 6.8 + 12.3 + 6.5 us that     */
-                                /*     overlap their launch latencies; profiles/r03_single_search_latency.log)                            */
+#define GACQ_OPT_SEARCH1 10       /* retired (round 6): the single-launch search of round 3 (Doppler scan inside the correlate kernel) measured     */
+                                /*     slower than three short launches and had no tie-safe re-evaluation; removed.  Accepted, ignored             */
 #define GACQ_OPT_BAR_UPLOAD 11    /* [1] gacq_search: inputs up to 256 KiB are written by the host straight into fine-grained device       */
                                 /*     memory through the PCIe BAR (large-BAR devices) instead of pinned staging + DMA                  */
 #define GACQ_OPT_WATCH_RESULTS 12 /* [1] gacq_search (BAR upload path only): wait for completion by watching the pinned result records for  */
@@ -246,7 +244,10 @@ gacq_ctx* gacq_group_member(gacq_group* group, int k);   /* member context, e.g.
  * ncclAllGather per chunk moves them over xGMI (single-process communicators from ncclCommInitAll; librccl.so is loaded on this
  * call, the library does not link against it) and a member merges them on the device with the tie-safe merge -- the same result bit
  * for bit.  Needs distinct devices; GACQ_ERR_UNSUPPORTED otherwise or when RCCL cannot be loaded (the group then stays on the host
- * merge).  Applies to Doppler-sliced searches; an item split needs no merge. */
+ * merge).  Applies to Doppler-sliced searches; an item split needs no merge.  EXPERIMENTAL beyond one device: the mode has run on one
+ * MI355X (a one-rank collective) and never on several -- no multi-GPU node was available to rounds 1-6.  A failed collective aborts the
+ * communicators (ncclCommAbort: nothing stays queued on a member's stream), returns the group to GACQ_EXCHANGE_HOST and reports the
+ * error; the call can be repeated. */
 #define GACQ_EXCHANGE_HOST 0
 #define GACQ_EXCHANGE_RCCL 1
 int gacq_group_set_exchange(gacq_group* group, int mode);

@@ -48,7 +48,7 @@ def test_kernels_with_lds_separators_use_no_accumulator_registers_and_hot_kernel
     assert len(kernels) > 40, sorted(kernels)
     with_agprs = sorted(k for k, m in kernels.items() if m["agpr_count"])
     assert with_agprs and all("tie_recheck" in k for k in with_agprs), with_agprs
-    for fragment in ("lds_fused4k_kernelILi4ELb1ELb0", "lds16k_correlate_kernelILb0", "r32_correlate_kernelILb0", "r32_fused_kernelILb0", "fused4k_c128_kernel", "lds_inner_correlate_kernel",
+    for fragment in ("lds_fused4k_kernelILi4ELb1E", "lds16k_correlate_kernelILb0", "r32_correlate_kernelILb0", "r32_fused_kernelILb0", "fused4k_c128_kernel", "lds_inner_correlate_kernel",
                      "lds_correlate_kernelILi2E", "pfa_inner_corr_kernelILi1980ELi3E", "pfa_inner_corr_kernelILi990ELi2E",
                      "pfa_outer_inverse_kernelILi1980ELi0E", "pfa_outer_inverse_kernelILi990ELi2E", "pfa_outer_inverse_mfma_kernelILi1980ELi0E"):
         hit = [k for k in kernels if fragment in k]

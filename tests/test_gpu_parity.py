@@ -1076,6 +1076,48 @@ def test_signal_handle_outliving_its_engine_is_harmless():
     del held, cached
 
 
+def test_search_on_a_nearly_full_device_runs_in_smaller_passes():
+    """The work buffers follow the device's FREE memory, not just the 32 GiB default limit (plumbing 11 / ADVICE): a context
+    created on a device that something else has filled sizes its passes to its share of what is left; one that had sized them while the
+    memory was free, and finds it gone, re-runs the search in passes of half the size instead of failing.  E1B, 36 items x 64 bins: 1.2 GB of
+    correlation workspace in one pass on an empty device.  Records identical either way (the pass size changes no arithmetic)."""
+    import torch
+    from gnss_dsp_tools_amd import acquire, signals, synth
+    sig = signals.get("galileo-e1b")
+    items = list(range(1, 37))
+    ds = [-4000.0, 4000.0, 125.0]
+    x = synth.make_iq(sig, 1, 11, synth.default_sats(items))
+    ref = acquire.Engine(0)
+    try:
+        want = ref.search_all(sig, x, items, ds, 8)
+    finally:
+        ref.close()
+    torch.cuda.empty_cache()
+    late = acquire.Engine(0)                         # sizes its budget NOW, with the device empty (32 GiB binds) ...
+    hog = None
+    try:
+        assert late.search_all(sig, x[:sig.samples_needed(1)], items[:2], [0.0, 500.0, 250.0], 8)
+        free, _ = torch.cuda.mem_get_info(0)
+        leave = int(2.5 * 2 ** 30)
+        hog = torch.empty(free - leave, dtype=torch.uint8, device="cuda:0")
+        early = acquire.Engine(0)                    # ... this one with 2.5 GB left: 0.8 x 2.5 GB / 2.25 / (contexts on the device) per buffer
+        try:
+            assert early.search_all(sig, x, items, ds, 8) == want
+        finally:
+            early.close()
+        del hog
+        hog = None
+        torch.cuda.empty_cache()
+        free, _ = torch.cuda.mem_get_info(0)
+        hog = torch.empty(free - 2 ** 30, dtype=torch.uint8, device="cuda:0")      # 1 GB left: the 1.2 GB pass `late` plans cannot be had
+        assert late.search_all(sig, x, items, ds, 8) == want
+    finally:
+        if hog is not None:
+            del hog
+        torch.cuda.empty_cache()
+        late.close()
+
+
 def test_doppler_slicing_when_one_epoch_exceeds_the_workspace(engine):
     """One epoch's forward spectra [D][B][N] larger than the workspace limit (galileo-e1b --time 200 would be 9 GB): the grid is
     searched in slices and merged with strict '>' in grid order -- same records as the single pass, on every engine that
@@ -1352,65 +1394,30 @@ def test_fused_4096_kernel_equals_two_kernel_path(engine):
 
 
 @pytest.mark.parametrize("cid", ["cfg1_gps_l1_prn1", "cfg2_gps_l1_all32", "edge_fractional_grid"])      # the B = 1 goldens of N = 4096
-@pytest.mark.parametrize("search1", [0, 1])
-def test_fused_4096_bench_kernel_matches_reference_golden(engine, golden_cases, cid, search1):
-    """The kernel the headline bench line times (lds_fused4k_kernel<4, true, false>; auto-selected only for batches of >= 1024
-    units) held to the reference's own outputs directly: option fused_4k = 2 forces it for these single-epoch golden cases
-    (search1 = 0), and the stage timers prove that it ran -- no separate forward launch, but a Doppler-scan launch.  search1 = 1 is
-    the single-launch instantiation of the same kernel (option search1, off by default): no Doppler-scan launch either."""
+def test_fused_4096_bench_kernel_matches_reference_golden(engine, golden_cases, cid):
+    """The kernel the headline bench line times (lds_fused4k_kernel<4, true>; auto-selected only for batches of >= 1024 units) held to
+    the reference's own outputs directly: option fused_4k = 2 forces it for these single-epoch golden cases, tie-safe locations on as
+    in the bench, and the stage timers prove that it ran -- no separate forward launch, one Doppler-scan launch.  (The option search1
+    of round 3 -- the scan inside the kernel, no re-evaluation hook -- is retired: accepted and ignored.)"""
     case = golden_cases[cid]
     x = case_iq(case)
     try:
         engine.set_engine(2)
         engine.set_option("fused_4k", 2)
-        engine.set_option("search1", search1)
-        engine.set_option("tie_safe", 0 if search1 else 1)      # the in-kernel Doppler scan has no re-evaluation hook
+        engine.set_option("search1", 1)                         # retired: must change nothing
         engine.set_profiling(True)
         engine.reset_stage_times()
         got = engine.search_all(case["script"], x, case["items"], case["doppler_search"], case["ms"])
         st = engine.stage_times()
         assert st["mix_nco"][1] == 0 and st["lds_correlate"][1] >= 1, st
-        assert st["best_doppler"][1] == (0 if search1 else 1), st
+        assert st["best_doppler"][1] == 1, st
+        assert engine.get_option("tie_safe") == 1
     finally:
         engine.set_profiling(False)
         engine.set_option("fused_4k", 1)
         engine.set_option("search1", 0)
-        engine.set_option("tie_safe", 1)
         engine.set_engine(0)
     _assert_results(got, case["results"], case)
-
-
-def test_single_launch_search_equals_the_three_kernel_path_bit_for_bit(engine):
-    """Option search1: small N = 4096 searches as ONE kernel (mix, forward transform, correlation and the Doppler scan by the last workgroup of
-    every item, records handed over with agent-scope stores/loads and an arrival counter).  The peak records must equal those of
-    forward + correlate + best_doppler byte for byte -- for one and several epochs, one and many items, repeated calls (the
-    counters are left zeroed) and noise-only inputs (near-tied Doppler bins)."""
-    import torch
-    from gnss_dsp_tools_amd import acquire, signals, synth
-    sig = signals.get("gps-l1")
-    dop = acquire.doppler_grid([-5000.0, 5000.0, 250.0])
-    for E, items, sats in ((1, list(range(1, 33)), None), (3, list(range(1, 33)), None), (1, [7], None), (2, [3, 3, 9], None), (1, list(range(1, 33)), [])):
-        xs = synth.make_epochs(sig, 1, 4242 + E, synth.default_sats(items) if sats is None else sats, E, nsamp=4096)
-        xd = torch.from_numpy(xs).cuda()
-        try:
-            engine.set_option("tie_safe", 0)                   # the single-launch form only runs with tie-safe locations off
-            engine.set_option("search1", 0)
-            want = engine.search_batch_dev(sig, xd, items, dop, 1)
-            torch.cuda.synchronize()
-            want = want.cpu().numpy().tobytes()
-            engine.set_option("search1", 1)
-            engine.set_profiling(True)
-            for rep in range(3):
-                engine.reset_stage_times()
-                got = engine.search_batch_dev(sig, xd, items, dop, 1)
-                torch.cuda.synchronize()
-                st = engine.stage_times()
-                assert st["best_doppler"][1] == 0 and st["mix_nco"][1] == 0 and st["lds_correlate"][1] == 1, st
-                assert got.cpu().numpy().tobytes() == want, (E, items, rep)
-        finally:
-            engine.set_profiling(False)
-            engine.set_option("search1", 0)
-            engine.set_option("tie_safe", 1)
 
 
 FULL_SIZE_JOBS = [  # BASELINE.json configs 2-5 (SURVEY.md 8d): signal, items, Doppler search, blocks

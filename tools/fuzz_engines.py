@@ -38,7 +38,7 @@ def draw(rng):
     E = int(rng.choice([1, 2, 3, 5] if not big else [1, 2]))
     opts = {"lds_pch": int(rng.choice([0, 1, 3, 8])), "split_pch": int(rng.choice([0, 1, 3, 5])), "fused_4k": int(rng.choice([0, 1, 2])),
             "fused_16k": int(rng.choice([0, 1])), "fused_inner": int(rng.choice([0, 1, 1, 1])), "split_mfma": int(rng.choice([0, 0, 1])),
-            "split_dt": int(rng.choice([0, 1, 2, 3])), "search1": int(rng.choice([0, 1, 1])), "lds_ugroup": int(rng.choice([0, 1, 2, 3]))}
+            "split_dt": int(rng.choice([0, 1, 2, 3])), "lds_ugroup": int(rng.choice([0, 1, 2, 3]))}
     row = 8 * sig.nfft * B
     ws = int(rng.choice([row // 2, 3 * row, 3 * row * D + 7 * row, 64 * row * D]))
     seed = int(rng.integers(1, 1 << 30))
