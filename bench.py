@@ -385,10 +385,13 @@ def reference_precision(args, env, f32_value, epochs=1024, seconds=1.0):
 
 
 def reference_precision_other_configs(args, env, seconds=0.6):
-    """BASELINE configs 3, 4 and 5 in the reference's arithmetic type: engine 5 (complex128 on the device; for these lengths the
-    five-stage pipeline on rocFFT's double-precision transforms) on each config's own step, >= `seconds` timed per config, the fp32
-    engines timed in the same loop, and the two engines' peak records compared on the same epochs (identical locations, metrics
-    within 1e-5)."""
+    """BASELINE configs 3, 4 and 5 in the reference's arithmetic type: engine 5 (complex128 on the device) on each config's own step,
+    >= `seconds` timed per config, the fp32 engines timed in the same loop, and the two engines' peak records compared on the same
+    epochs (identical locations, metrics within 1e-5).  N = 16384 / 65536 (configs 3 and 5) run the hand-written split form (round 6:
+    forward spectra shared by the items, ONE Z' round trip of 32 N bytes per row and block on the LDS-resident complex128 transform);
+    the five-stage rocFFT double-precision pipeline it replaced is timed in the same loop (option fused_c128 = 0).  N = 61380 (config 4)
+    and GPS L1 with B > 1 still run that pipeline.  Every record carries its own roofline block: HIP-event time of the Z' writer +
+    reader (or of the pipeline's five stages) against the bytes they must move."""
     from gnss_dsp_tools_amd import acquire
     dev = env["dev"]
     out = []
@@ -399,10 +402,14 @@ def reference_precision_other_configs(args, env, seconds=0.6):
         cells = sum(E * j["P"] * len(j["dop"]) * j["sig"].nfft for j in jobs)
         rec = {"baseline_config": k, "workload": cfg["label"], "epochs_per_step": E, "unit": "cells/s", "dtype": "f64"}
         peaks = {}
+        split_jobs = [j for j in jobs if j["sig"].nfft in (16384, 65536)]
         try:
-            for label, which in (("f64", 5), ("f32", 0)):
+            for label, which, opt in (("f64", 5, 1), ("f64_pipeline", 5, 0), ("f32", 0, 1)):
+                if label == "f64_pipeline" and not split_jobs:
+                    continue
                 eng = acquire.Engine(env["local_rank"], engine=which)
                 eng.use_torch_stream(dev)
+                eng.set_option("fused_c128", opt)
                 try:
                     def step():
                         res = []
@@ -421,12 +428,44 @@ def reference_precision_other_configs(args, env, seconds=0.6):
                         torch.cuda.synchronize(dev)
                         n += 1
                     dt = time.perf_counter() - t0
-                    rec[label if label == "f32" else "f64_timing"] = {"value": n * cells / dt, "ms_per_step": dt / n * 1e3, "steps_timed": n, "seconds_timed": dt}
+                    rec[label if label != "f64" else "f64_timing"] = {"value": n * cells / dt, "ms_per_step": dt / n * 1e3, "steps_timed": n, "seconds_timed": dt}
+                    if label == "f64":
+                        # HIP events around the stages (one context for all signals of the step: the stage sums are the step's)
+                        eng.set_profiling(True)
+                        eng.reset_stage_times()
+                        for _ in range(3):
+                            step()
+                        torch.cuda.synchronize(dev)
+                        stg = {kk: v[0] / 3.0 for kk, v in eng.stage_times().items() if v[1]}
+                        eng.set_profiling(False)
+                        z_bytes = sum(2.0 * 16 * j["sig"].nfft * E * j["P"] * len(j["dop"]) * j["B"] for j in split_jobs)
+                        if split_jobs:
+                            ms_z = stg.get("lds_correlate", 0.0) + stg.get("mag_peak", 0.0)
+                            rec["roofline"] = {"bound": "hbm", "kernels": "c128_split_corr_kernel (Z' writer) + c128_split_reader_kernel", "unit": "GB/s",
+                                               "signals": [j["label"] for j in split_jobs], "alg_bytes_per_step": z_bytes, "kernels_ms_per_step": ms_z,
+                                               "achieved": z_bytes / (ms_z * 1e-3) / 1e9 if ms_z else None, "peak": HBM_PEAK_GBPS,
+                                               "frac": (z_bytes / (ms_z * 1e-3) / 1e9 / HBM_PEAK_GBPS) if ms_z else None, "stage_ms_per_step": stg,
+                                               "model": "the Z' round trip of the split form: 16 N bytes written and 16 N read per correlation row and block, "
+                                                        "over the HIP-event time of the writer and reader launches of a step (all signals of the step; the "
+                                                        "stages of signals still on the rocFFT pipeline share the timers)"}
+                        else:
+                            p_bytes = sum(5.0 * 32 * j["sig"].nfft * E * j["P"] * len(j["dop"]) * j["B"] for j in jobs)
+                            rec["roofline"] = {"bound": "hbm", "kernels": "rocFFT double-precision pipeline: conj-multiply, inverse transform (>= 2 passes), magnitudes",
+                                               "unit": "GB/s", "alg_bytes_per_step": p_bytes, "ms_per_step": dt / n * 1e3,
+                                               "achieved": p_bytes / (dt / n) / 1e9, "peak": HBM_PEAK_GBPS, "frac": p_bytes / (dt / n) / 1e9 / HBM_PEAK_GBPS,
+                                               "model": "five stage boundaries of 32 N bytes (16 N in, 16 N out) per correlation row and block over the step time"}
                 finally:
                     eng.close()
             rec.update(rec.pop("f64_timing"))
             rec["f32_same_loop"] = rec.pop("f32")
             rec["f32_over_f64"] = rec["f32_same_loop"]["value"] / rec["value"]
+            if "f64_pipeline" in rec:
+                rec["rocfft_pipeline_same_loop"] = rec.pop("f64_pipeline")
+                rec["split_form_over_rocfft_pipeline"] = rec["value"] / rec["rocfft_pipeline_same_loop"]["value"]
+                a, b = peaks["f64"], peaks["f64_pipeline"]
+                rec["split_form_vs_rocfft_pipeline_on_the_same_epochs"] = {
+                    "searches": int(a.size), "peak_location_mismatches": int(((a["idx"] != b["idx"]) | (a["d_index"] != b["d_index"])).sum()),
+                    "max_rel_metric_error": float(np.max(np.abs(a["metric"] - b["metric"]) / np.abs(b["metric"])))}
             a, b = peaks["f32"], peaks["f64"]
             rec["f32_vs_f64_on_the_same_epochs"] = {
                 "searches": int(a.size), "peak_location_mismatches": int(((a["idx"] != b["idx"]) | (a["d_index"] != b["d_index"])).sum()),

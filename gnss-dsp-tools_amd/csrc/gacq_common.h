@@ -128,6 +128,7 @@ struct gacq_sig {
   float2* spectra_lds = nullptr;   // same in the LDS engine's lane-pair layout (only when lds_supported(N))
   float2* spectra_lds16 = nullptr; // N = 16384 only: the order of the radix-16 form of the transform (GACQ_OPT_LDS_VARIANT = 16; spectra_lds holds the radix-32 form's, gacq_lds16k.hip)
   double2* spectra64 = nullptr;    // complex128 code spectra of the verification engine (engine 5), built on first use
+  double2* spectra64_split = nullptr;   // the same as R rows per item, [p][k1][k2] = C[k1 + R k2] (N = R x 4096: the split form of engine 5), built on first use
   std::vector<float> replica;      // host copy of the +-1 replicas [nprn][n] (source of spectra64)
 };
 
@@ -238,7 +239,8 @@ int pfa_inverse_reduce(gacq_ctx* ctx, const float2* Z, RowRec* rows, long g0, lo
 int pfa_debug_nco(gacq_ctx* ctx, int N, int n, const double* d_freq, int* d_idx);
 
 // tie-safe re-evaluation (gacq_tiesafe.hip)
-int tie_code_spectra64(gacq_ctx* ctx, double2* rows, int nrows, int N);      // gacq_tiesafe.hip: complex128 forward transforms of nrows rows, no rocFFT
+int tie_code_spectra64(gacq_ctx* ctx, double2* rows, int nrows, int N);
+int twiddles64(gacq_ctx* ctx, int N, const double2** out);      // W_N^k, k < N, in fp64 on the device, cached per context      // gacq_tiesafe.hip: complex128 forward transforms of nrows rows, no rocFFT
 bool tie_supported(int N);                       // prime factors of N in {2, 3, 5, 7, 11, 13, 31}: every FFT length of the reference's scripts
 float tie_scale_of(const gacq_ctx* ctx);            // 1 - eps from GACQ_OPT_TIE_EPS_PPB
 int tie_prepare(gacq_sig* sig);                  // complex128 code spectra on first use

@@ -798,6 +798,7 @@ void gacq_signal_destroy(gacq_sig* sig) {
   if (sig->spectra_pfa) (void)hipFree(sig->spectra_pfa);
   if (sig->spectra_split) (void)hipFree(sig->spectra_split);
   if (sig->spectra64) (void)hipFree(sig->spectra64);
+  if (sig->spectra64_split) (void)hipFree(sig->spectra64_split);
   delete sig;
 }
 

@@ -526,7 +526,7 @@ bool tie_supported(int N) {
 }
 
 // W_N^k, k < N, in fp64 (device-side sincospi), cached per context
-static int twiddles64(gacq_ctx* ctx, int N, const double2** out) {
+int twiddles64(gacq_ctx* ctx, int N, const double2** out) {
   const std::string key = "W64_" + std::to_string(N);
   auto wt = ctx->tables.find(key);
   if (wt == ctx->tables.end()) {

@@ -208,6 +208,188 @@ __global__ __launch_bounds__(kBlock, 2) void fused4k_c128_kernel(XSrc x, size_t 
   }
 }
 
+// ---- N = R x 4096 (R = 4: BeiDou B1I / B2I, GLONASS L1 / L2; R = 16: Galileo E1B / E1C) in complex128: the split of engine 4 ----------
+// n = 4096 n1 + n2, k = k1 + R k2 (the split of gacq_split.hip and of the re-evaluation's tie_recheck_split_kernel, whose arithmetic this
+// follows step by step), with every 4096-point transform on the LDS-resident complex128 transform of gacq_fft64.h:
+//   forward   (one workgroup per (forward row, k1), shared by all items):  A[k1][n2] = W_N^{n2 k1} sum_n1 x[4096 n1 + n2] nco[.] W_R^{n1 k1},
+//             X[k1][k2] = FFT_4096(A[k1])                                         -> Xs, 16 N bytes per forward row
+//   writer    (per correlation row, block, k1):  T = FFT_4096(conj(C_p[k1][.]) X[k1][.]);  Z'[k1][n2] = W_N^{n2 k1} T[n2]   (|ifft(Y)| =
+//             |fft(conj Y)| / N: both transforms of the chain are forward ones)     -> Z', 16 N bytes per row and block
+//   reader    (per correlation row):  DFT_R over k1 for every n2, |.| / N, sum over the blocks, (max, first argmax, sum)
+// One Z' round trip of 32 N bytes per row and block instead of the five stage boundaries of the rocFFT pipeline (5 x 32 N), no rocFFT
+// plan.  The writer keeps the forward-spectrum row in registers over the items of its chunk (one carrier for all of them) and streams
+// the code-spectrum rows; Z' rows of a pass are ordered (epoch, Doppler bin, item), the records go out in the (epoch, item, Doppler bin)
+// order of the Doppler scan.
+__device__ __forceinline__ f64::cd ldc(const double2* p) { const double2 v = *p; return f64::cd{v.x, v.y}; }
+__device__ __forceinline__ void stc(double2* p, f64::cd v) { *p = make_double2(v.x, v.y); }
+
+// C[p][k] (natural order) -> Cs[p][k1][k2] = C[p][k1 + R k2]
+__global__ __launch_bounds__(kBlock) void c128_split_spectra_kernel(const double2* __restrict__ C, double2* __restrict__ Cs, int R) {
+  const long p = blockIdx.x / (unsigned)R;
+  const int k1 = (int)(blockIdx.x % (unsigned)R);
+  const double2* src = C + p * (long)R * f64::kN + k1;
+  double2* dst = Cs + (p * R + k1) * (long)f64::kN;
+  for (int k2 = threadIdx.x; k2 < f64::kN; k2 += kBlock) dst[k2] = src[(long)R * k2];
+}
+
+// y: the carrier-wiped rows of mix64_kernel (one N-sample window per forward row) -- the table-NCO index arithmetic runs once per sample
+// in that streaming kernel instead of once per (sample, k1) here, where two workgroups per CU cannot hide it (GLONASS, a carrier per
+// item: forward stage 6.7 -> see profiles/r06_complex128_split_engine.log)
+template <int R>
+__global__ __launch_bounds__(kBlock, 2) void c128_split_forward_kernel(const double2* __restrict__ y, double2* __restrict__ Xs,
+                                                                       const double2* __restrict__ WN) {
+  using namespace gacq::f64;
+  constexpr int M = kN, N = R * kN;
+  extern __shared__ __attribute__((aligned(16))) double lds64[];
+  const int t = threadIdx.x;
+  const int k1 = (int)(blockIdx.x % (unsigned)R);
+  const unsigned row = blockIdx.x / (unsigned)R;        // ((e*FD + fd)*B + b)
+  const double2* src = y + (long)row * N + t;
+  const cd wa = ldc(WN + t * R), wb = ldc(WN + 16 * (t & 15) * R);      // W_4096^t, W_256^(t & 15)
+  cd v[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) v[j] = cd{0.0, 0.0};
+  for (int n1 = 0; n1 < R; n1++) {
+    cd sv[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) sv[j] = ldc(src + M * n1 + 256 * j);
+    const cd wr = ldc(WN + ((n1 * k1) % R) * M);                       // W_R^{n1 k1}
+#pragma unroll
+    for (int j = 0; j < 16; j++) v[j] = v[j] + sv[j] * wr;
+  }
+#pragma unroll
+  for (int j = 0; j < 16; j++) v[j] = v[j] * ldc(WN + (t + 256 * j) * k1);      // W_N^{n2 k1}  (n2 k1 < N)
+  fft4096<false>(v, lds64, wa, wb, t);
+  double2* dst = Xs + ((long)row * R + k1) * M + t;
+#pragma unroll
+  for (int j = 0; j < 16; j++) stc(dst + 256 * j, v[rev16(j)]);                  // X[k1 + R k2], k2 = t + 256 j
+}
+
+// grid: (units of the pass) x B x R x nchunk; unit = (epoch, Doppler bin)
+template <int R>
+__global__ __launch_bounds__(kBlock, 2) void c128_split_corr_kernel(const double2* __restrict__ Xs, const double2* __restrict__ Cs,
+                                                                    double2* __restrict__ Z, const int* __restrict__ items,
+                                                                    const int* __restrict__ fset, const double2* __restrict__ WN, long u0,
+                                                                    int P, int F, int D, int B, int pch, int nchunk) {
+  using namespace gacq::f64;
+  constexpr int M = kN;
+  extern __shared__ __attribute__((aligned(16))) double lds64[];
+  const int t = threadIdx.x;
+  unsigned blk = blockIdx.x;
+  const int k1 = (int)(blk % (unsigned)R);
+  blk /= (unsigned)R;
+  const int p0 = (int)(blk % (unsigned)nchunk) * pch;
+  blk /= (unsigned)nchunk;
+  const int b = (int)(blk % (unsigned)B);
+  const long ul = blk / (unsigned)B;                    // unit within the pass
+  const long u = u0 + ul;
+  const long e = u / D;
+  const int d = (int)(u % D);
+  const int p1 = min(P, p0 + pch);
+  const cd wa = ldc(WN + t * R), wb = ldc(WN + 16 * (t & 15) * R);
+  // pass-2 twiddle powers W_256^{c k} of the 16 lane classes c = t & 15 from a 3.8 KB LDS table (as in fused4k_c128_kernel): rebuilt
+  // per transform they cost the registers the resident forward-spectrum row needs
+  __shared__ cd s_tw2[15 * 16];
+  if (t < 16) {
+    cd pw[15];
+    make_powers(pw, wb);
+#pragma unroll
+    for (int k = 0; k < 15; k++) s_tw2[16 * k + t] = pw[k];
+  }
+  __syncthreads();
+  cd xs[16];
+  int have = -1;
+  for (int p = p0; p < p1; p++) {
+    if (fset[p] != have) {
+      have = fset[p];
+      const double2* xr = Xs + (((((long)e * F + have) * D + d) * B + b) * R + k1) * (long)M + t;
+#pragma unroll
+      for (int j = 0; j < 16; j++) xs[j] = ldc(xr + 256 * j);
+    }
+    const double2* cr = Cs + ((long)items[p] * R + k1) * M + t;
+    cd y[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) y[j] = ldc(cr + 256 * j);
+#pragma unroll
+    for (int j = 0; j < 16; j++) y[j] = conj(y[j]) * xs[j];                      // conj(C_p * conj(X))   acquire-beidou-b1i.py:32
+    if (p > p0) __syncthreads();                                                 // the previous transform's exchange-2 reads are complete
+    fft4096<false, true>(y, lds64, wa, wb, t, s_tw2 + (t & 15));
+    double2* zr = Z + ((((ul * P + p) * B + b) * R + k1) * (long)M) + t;
+    // W_N^{n2 k1}: re-read per item (L1 / L2 hits) -- resident, its 64 registers push the transform into scratch
+    const double2* twp = WN;
+    asm volatile("" : "+s"(twp));
+#pragma unroll
+    for (int j = 0; j < 16; j++) stc(zr + 256 * j, y[rev16(j)] * ldc(twp + (t + 256 * j) * k1));
+  }
+}
+
+// one workgroup per correlation row of the pass (Z' order: (unit, item)); lags M n1 + n2
+template <int R>
+__global__ __launch_bounds__(kBlock, 2) void c128_split_reader_kernel(const double2* __restrict__ Z, RowRec64* __restrict__ rows, long u0, int P,
+                                                                      int D, int B, float* __restrict__ q_out) {
+  using namespace gacq::f64;
+  constexpr int M = kN, N = R * kN;
+  __shared__ double s_peak[kBlock / 64], s_sum[kBlock / 64];
+  __shared__ int s_idx[kBlock / 64];
+  const int t = threadIdx.x;
+  const long gl = blockIdx.x;                           // ul * P + p
+  const long ul = gl / P;
+  const int p = (int)(gl % P);
+  const long u = u0 + ul;
+  const long e = u / D;
+  const int d = (int)(u % D);
+  const double inv_n = 1.0 / (double)N;
+  const double2* z0 = Z + gl * (long)B * R * M + t;
+  double peak = -1.0, sum = 0.0;
+  int idx = 0x7fffffff;
+  for (int j = 0; j < 16; j++) {
+    const int n2 = t + 256 * j;
+    double acc[R];
+#pragma unroll
+    for (int n1 = 0; n1 < R; n1++) acc[n1] = 0.0;
+    for (int b = 0; b < B; b++) {
+      cd z[R];
+#pragma unroll
+      for (int kk = 0; kk < R; kk++) z[kk] = ldc(z0 + ((long)b * R + kk) * M + 256 * j);
+      if constexpr (R == 4) {
+        dft4<false>(z[0], z[1], z[2], z[3]);
+#pragma unroll
+        for (int n1 = 0; n1 < 4; n1++) acc[n1] += sqrt_pos(z[n1].x * z[n1].x + z[n1].y * z[n1].y) * inv_n;
+      } else {
+        dft16<false>(z);
+#pragma unroll
+        for (int n1 = 0; n1 < 16; n1++) { const cd r = z[rev16(n1)]; acc[n1] += sqrt_pos(r.x * r.x + r.y * r.y) * inv_n; }
+      }
+    }
+#pragma unroll
+    for (int n1 = 0; n1 < R; n1++) {
+      const int lag = M * n1 + n2;
+      if (q_out) q_out[lag] = (float)acc[n1];
+      if (acc[n1] > peak || (acc[n1] == peak && lag < idx)) { peak = acc[n1]; idx = lag; }      // np.argmax: the first maximum
+      sum += acc[n1];
+    }
+  }
+  // (max, first argmax, sum) over the workgroup
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double op = __shfl_down(peak, off), os = __shfl_down(sum, off);
+    const int oi = __shfl_down(idx, off);
+    if (op > peak || (op == peak && oi < idx)) { peak = op; idx = oi; }
+    sum += os;
+  }
+  if ((t & 63) == 0) { s_peak[t >> 6] = peak; s_idx[t >> 6] = idx; s_sum[t >> 6] = sum; }
+  __syncthreads();
+  if (t == 0) {
+    for (int w = 1; w < kBlock / 64; w++) {
+      if (s_peak[w] > peak || (s_peak[w] == peak && s_idx[w] < idx)) { peak = s_peak[w]; idx = s_idx[w]; }
+      sum += s_sum[w];
+    }
+    RowRec64 r;
+    r.peak = peak; r.sum = sum; r.idx = idx; r.pad = 0;
+    rows[(e * P + p) * (long)D + d] = r;
+  }
+}
+
 // W_4096^k in fp64 (sincospi on the exactly reduced argument, device-side)
 __global__ void twiddle4096_64_kernel(double2* __restrict__ w) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -277,6 +459,83 @@ int verify_spectra(gacq_sig* s) {
   return GACQ_OK;
 }
 
+// the split form of engine 5 (N = 4 x 4096 or 16 x 4096): see c128_split_*_kernel
+template <int R>
+static int split64_search(gacq_sig* sig, XSrc d_x, size_t nsamp, int nepoch, int P, int F, int D, int B, gacq_peak* d_out, float* d_qrow,
+                          const double2* tab) {
+  gacq_ctx* ctx = sig->ctx;
+  hipStream_t st = ctx->stream;
+  const int n = sig->desc.n, N = sig->N;
+  int rc;
+  const double2* WN;
+  if ((rc = twiddles64(ctx, N, &WN)) != GACQ_OK) return rc;
+  if (!sig->spectra64_split) {
+    double2* buf = nullptr;
+    GACQ_HIP(ctx, hipMalloc((void**)&buf, sizeof(double2) * (size_t)sig->nprn * N));
+    hipLaunchKernelGGL(c128_split_spectra_kernel, dim3((unsigned)(sig->nprn * R)), dim3(kBlock), 0, st, (const double2*)sig->spectra64, buf, R);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+      (void)hipFree(buf);
+      return set_error(ctx, GACQ_ERR_HIP, "complex128 split engine: code-spectrum reorder failed");
+    }
+    sig->spectra64_split = buf;
+  }
+  GACQ_HIP(ctx, hipFuncSetAttribute((const void*)c128_split_forward_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, f64::kLdsBytes));
+  GACQ_HIP(ctx, hipFuncSetAttribute((const void*)c128_split_corr_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, f64::kLdsBytes));
+  const size_t x_epoch_bytes = sizeof(double2) * (size_t)F * D * B * N;
+  const int Ec = (int)std::max<size_t>(1, std::min<size_t>((size_t)nepoch, ws_budget(ctx) / std::max<size_t>(1, x_epoch_bytes)));
+  if ((rc = ensure(ctx, ctx->X, x_epoch_bytes * Ec)) != GACQ_OK) return rc;
+  if ((rc = ensure(ctx, ctx->rows, sizeof(RowRec64) * (size_t)Ec * P * D)) != GACQ_OK) return rc;
+  // items per writer workgroup: the forward-spectrum row stays in registers over them (one carrier); with a carrier per item (GLONASS)
+  // every item has its own row and nothing is shared
+  const int pch = (F == 1) ? std::min(P, 8) : 1;
+  const int nchunk = (P + pch - 1) / pch;
+  for (int e0 = 0; e0 < nepoch; e0 += Ec) {
+    const int ne = std::min(Ec, nepoch - e0);
+    double2* Xs = (double2*)ctx->X.p;
+    RowRec64* rows = (RowRec64*)ctx->rows.p;
+    const long rows_x = (long)ne * F * D * B;
+    const unsigned cols = (unsigned)(N / kBlock);
+    if (rows_x * cols >= (1L << 31)) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "complex128 split engine: too many forward rows in one pass (lower the workspace limit)");
+    // carrier wipe-off into the correlation workspace (free until the first Z' pass), then the split forward transform out of it
+    if ((rc = ensure(ctx, ctx->Y, x_epoch_bytes * ne)) != GACQ_OK) return rc;
+    stage_begin(ctx, 0);
+    hipLaunchKernelGGL(mix64_kernel, dim3((unsigned)(rows_x * cols)), dim3(kBlock), 0, st, d_x.offset((size_t)e0 * nsamp), nsamp, (double2*)ctx->Y.p,
+                       (const double*)ctx->freq.p, tab, n, N, F * D, B, cols);
+    GACQ_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(c128_split_forward_kernel<R>, dim3((unsigned)(rows_x * R)), dim3(kBlock), f64::kLdsBytes, st, (const double2*)ctx->Y.p, Xs, WN);
+    stage_end(ctx);
+    GACQ_HIP(ctx, hipGetLastError());
+    // Z' passes of whole (epoch, Doppler bin) units, P items each: at most 4 GiB a pass, as in the fp32 split engines
+    const long units = (long)ne * D;
+    const size_t unit_bytes = sizeof(double2) * (size_t)P * B * N;
+    const size_t pass_cap = std::min(ws_budget(ctx), std::max<size_t>((size_t)4 << 30, unit_bytes));
+    long uc = (long)std::max<size_t>(1, std::min<size_t>((size_t)units, pass_cap / unit_bytes));
+    uc = std::min<long>(uc, std::max<long>(1, ((1L << 31) - 1) / ((long)B * R * nchunk)));
+    if (d_qrow) uc = 1;
+    if ((rc = ensure(ctx, ctx->Y, unit_bytes * uc)) != GACQ_OK) return rc;
+    double2* Z = (double2*)ctx->Y.p;
+    for (long u0 = 0; u0 < units; u0 += uc) {
+      const long nu = std::min(uc, units - u0);
+      stage_begin(ctx, 6);
+      hipLaunchKernelGGL(c128_split_corr_kernel<R>, dim3((unsigned)(nu * B * nchunk * R)), dim3(kBlock), f64::kLdsBytes, st, (const double2*)Xs,
+                         (const double2*)sig->spectra64_split, Z, (const int*)ctx->items.p, (const int*)ctx->fset.p, WN, u0, P, F, D, B, pch, nchunk);
+      stage_end(ctx);
+      GACQ_HIP(ctx, hipGetLastError());
+      stage_begin(ctx, 4);
+      hipLaunchKernelGGL(c128_split_reader_kernel<R>, dim3((unsigned)(nu * P)), dim3(kBlock), 0, st, (const double2*)Z, rows, u0, P, D, B, d_qrow);
+      stage_end(ctx);
+      GACQ_HIP(ctx, hipGetLastError());
+    }
+    const long nep = (long)ne * P;
+    stage_begin(ctx, 5);
+    hipLaunchKernelGGL(best_doppler64_kernel, dim3((unsigned)((nep + 63) / 64)), dim3(64), 0, st, (const RowRec64*)rows, d_out + (size_t)e0 * P, nep, D, N,
+                       sig->desc.metric_mode);
+    stage_end(ctx);
+    GACQ_HIP(ctx, hipGetLastError());
+  }
+  return GACQ_OK;
+}
+
 int verify_search(gacq_sig* sig, XSrc d_x, size_t nsamp, int nepoch, int P, int F, int D, int B, gacq_peak* d_out, float* d_qrow) {
   gacq_ctx* ctx = sig->ctx;
   hipStream_t st = ctx->stream;
@@ -310,6 +569,9 @@ int verify_search(gacq_sig* sig, XSrc d_x, size_t nsamp, int nepoch, int P, int 
     GACQ_HIP(ctx, hipGetLastError());
     return GACQ_OK;
   }
+  // N = 4 x 4096 / 16 x 4096: the hand-written split form (one Z' round trip, no rocFFT plan); GACQ_OPT_FUSED_C128 = 0 keeps the pipeline
+  if (ctx->opt[GACQ_OPT_FUSED_C128] && N == 4 * f64::kN) return split64_search<4>(sig, d_x, nsamp, nepoch, P, F, D, B, d_out, d_qrow, tab);
+  if (ctx->opt[GACQ_OPT_FUSED_C128] && N == 16 * f64::kN) return split64_search<16>(sig, d_x, nsamp, nepoch, P, F, D, B, d_out, d_qrow, tab);
   const size_t x_epoch_bytes = sizeof(double2) * (size_t)F * D * B * N;
   const int Ec = (int)std::max<size_t>(1, std::min<size_t>((size_t)nepoch, ws_budget(ctx) / std::max<size_t>(1, x_epoch_bytes)));
   if ((rc = ensure(ctx, ctx->X, x_epoch_bytes * Ec)) != GACQ_OK) return rc;

@@ -1355,6 +1355,42 @@ def test_fp32_engines_agree_with_the_complex128_engine_on_near_ties(engine):
         engine.set_engine(0)
 
 
+@pytest.mark.parametrize("name,items,ds,ms,E", [("galileo-e1b", [1, 2, 19, 36], [-500.0, 500.0, 125.0], 8, 2),           # N = 65536, B = 1
+                                                ("beidou-b1i", [6, 7, 33], [1000.0, 2000.0, 250.0], 3, 2),               # N = 16384, B = 3, padded
+                                                ("glonass-l1", [-7, 0, 3, 6], [1000.0, 2000.0, 500.0], 2, 1)])           # a carrier per item
+def test_complex128_split_form_equals_the_rocfft_double_pipeline(engine, name, items, ds, ms, E):
+    """Engine 5 for N = 4 x 4096 / 16 x 4096 (round 6): the hand-written split form -- forward spectra shared by the items, one Z' round trip
+    on the LDS-resident complex128 transform -- against the five-stage pipeline on rocFFT's double-precision transforms it replaces (option
+    fused_c128 = 0): the same locations and metrics to 1e-12 (both are fp64 throughout; only the butterfly order differs), the magnitude row
+    of one search to 1e-12 of its maximum, and no rocFFT plan created on the way."""
+    import torch
+    from gnss_dsp_tools_amd import acquire, signals, synth
+    sig = signals.get(name)
+    B = sig.blocks(ms)
+    dop = acquire.doppler_grid(ds)
+    xs = synth.make_epochs(sig, B, 2468, synth.default_sats(items), E, nsamp=sig.samples_needed(B))
+    xd = torch.from_numpy(xs).cuda()
+    eng = acquire.Engine(0, engine=5)
+    try:
+        got = eng.search_batch_dev(sig, xd, items, dop, B)
+        torch.cuda.synchronize()
+        got = got.cpu().numpy().view(acquire.PEAK_DTYPE)
+        assert eng.fft_plans() == 0
+        row = eng.debug_row(sig, xs[0], items[1], float(dop[1]), B)
+        eng.set_option("fused_c128", 0)
+        ref = eng.search_batch_dev(sig, xd, items, dop, B)
+        torch.cuda.synchronize()
+        ref = ref.cpu().numpy().view(acquire.PEAK_DTYPE)
+        assert eng.fft_plans() > 0
+        row_ref = eng.debug_row(sig, xs[0], items[1], float(dop[1]), B)
+    finally:
+        eng.close()
+    np.testing.assert_array_equal(got["idx"], ref["idx"])
+    np.testing.assert_array_equal(got["d_index"], ref["d_index"])
+    np.testing.assert_allclose(got["metric"], ref["metric"], rtol=1e-12)
+    assert np.abs(row - row_ref).max() <= 2e-7 * np.abs(row_ref).max()          # the row dump is float32
+
+
 def test_fused_4096_kernel_equals_two_kernel_path(engine):
     """N = 4096, one block, one carrier: forward + correlate in one kernel (option fused_4k) -- same arithmetic in the same
     order as lds_forward_kernel + lds_correlate_kernel, so the peak records are bit-identical, for every item-chunk size."""
