@@ -76,7 +76,10 @@ def main():
     trace(out, "config2_complex128", c128)
     pmc(out, "config2_complex128", c128 + ["--steps", "2", "--sustained-s", "0", "--preroll-s", "0"], "fused4k_c128|best_doppler64")
     cfgs = [py, os.path.join(ROOT, "tools", "bench_configs.py"), "--reps", "2", "cfg3_e1b", "cfg4_l5i", "cfg4_b2ad_b1", "cfg5_b1i", "cfg5_glonass", "cfg5_e1b", "gps_l1_ms10"]
-    pmc(out, "configs345", cfgs, "inner_corr|outer_inverse|lds16k|lds_inner|outer_forward|inner_forward|lds_correlate|lds_forward")
+    pmc(out, "configs345", cfgs, "inner_corr|outer_inverse|lds16k|r32_|lds_inner|outer_forward|inner_forward|lds_correlate|lds_forward")
+    # the radix-16 form of the N = 16384 transform (option lds_variant = 16) next to the default radix-32 form, and engine 5's split form
+    pmc(out, "n16384_radix16", [py, os.path.join(ROOT, "tools", "bench_configs.py"), "--reps", "2", "--option", "lds_variant=16", "cfg5_b1i", "cfg5_glonass"], "lds16k")
+    pmc(out, "complex128_split", [py, os.path.join(ROOT, "tools", "bench_configs.py"), "--reps", "2", "--engine", "5", "cfg3_e1b", "cfg5_b1i"], "c128_split|mix64")
     r = subprocess.run([py, os.path.join(ROOT, "tools", "bench_configs.py"), "--stages"], capture_output=True, text=True)
     open(os.path.join(out, "all_configs_stage_times.log"), "w").write("\n".join(l for l in r.stdout.splitlines() if "amdgpu.ids" not in l) + "\n")
 
