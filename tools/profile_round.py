@@ -19,7 +19,8 @@ def trace(out, name, cmd):
     d = os.path.join(out, "trace_" + name)
     r = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "t", "--"] + cmd, cwd="/tmp", env=ENV,
                        capture_output=True, text=True)
-    lines = ["# rocprofv3 --kernel-trace --stats -- " + " ".join(os.path.relpath(c, ROOT) if c.startswith(ROOT) else c for c in cmd), ""]
+    lines = ["# rocprofv3 --kernel-trace --stats -- " + " ".join(os.path.relpath(c, ROOT) if c.startswith(ROOT) else c for c in cmd),
+             "# taken at commit " + os.environ.get("GACQ_EVIDENCE_HEAD", "unknown"), ""]
     for path in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
         rows = list(csv.DictReader(open(path)))
         lines.append("%-100s %6s %12s %12s %7s %10s %10s" % ("kernel", "calls", "total_us", "avg_us", "%", "min_us", "max_us"))
@@ -43,7 +44,8 @@ def trace(out, name, cmd):
 def pmc(out, name, cmd, filt):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_profile.py"), os.path.join(out, "pmc_" + name), "--groups",
                         "sq_time,sq_inst,grbm,fetch,write,tcc_hit", "--filter", filt, "--"] + cmd, capture_output=True, text=True, env=ENV)
-    head = "# rocprofv3 --pmc, one pass per counter group (tools/pmc_profile.py), command: %s\n" % " ".join(os.path.relpath(c, ROOT) if c.startswith(ROOT) else c for c in cmd)
+    head = "# rocprofv3 --pmc, one pass per counter group (tools/pmc_profile.py), command: %s\n# taken at commit %s\n" % (
+        " ".join(os.path.relpath(c, ROOT) if c.startswith(ROOT) else c for c in cmd), os.environ.get("GACQ_EVIDENCE_HEAD", "unknown"))
     open(os.path.join(out, "pmc_counters_%s.txt" % name), "w").write(head + r.stdout + ("\n" + r.stderr[-2000:] if r.returncode else ""))
     print(head + r.stdout[-6000:])
     return r.stdout

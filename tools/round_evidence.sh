@@ -2,7 +2,9 @@
 # PMC counters (tools/profile_round.py), the near-tie census and a randomised differential run.  Everything lands under gpurun_out/ and
 # is copied into profiles/ by hand afterwards.  usage: bash tools/round_evidence.sh r04
 TAG=${1:-r06}
-git rev-parse HEAD > gpurun_out/evidence_head.txt 2>/dev/null || true
+# second argument: the commit the evidence is taken at (the GPU box has no .git): bash tools/round_evidence.sh r06 $(git rev-parse --short HEAD)
+export GACQ_EVIDENCE_HEAD=${2:-unknown}
+echo "$GACQ_EVIDENCE_HEAD" > gpurun_out/evidence_head.txt
 timeout 900 python tools/parity_sweep.py > gpurun_out/parity_sweep.log 2>&1
 for c in 2 3 4 5; do timeout 600 python bench.py --config $c --steps 20 --warmup 5 --no-others 2>/dev/null | grep '^{' ; done > gpurun_out/bench_lines.json
 timeout 900 python bench.py > gpurun_out/bench_default_line.json 2>/dev/null
