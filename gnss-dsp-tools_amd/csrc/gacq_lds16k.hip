@@ -20,8 +20,8 @@
 // every cheaper source (LDS or memory tables) cost more than it saved.  Eight waves x 256 registers hold the same row state
 // (64 + 64 + 32) plus half of the big twiddle set (table A, 32); the second set is small enough for LDS (table B, 4 KB, 16 distinct
 // addresses per read); one exchange and one twiddle set are gone with the fourth pass: 13 % fewer VALU instructions per row
-// (SQ_INSTS_VALU 9.75e8 against 1.117e9 per B1I launch) and 2/3 of the LDS store traffic.  What that buys is small -- config 5's B1I /
-// GLONASS searches 0-5 % / 0-2.5 % faster than the radix-16 form, alternating in one process on four boxes -- because with two waves per
+// (SQ_INSTS_VALU 9.75e8 against 1.117e9 per B1I launch) and 2/3 of the LDS store traffic.  What that buys is small -- config 5's B1I
+// search 0-5 % faster than the radix-16 form, its GLONASS search within 2 %, alternating in one process on six boxes -- because with two waves per
 // SIMD instead of four the LDS round trips and the two workgroup barriers of a row are covered less (VALU pipes 61 % busy against 77 %):
 // one row in flight per CU is what the register file allows either way (row + code spectrum + accumulators = 320 KB of its 512), and
 // that, not the instruction count, is what paces a row.  The default since round 6; GACQ_OPT_LDS_VARIANT = 16 selects the radix-16

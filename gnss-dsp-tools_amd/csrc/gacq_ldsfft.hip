@@ -996,8 +996,8 @@ namespace gacq {
 
 bool lds_supported(int N) { return N == kLdsN || N == kBig; }
 
-// N = 16384: the radix-32 form of gacq_lds16k.hip unless GACQ_OPT_LDS_VARIANT = 16 selects the radix-16 form of this file (0-5 % slower
-// in the same process on every box measured, never faster: the in-run A/B of bench.py, roofline.ab.n16384_transform)
+// N = 16384: the radix-32 form of gacq_lds16k.hip unless GACQ_OPT_LDS_VARIANT = 16 selects the radix-16 form of this file (B1I 0-5 %
+// slower, GLONASS within 2 % either way in the same process: the in-run A/B of bench.py, roofline.ab.n16384_transform)
 static bool radix16_16k(const gacq_ctx* ctx) { return ctx->opt[GACQ_OPT_LDS_VARIANT] == 16; }
 
 #ifdef GACQ_PHASE_TIMING16

@@ -128,7 +128,7 @@ int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes);
 #define GACQ_OPT_LDS_VARIANT 2  /* [-1] N = 16384: 16 = the radix-16 form of the one-workgroup transform (1024 threads x 16 points, three     */
                                 /*     exchanges; gacq_ldsfft.hip) instead of the radix-32 form (512 x 32, two exchanges; gacq_lds16k.hip).    */
                                 /*     Same results to fp32 rounding; the radix-32 form issues 13 % fewer VALU instructions at half the waves  */
-                                /*     and measures 0-5 % faster (the in-run A/B of bench.py); every other value: radix-32 form                */
+                                /*     and measures 0-5 % faster on B1I, within 2 % on GLONASS (the in-run A/B of bench.py); other values: radix-32 form                */
 #define GACQ_OPT_LDS_PCH 3      /* [0 = auto] items per workgroup of the LDS correlate kernels                          */
 #define GACQ_OPT_SPLIT_PCH 4    /* [0 = auto] (epoch, item) rows per workgroup of the split engines' inner kernels      */
 #define GACQ_OPT_SPLIT_TEAMS 5  /* retired (round 5): belonged to the Stockham inner kernel the prime-factor engine replaced; accepted, ignored */
