@@ -388,9 +388,10 @@ def reference_precision_other_configs(args, env, seconds=0.6):
     """BASELINE configs 3, 4 and 5 in the reference's arithmetic type: engine 5 (complex128 on the device) on each config's own step,
     >= `seconds` timed per config, the fp32 engines timed in the same loop, and the two engines' peak records compared on the same
     epochs (identical locations, metrics within 1e-5).  N = 16384 / 65536 (configs 3 and 5) run the hand-written split form (round 6:
-    forward spectra shared by the items, ONE Z' round trip of 32 N bytes per row and block on the LDS-resident complex128 transform);
-    the five-stage rocFFT double-precision pipeline it replaced is timed in the same loop (option fused_c128 = 0).  N = 61380 (config 4)
-    and GPS L1 with B > 1 still run that pipeline.  Every record carries its own roofline block: HIP-event time of the Z' writer +
+    forward spectra shared by the items, ONE Z' round trip of 32 N bytes per row and block on the LDS-resident complex128 transform),
+    N = 61380 (config 4) the Cooley-Tukey form 31 x 1980 with hand-written fp64 DFT-31 stages around rocFFT's native length-1980
+    transforms (no Bluestein); the five-stage rocFFT double-precision pipeline they replaced is timed in the same loop (option
+    fused_c128 = 0).  GPS L1 with B > 1 still runs that pipeline.  Every record carries its own roofline block: HIP-event time of the Z' writer +
     reader (or of the pipeline's five stages) against the bytes they must move."""
     from gnss_dsp_tools_amd import acquire
     dev = env["dev"]
@@ -402,7 +403,7 @@ def reference_precision_other_configs(args, env, seconds=0.6):
         cells = sum(E * j["P"] * len(j["dop"]) * j["sig"].nfft for j in jobs)
         rec = {"baseline_config": k, "workload": cfg["label"], "epochs_per_step": E, "unit": "cells/s", "dtype": "f64"}
         peaks = {}
-        split_jobs = [j for j in jobs if j["sig"].nfft in (16384, 65536)]
+        split_jobs = [j for j in jobs if j["sig"].nfft in (16384, 65536, 61380, 30690)]          # lengths with a hand-written complex128 form
         try:
             for label, which, opt in (("f64", 5, 1), ("f64_pipeline", 5, 0), ("f32", 0, 1)):
                 if label == "f64_pipeline" and not split_jobs:
@@ -438,16 +439,21 @@ def reference_precision_other_configs(args, env, seconds=0.6):
                         torch.cuda.synchronize(dev)
                         stg = {kk: v[0] / 3.0 for kk, v in eng.stage_times().items() if v[1]}
                         eng.set_profiling(False)
-                        z_bytes = sum(2.0 * 16 * j["sig"].nfft * E * j["P"] * len(j["dop"]) * j["B"] for j in split_jobs)
+                        # R x 4096: Z' written once and read once (2 x 16 N per row and block); 31 x M: conj-multiply out, rocFFT inverse in
+                        # and out, reader in (4 x 16 N)
+                        z_bytes = sum((2.0 if j["sig"].nfft in (16384, 65536) else 4.0) * 16 * j["sig"].nfft * E * j["P"] * len(j["dop"]) * j["B"] for j in split_jobs)
                         if split_jobs:
-                            ms_z = stg.get("lds_correlate", 0.0) + stg.get("mag_peak", 0.0)
-                            rec["roofline"] = {"bound": "hbm", "kernels": "c128_split_corr_kernel (Z' writer) + c128_split_reader_kernel", "unit": "GB/s",
+                            ms_z = stg.get("lds_correlate", 0.0) + stg.get("mag_peak", 0.0) + stg.get("conj_mul", 0.0) + stg.get("rocfft_inverse", 0.0)
+                            r31 = any(j["sig"].nfft in (61380, 30690) for j in split_jobs)
+                            rec["roofline"] = {"bound": "hbm", "kernels": ("conj_mul64_kernel + rocFFT double inverse (length N / 31) + c128_r31_reader_kernel" if r31 else
+                                                                           "c128_split_corr_kernel (Z' writer) + c128_split_reader_kernel"), "unit": "GB/s",
                                                "signals": [j["label"] for j in split_jobs], "alg_bytes_per_step": z_bytes, "kernels_ms_per_step": ms_z,
                                                "achieved": z_bytes / (ms_z * 1e-3) / 1e9 if ms_z else None, "peak": HBM_PEAK_GBPS,
                                                "frac": (z_bytes / (ms_z * 1e-3) / 1e9 / HBM_PEAK_GBPS) if ms_z else None, "stage_ms_per_step": stg,
-                                               "model": "the Z' round trip of the split form: 16 N bytes written and 16 N read per correlation row and block, "
-                                                        "over the HIP-event time of the writer and reader launches of a step (all signals of the step; the "
-                                                        "stages of signals still on the rocFFT pipeline share the timers)"}
+                                               "model": "the correlation-side stage boundaries of the hand-written form -- R x 4096: Z' written and read once, 2 x 16 N "
+                                                        "bytes per correlation row and block; 31 x M: conj-multiply out, inner inverse transform in and out, "
+                                                        "reader in, 4 x 16 N -- over the HIP-event time of those launches of a step (all signals of the step; "
+                                                        "the stages of signals still on the rocFFT pipeline share the timers)"}
                         else:
                             p_bytes = sum(5.0 * 32 * j["sig"].nfft * E * j["P"] * len(j["dop"]) * j["B"] for j in jobs)
                             rec["roofline"] = {"bound": "hbm", "kernels": "rocFFT double-precision pipeline: conj-multiply, inverse transform (>= 2 passes), magnitudes",

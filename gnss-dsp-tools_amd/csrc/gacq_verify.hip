@@ -223,13 +223,13 @@ __global__ __launch_bounds__(kBlock, 2) void fused4k_c128_kernel(XSrc x, size_t 
 __device__ __forceinline__ f64::cd ldc(const double2* p) { const double2 v = *p; return f64::cd{v.x, v.y}; }
 __device__ __forceinline__ void stc(double2* p, f64::cd v) { *p = make_double2(v.x, v.y); }
 
-// C[p][k] (natural order) -> Cs[p][k1][k2] = C[p][k1 + R k2]
-__global__ __launch_bounds__(kBlock) void c128_split_spectra_kernel(const double2* __restrict__ C, double2* __restrict__ Cs, int R) {
+// C[p][k] (natural order) -> Cs[p][k1][k2] = C[p][k1 + R k2], k2 < M
+__global__ __launch_bounds__(kBlock) void c128_split_spectra_kernel(const double2* __restrict__ C, double2* __restrict__ Cs, int R, int M) {
   const long p = blockIdx.x / (unsigned)R;
   const int k1 = (int)(blockIdx.x % (unsigned)R);
-  const double2* src = C + p * (long)R * f64::kN + k1;
-  double2* dst = Cs + (p * R + k1) * (long)f64::kN;
-  for (int k2 = threadIdx.x; k2 < f64::kN; k2 += kBlock) dst[k2] = src[(long)R * k2];
+  const double2* src = C + p * (long)R * M + k1;
+  double2* dst = Cs + (p * R + k1) * (long)M;
+  for (int k2 = threadIdx.x; k2 < M; k2 += kBlock) dst[k2] = src[(long)R * k2];
 }
 
 // y: the carrier-wiped rows of mix64_kernel (one N-sample window per forward row) -- the table-NCO index arithmetic runs once per sample
@@ -390,6 +390,136 @@ __global__ __launch_bounds__(kBlock, 2) void c128_split_reader_kernel(const doub
   }
 }
 
+// ---- N = 31 x M (61380 = 31 x 1980, 30690 = 31 x 990: every 10.23 Mcps script, E6, Xona X5) in complex128 ---------------------------
+// rocFFT has no radix-31 butterfly and runs these lengths through Bluestein (three transforms of twice the size per FFT): the pipeline
+// above manages 1.4e10 cells/s at BASELINE config 4.  The Cooley-Tukey split of gacq_split.hip in fp64 keeps the prime out of rocFFT:
+//   n = M n1 + n2, k = k1 + 31 k2:  X[k1 + 31 k2] = sum_n2 W_M^{n2 k2} (W_N^{n2 k1} sum_n1 x[M n1 + n2] W_31^{n1 k1})
+//   forward:  c128_r31_forward_kernel (DFT-31 over n1 + twiddle, thread = n2)  ->  rocFFT double, length M (= 4 x 5 x 9 x 11: native radices),
+//             batch 31 x rows, in place  ->  X in [k1][k2] order (the code spectra are reordered once to match)
+//   inverse:  conj_mul64_kernel  ->  rocFFT inverse length M  ->  c128_r31_reader_kernel (twiddle, inverse DFT-31, |.| / N, sum over the
+//             blocks, first-argmax reduce; one workgroup per correlation row)
+// The DFT-31 uses the conjugate symmetry of W_31 like dft_prime of gacq_cplx.h: s_n = x[n] + x[31-n], d_n = x[n] - x[31-n],
+// A_k = x[0] + sum cos(2 pi nk/31) s_n, B_k = sum sin(2 pi nk/31) d_n, X[k], X[31-k] = A_k -/+ i B_k (inverse: signs swapped).
+__constant__ double kCos31[16] = {1.0, 0.97952994125249448, 0.9189578116202306, 0.82076344120727629, 0.68896691907568663, 0.52896401032696239,
+                                  0.34730525284482028, 0.1514277775045767, -0.050649168838712642, -0.25065253225872042, -0.44039415155763439,
+                                  -0.61210598254766257, -0.75875812269279086, -0.87434661614458209, -0.95413925640004882, -0.99486932339189504};
+__constant__ double kSin31[16] = {0.0, 0.20129852008866006, 0.39435585511331855, 0.57126821509479231, 0.72479278722911988, 0.84864425749475092,
+                                  0.93775213214708042, 0.98846832432811138, 0.99871650717105276, 0.96807711886620429, 0.89780453957074158,
+                                  0.79077573693769887, 0.65137248272222226, 0.48530196253108104, 0.29936312297335804, 0.10116832198743272};
+
+// out(k, X[k]) for k = 0..30 from x[0] and the folded pairs sn[n] = x[n] + x[31-n], dn[n] = x[n] - x[31-n], n = 1..15
+template <bool INV, class Sink> __device__ __forceinline__ void dft31_core_f64(f64::cd x0, const f64::cd (&sn)[16], const f64::cd (&dn)[16], Sink&& out) {
+  using f64::cd;
+  cd sum = x0;
+#pragma unroll
+  for (int n = 1; n <= 15; n++) sum = sum + sn[n];
+  out(0, sum);
+#pragma unroll
+  for (int k = 1; k <= 15; k++) {
+    cd A = x0, B = cd{0.0, 0.0};
+#pragma unroll
+    for (int n = 1; n <= 15; n++) {
+      const int m = (n * k) % 31;
+      const int mm = m <= 15 ? m : 31 - m;
+      const double c = kCos31[mm], sg = m <= 15 ? kSin31[mm] : -kSin31[mm];
+      A.x = __builtin_fma(c, sn[n].x, A.x);
+      A.y = __builtin_fma(c, sn[n].y, A.y);
+      B.x = __builtin_fma(sg, dn[n].x, B.x);
+      B.y = __builtin_fma(sg, dn[n].y, B.y);
+    }
+    // forward: X[k] = A - i B, X[31-k] = A + i B
+    out(k, INV ? f64::add_i(A, B) : f64::sub_i(A, B));
+    out(31 - k, INV ? f64::sub_i(A, B) : f64::add_i(A, B));
+  }
+}
+template <bool INV, class Sink> __device__ __forceinline__ void dft31_f64(f64::cd (&x)[31], Sink&& out) {
+  f64::cd sn[16], dn[16];
+#pragma unroll
+  for (int n = 1; n <= 15; n++) {
+    sn[n] = x[n] + x[31 - n];
+    dn[n] = x[n] - x[31 - n];
+  }
+  dft31_core_f64<INV>(x[0], sn, dn, out);
+}
+
+// grid: rows x chunks; thread = n2.  y: the carrier-wiped rows of mix64_kernel (N samples per forward row)
+__global__ __launch_bounds__(kBlock) void c128_r31_forward_kernel(const double2* __restrict__ y, double2* __restrict__ A, const double2* __restrict__ WN,
+                                                                   int M, int chunks) {
+  using f64::cd;
+  const unsigned row = blockIdx.x / (unsigned)chunks;
+  const int n2 = (int)(blockIdx.x % (unsigned)chunks) * kBlock + threadIdx.x;
+  if (n2 >= M) return;
+  const double2* src = y + (long)row * 31 * M + n2;
+  cd v[31];
+#pragma unroll
+  for (int n1 = 0; n1 < 31; n1++) v[n1] = ldc(src + (long)n1 * M);
+  double2* dst = A + (long)row * 31 * M + n2;
+  dft31_f64<false>(v, [&](int k1, cd val) { stc(dst + (long)k1 * M, k1 ? val * ldc(WN + n2 * k1) : val); });      // W_N^{n2 k1}, n2 k1 < N
+}
+
+// one workgroup per correlation row g (Z: [g][b][k1][n2] after the inner inverse transforms, unnormalised); lags M n1 + n2.
+// The magnitudes are summed over the blocks in the thread's own 31 LDS slots (in registers, or reduced on the fly for B = 1, the unrolled
+// transform spills 0.3-0.9 KB per lane).  The inputs are loaded and folded pair by pair (x[n], x[31-n]).
+__global__ __launch_bounds__(kBlock, 2) void c128_r31_reader_kernel(const double2* __restrict__ Z, RowRec64* __restrict__ rows, const double2* __restrict__ WN,
+                                                                     long g0, int M, int B, float* __restrict__ q_out) {
+  using f64::cd;
+  __shared__ double s_peak[kBlock / 64], s_sum[kBlock / 64];
+  __shared__ int s_idx[kBlock / 64];
+  __shared__ double s_acc[31 * kBlock];
+  const int t = threadIdx.x;
+  const long gl = blockIdx.x;
+  const long N = 31L * M;
+  const double inv_n = 1.0 / (double)N;
+  double peak = -1.0, sum = 0.0;
+  int idx = 0x7fffffff;
+  auto take = [&](double m, int lag) {
+    if (q_out) q_out[lag] = (float)m;
+    if (m > peak || (m == peak && lag < idx)) { peak = m; idx = lag; }      // np.argmax: the first maximum (lags arrive in any order)
+    sum += m;
+  };
+  for (int n2 = t; n2 < M; n2 += kBlock) {
+#pragma unroll
+    for (int n1 = 0; n1 < 31; n1++) s_acc[n1 * kBlock + t] = 0.0;
+    for (int b = 0; b < B; b++) {
+      const double2* src = Z + ((gl * B + b) * 31L) * M + n2;
+      const cd x0 = ldc(src);
+      cd sn[16], dn[16];
+      // five pairs (20 loads) at a time: hoisted all together -- the compiler's choice -- the 120 loads of a column take 480 registers
+#pragma unroll
+      for (int n = 1; n <= 15; n++) {
+        const cd a = ldc(src + (long)n * M) * f64::conj(ldc(WN + n2 * n));
+        const cd c = ldc(src + (long)(31 - n) * M) * f64::conj(ldc(WN + n2 * (31 - n)));
+        sn[n] = a + c;
+        dn[n] = a - c;
+        if (n % 5 == 0) asm volatile("" : "+v"(sn[n].x), "+v"(dn[n].x) :: "memory");
+      }
+      dft31_core_f64<true>(x0, sn, dn, [&](int n1, cd val) {
+        s_acc[n1 * kBlock + t] += f64::sqrt_pos(val.x * val.x + val.y * val.y) * inv_n;
+      });
+    }
+#pragma unroll
+    for (int n1 = 0; n1 < 31; n1++) take(s_acc[n1 * kBlock + t], M * n1 + n2);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double op = __shfl_down(peak, off), os = __shfl_down(sum, off);
+    const int oi = __shfl_down(idx, off);
+    if (op > peak || (op == peak && oi < idx)) { peak = op; idx = oi; }
+    sum += os;
+  }
+  if ((t & 63) == 0) { s_peak[t >> 6] = peak; s_idx[t >> 6] = idx; s_sum[t >> 6] = sum; }
+  __syncthreads();
+  if (t == 0) {
+    for (int w = 1; w < kBlock / 64; w++) {
+      if (s_peak[w] > peak || (s_peak[w] == peak && s_idx[w] < idx)) { peak = s_peak[w]; idx = s_idx[w]; }
+      sum += s_sum[w];
+    }
+    RowRec64 r;
+    r.peak = peak; r.sum = sum; r.idx = idx; r.pad = 0;
+    rows[g0 + gl] = r;
+  }
+}
+
 // W_4096^k in fp64 (sincospi on the exactly reduced argument, device-side)
 __global__ void twiddle4096_64_kernel(double2* __restrict__ w) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -472,7 +602,7 @@ static int split64_search(gacq_sig* sig, XSrc d_x, size_t nsamp, int nepoch, int
   if (!sig->spectra64_split) {
     double2* buf = nullptr;
     GACQ_HIP(ctx, hipMalloc((void**)&buf, sizeof(double2) * (size_t)sig->nprn * N));
-    hipLaunchKernelGGL(c128_split_spectra_kernel, dim3((unsigned)(sig->nprn * R)), dim3(kBlock), 0, st, (const double2*)sig->spectra64, buf, R);
+    hipLaunchKernelGGL(c128_split_spectra_kernel, dim3((unsigned)(sig->nprn * R)), dim3(kBlock), 0, st, (const double2*)sig->spectra64, buf, R, f64::kN);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
       (void)hipFree(buf);
       return set_error(ctx, GACQ_ERR_HIP, "complex128 split engine: code-spectrum reorder failed");
@@ -536,6 +666,83 @@ static int split64_search(gacq_sig* sig, XSrc d_x, size_t nsamp, int nepoch, int
   return GACQ_OK;
 }
 
+// the N = 31 x M form of engine 5: see c128_r31_*_kernel
+static int r31_64_search(gacq_sig* sig, XSrc d_x, size_t nsamp, int nepoch, int P, int F, int D, int B, gacq_peak* d_out, float* d_qrow,
+                         const double2* tab) {
+  gacq_ctx* ctx = sig->ctx;
+  hipStream_t st = ctx->stream;
+  const int n = sig->desc.n, N = sig->N, M = N / 31;
+  int rc;
+  const double2* WN;
+  if ((rc = twiddles64(ctx, N, &WN)) != GACQ_OK) return rc;
+  if (!sig->spectra64_split) {
+    double2* buf = nullptr;
+    GACQ_HIP(ctx, hipMalloc((void**)&buf, sizeof(double2) * (size_t)sig->nprn * N));
+    hipLaunchKernelGGL(c128_split_spectra_kernel, dim3((unsigned)(sig->nprn * 31)), dim3(kBlock), 0, st, (const double2*)sig->spectra64, buf, 31, M);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+      (void)hipFree(buf);
+      return set_error(ctx, GACQ_ERR_HIP, "complex128 radix-31 engine: code-spectrum reorder failed");
+    }
+    sig->spectra64_split = buf;
+  }
+  const size_t x_epoch_bytes = sizeof(double2) * (size_t)F * D * B * N;
+  const int Ec = (int)std::max<size_t>(1, std::min<size_t>((size_t)nepoch, ws_budget(ctx) / std::max<size_t>(1, x_epoch_bytes)));
+  if ((rc = ensure(ctx, ctx->X, x_epoch_bytes * Ec)) != GACQ_OK) return rc;
+  if ((rc = ensure(ctx, ctx->rows, sizeof(RowRec64) * (size_t)Ec * P * D)) != GACQ_OK) return rc;
+  const unsigned cols = (unsigned)((N + kBlock - 1) / kBlock);
+  const int chunks = (M + kBlock - 1) / kBlock;
+  for (int e0 = 0; e0 < nepoch; e0 += Ec) {
+    const int ne = std::min(Ec, nepoch - e0);
+    double2* X = (double2*)ctx->X.p;
+    RowRec64* rows = (RowRec64*)ctx->rows.p;
+    const long rows_x = (long)ne * F * D * B;
+    if (rows_x * cols >= (1L << 31)) return set_error(ctx, GACQ_ERR_UNSUPPORTED, "complex128 radix-31 engine: too many forward rows in one pass (lower the workspace limit)");
+    if ((rc = ensure(ctx, ctx->Y, x_epoch_bytes * ne)) != GACQ_OK) return rc;
+    stage_begin(ctx, 0);
+    hipLaunchKernelGGL(mix64_kernel, dim3((unsigned)(rows_x * cols)), dim3(kBlock), 0, st, d_x.offset((size_t)e0 * nsamp), nsamp, (double2*)ctx->Y.p,
+                       (const double*)ctx->freq.p, tab, n, N, F * D, B, cols);
+    GACQ_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(c128_r31_forward_kernel, dim3((unsigned)(rows_x * chunks)), dim3(kBlock), 0, st, (const double2*)ctx->Y.p, X, WN, M, chunks);
+    stage_end(ctx);
+    GACQ_HIP(ctx, hipGetLastError());
+    stage_begin(ctx, 1);
+    rc = fft_exec(ctx, M, rows_x * 31, false, X, true);
+    stage_end(ctx);
+    if (rc != GACQ_OK) return rc;
+    const long groups = (long)ne * P * D;
+    const size_t group_bytes = sizeof(double2) * (size_t)B * N;
+    const size_t pass_cap = std::min(ws_budget(ctx), std::max<size_t>((size_t)4 << 30, 8 * group_bytes * (size_t)D));
+    long gc = (long)std::max<size_t>(1, std::min<size_t>((size_t)groups, pass_cap / group_bytes));
+    gc = std::min<long>(gc, std::max<long>(1, ((1L << 31) - 1) / ((long)B * cols)));
+    if (d_qrow) gc = 1;
+    if ((rc = ensure(ctx, ctx->Y, group_bytes * gc)) != GACQ_OK) return rc;
+    double2* Y = (double2*)ctx->Y.p;
+    for (long g0 = 0; g0 < groups; g0 += gc) {
+      const long ng = std::min(gc, groups - g0);
+      stage_begin(ctx, 2);
+      hipLaunchKernelGGL(conj_mul64_kernel, dim3((unsigned)(ng * B * cols)), dim3(kBlock), 0, st, (const double2*)X, (const double2*)sig->spectra64_split, Y,
+                         (const int*)ctx->items.p, (const int*)ctx->fset.p, g0, P, F, D, B, N, cols);
+      stage_end(ctx);
+      GACQ_HIP(ctx, hipGetLastError());
+      stage_begin(ctx, 3);
+      rc = fft_exec(ctx, M, ng * B * 31, true, Y, true);
+      stage_end(ctx);
+      if (rc != GACQ_OK) return rc;
+      stage_begin(ctx, 4);
+      hipLaunchKernelGGL(c128_r31_reader_kernel, dim3((unsigned)ng), dim3(kBlock), 0, st, (const double2*)Y, rows, WN, g0, M, B, d_qrow);
+      stage_end(ctx);
+      GACQ_HIP(ctx, hipGetLastError());
+    }
+    const long nep = (long)ne * P;
+    stage_begin(ctx, 5);
+    hipLaunchKernelGGL(best_doppler64_kernel, dim3((unsigned)((nep + 63) / 64)), dim3(64), 0, st, (const RowRec64*)rows, d_out + (size_t)e0 * P, nep, D, N,
+                       sig->desc.metric_mode);
+    stage_end(ctx);
+    GACQ_HIP(ctx, hipGetLastError());
+  }
+  return GACQ_OK;
+}
+
 int verify_search(gacq_sig* sig, XSrc d_x, size_t nsamp, int nepoch, int P, int F, int D, int B, gacq_peak* d_out, float* d_qrow) {
   gacq_ctx* ctx = sig->ctx;
   hipStream_t st = ctx->stream;
@@ -572,6 +779,8 @@ int verify_search(gacq_sig* sig, XSrc d_x, size_t nsamp, int nepoch, int P, int 
   // N = 4 x 4096 / 16 x 4096: the hand-written split form (one Z' round trip, no rocFFT plan); GACQ_OPT_FUSED_C128 = 0 keeps the pipeline
   if (ctx->opt[GACQ_OPT_FUSED_C128] && N == 4 * f64::kN) return split64_search<4>(sig, d_x, nsamp, nepoch, P, F, D, B, d_out, d_qrow, tab);
   if (ctx->opt[GACQ_OPT_FUSED_C128] && N == 16 * f64::kN) return split64_search<16>(sig, d_x, nsamp, nepoch, P, F, D, B, d_out, d_qrow, tab);
+  // N = 31 x M with M in rocFFT's native radices (61380, 30690): the prime stays out of rocFFT (no Bluestein)
+  if (ctx->opt[GACQ_OPT_FUSED_C128] && (N == 61380 || N == 30690)) return r31_64_search(sig, d_x, nsamp, nepoch, P, F, D, B, d_out, d_qrow, tab);
   const size_t x_epoch_bytes = sizeof(double2) * (size_t)F * D * B * N;
   const int Ec = (int)std::max<size_t>(1, std::min<size_t>((size_t)nepoch, ws_budget(ctx) / std::max<size_t>(1, x_epoch_bytes)));
   if ((rc = ensure(ctx, ctx->X, x_epoch_bytes * Ec)) != GACQ_OK) return rc;

@@ -106,8 +106,9 @@ int gacq_use_null_stream(gacq_ctx* ctx);
  *     to ~1e-12 and is what a near-tie disagreement of an fp32 engine is bisected against.  N = 4096 with one block and one carrier
  *     runs as ONE fused kernel (fp64 transform resident in LDS); N = 16384 and 65536 (B1I / B2I, GLONASS, E1B / E1C) as the split
  *     form 4 x / 16 x 4096 on the same transform -- forward spectra shared by the items, one Z' round trip of 32 N bytes per row and
- *     block, no rocFFT plan (both: GACQ_OPT_FUSED_C128); every other shape as the five-stage pipeline on rocFFT's double-precision
- *     transforms.  Never chosen by auto. */
+ *     block, no rocFFT plan; N = 61380 / 30690 (the 10.23 Mcps scripts, E6, Xona X5) as 31 x M with hand-written fp64 DFT-31 stages
+ *     around rocFFT's native length-M double transforms, which keeps the prime 31 out of rocFFT's Bluestein path (all three:
+ *     GACQ_OPT_FUSED_C128); every other shape as the five-stage pipeline on rocFFT's double-precision transforms.  Never chosen by auto. */
 int gacq_set_engine(gacq_ctx* ctx, int engine);
 /* Upper bound in bytes for EACH of the two library-owned work buffers of a context -- the forward spectra and the correlation workspace;
  * both are allocated as searches need them, with 1/8 of headroom, and kept, so a context can hold about 2.25 x this (default 32 GiB
@@ -160,8 +161,9 @@ int gacq_set_workspace_limit(gacq_ctx* ctx, size_t bytes);
                                 /*     capacity) stay within an eighth of the workspace limit (gacq_set_workspace_limit), between 32 and    */
                                 /*     256 MiB; an explicit value is taken as given                                                         */
 #define GACQ_OPT_FUSED_C128 16     /* [1] engine 5 on the hand-written complex128 kernels where they exist -- N = 4096, B = 1, one carrier: the     */
-                                /*     whole search row in one workgroup; N = 16384 / 65536: the split form (c128_split_*_kernel) -- instead of   */
-                                /*     the five-stage rocFFT double-precision pipeline; 0 = always the pipeline (the cross-check)                */
+                                /*     whole search row in one workgroup; N = 16384 / 65536: the split form (c128_split_*_kernel); N = 61380 /    */
+                                /*     30690: the 31 x M form (c128_r31_*_kernel) -- instead of the five-stage rocFFT double-precision pipeline; */
+                                /*     0 = always the pipeline (the cross-check)                                                                */
 #define GACQ_OPT_SPLIT_MFMA 17     /* [0] prime-factor engine: the inverse DFT-31 of the outer stage as two real 16 x 16 matrices on the       */
                                 /*     matrix pipe (v_mfma_f32_16x16x4_f32, exact fp32) instead of packed math on the VALU.  Off: measured     */
                                 /*     12-18 % slower -- the stage is paced by its load stream, not by arithmetic                             */

@@ -1357,12 +1357,15 @@ def test_fp32_engines_agree_with_the_complex128_engine_on_near_ties(engine):
 
 @pytest.mark.parametrize("name,items,ds,ms,E", [("galileo-e1b", [1, 2, 19, 36], [-500.0, 500.0, 125.0], 8, 2),           # N = 65536, B = 1
                                                 ("beidou-b1i", [6, 7, 33], [1000.0, 2000.0, 250.0], 3, 2),               # N = 16384, B = 3, padded
-                                                ("glonass-l1", [-7, 0, 3, 6], [1000.0, 2000.0, 500.0], 2, 1)])           # a carrier per item
+                                                ("glonass-l1", [-7, 0, 3, 6], [1000.0, 2000.0, 500.0], 2, 1),            # a carrier per item
+                                                ("gps-l5i", [3, 17, 32], [-400.0, 400.0, 200.0], 2, 2),                 # N = 61380 = 31 x 1980, B = 2
+                                                ("galileo-e6b", [1, 50], [0.0, 600.0, 200.0], 3, 1)])                   # N = 30690 = 31 x 990
 def test_complex128_split_form_equals_the_rocfft_double_pipeline(engine, name, items, ds, ms, E):
-    """Engine 5 for N = 4 x 4096 / 16 x 4096 (round 6): the hand-written split form -- forward spectra shared by the items, one Z' round trip
-    on the LDS-resident complex128 transform -- against the five-stage pipeline on rocFFT's double-precision transforms it replaces (option
-    fused_c128 = 0): the same locations and metrics to 1e-12 (both are fp64 throughout; only the butterfly order differs), the magnitude row
-    of one search to 1e-12 of its maximum, and no rocFFT plan created on the way."""
+    """Engine 5 beyond N = 4096 on hand-written kernels (round 6) against the five-stage pipeline on rocFFT's double-precision transforms it
+    replaces (option fused_c128 = 0): N = 4 x 4096 / 16 x 4096 as the split form -- forward spectra shared by the items, one Z' round trip on
+    the LDS-resident complex128 transform, no rocFFT plan --; N = 31 x M with fp64 DFT-31 stages around rocFFT's native length-M transforms (no
+    Bluestein).  The same locations and metrics to 1e-12 (both are fp64 throughout; only the butterfly order differs) and the magnitude row of
+    one search to float32 resolution."""
     import torch
     from gnss_dsp_tools_amd import acquire, signals, synth
     sig = signals.get(name)
@@ -1375,13 +1378,12 @@ def test_complex128_split_form_equals_the_rocfft_double_pipeline(engine, name, i
         got = eng.search_batch_dev(sig, xd, items, dop, B)
         torch.cuda.synchronize()
         got = got.cpu().numpy().view(acquire.PEAK_DTYPE)
-        assert eng.fft_plans() == 0
+        assert eng.fft_plans() == (0 if sig.nfft in (16384, 65536) else 2)          # 31 x M: the length-M forward and inverse plans
         row = eng.debug_row(sig, xs[0], items[1], float(dop[1]), B)
         eng.set_option("fused_c128", 0)
         ref = eng.search_batch_dev(sig, xd, items, dop, B)
         torch.cuda.synchronize()
         ref = ref.cpu().numpy().view(acquire.PEAK_DTYPE)
-        assert eng.fft_plans() > 0
         row_ref = eng.debug_row(sig, xs[0], items[1], float(dop[1]), B)
     finally:
         eng.close()
