@@ -454,7 +454,16 @@ __global__ __launch_bounds__(kBlock) void c128_r31_forward_kernel(const double2*
 #pragma unroll
   for (int n1 = 0; n1 < 31; n1++) v[n1] = ldc(src + (long)n1 * M);
   double2* dst = A + (long)row * 31 * M + n2;
-  dft31_f64<false>(v, [&](int k1, cd val) { stc(dst + (long)k1 * M, k1 ? val * ldc(WN + n2 * k1) : val); });      // W_N^{n2 k1}, n2 k1 < N
+  // W_N^{n2 k1}: the outputs arrive as k1 = 0, then the pairs (k, 31 - k): w^k by a chain of products from w = W_N^{n2}, and
+  // w^{31-k} = W_M^{n2} conj(w^k) -- two coalesced table reads per column instead of 30 gathers with a lane stride of 16 k1 bytes
+  // (64 cache lines per wave and load)
+  const cd w1 = ldc(WN + n2), w31 = ldc(WN + 31 * n2);
+  cd wk = cd{1.0, 0.0};
+  dft31_f64<false>(v, [&](int k1, cd val) {
+    if (k1 == 0) { stc(dst, val); return; }
+    if (k1 <= 15) { wk = wk * w1; stc(dst + (long)k1 * M, val * wk); }
+    else stc(dst + (long)k1 * M, val * (w31 * f64::conj(wk)));
+  });
 }
 
 // one workgroup per correlation row g (Z: [g][b][k1][n2] after the inner inverse transforms, unnormalised); lags M n1 + n2.
@@ -480,15 +489,19 @@ __global__ __launch_bounds__(kBlock, 2) void c128_r31_reader_kernel(const double
   for (int n2 = t; n2 < M; n2 += kBlock) {
 #pragma unroll
     for (int n1 = 0; n1 < 31; n1++) s_acc[n1 * kBlock + t] = 0.0;
+    const cd w1c = f64::conj(ldc(WN + n2)), w31c = f64::conj(ldc(WN + 31 * n2));
     for (int b = 0; b < B; b++) {
       const double2* src = Z + ((gl * B + b) * 31L) * M + n2;
       const cd x0 = ldc(src);
       cd sn[16], dn[16];
-      // five pairs (20 loads) at a time: hoisted all together -- the compiler's choice -- the 120 loads of a column take 480 registers
+      // conj(W_N^{n2 k1}): conj(w)^n by a chain of products, conj(w^{31-n}) = conj(W_M^{n2}) w^n (see c128_r31_forward_kernel).  Ten
+      // loads at a time: hoisted all together -- the compiler's choice -- the 60 loads of a column take 240 registers
+      cd wn = cd{1.0, 0.0};
 #pragma unroll
       for (int n = 1; n <= 15; n++) {
-        const cd a = ldc(src + (long)n * M) * f64::conj(ldc(WN + n2 * n));
-        const cd c = ldc(src + (long)(31 - n) * M) * f64::conj(ldc(WN + n2 * (31 - n)));
+        wn = wn * w1c;
+        const cd a = ldc(src + (long)n * M) * wn;
+        const cd c = ldc(src + (long)(31 - n) * M) * (w31c * f64::conj(wn));
         sn[n] = a + c;
         dn[n] = a - c;
         if (n % 5 == 0) asm volatile("" : "+v"(sn[n].x), "+v"(dn[n].x) :: "memory");
