@@ -237,13 +237,18 @@ __global__ __launch_bounds__(kBlock) void c128_split_spectra_kernel(const double
 // item: forward stage 6.7 -> see profiles/r06_complex128_split_engine.log)
 template <int R>
 __global__ __launch_bounds__(kBlock, 2) void c128_split_forward_kernel(const double2* __restrict__ y, double2* __restrict__ Xs,
-                                                                       const double2* __restrict__ WN) {
+                                                                       const double2* __restrict__ WN, unsigned nrows) {
   using namespace gacq::f64;
   constexpr int M = kN, N = R * kN;
   extern __shared__ __attribute__((aligned(16))) double lds64[];
   const int t = threadIdx.x;
-  const int k1 = (int)(blockIdx.x % (unsigned)R);
-  const unsigned row = blockIdx.x / (unsigned)R;        // ((e*FD + fd)*B + b)
+  // the R workgroups of a forward row read the same N mixed samples: placed on ONE XCD (workgroup b runs on XCD b % 8), consecutive in
+  // its dispatch order, so that the row crosses the fabric once and the other R - 1 find it in that L2 (GLONASS, a carrier per item:
+  // 30 000 rows of 256 KB -- read by k1 = blockIdx % R from four XCDs they came out of HBM four times)
+  const unsigned xcd = blockIdx.x & 7u, jx = blockIdx.x >> 3;
+  const int k1 = (int)(jx % (unsigned)R);
+  const unsigned row = (jx / (unsigned)R) * 8u + xcd;   // ((e*FD + fd)*B + b)
+  if (row >= nrows) return;
   const double2* src = y + (long)row * N + t;
   const cd wa = ldc(WN + t * R), wb = ldc(WN + 16 * (t & 15) * R);      // W_4096^t, W_256^(t & 15)
   cd v[16];
@@ -257,8 +262,12 @@ __global__ __launch_bounds__(kBlock, 2) void c128_split_forward_kernel(const dou
 #pragma unroll
     for (int j = 0; j < 16; j++) v[j] = v[j] + sv[j] * wr;
   }
+  {
+    // W_N^{n2 k1} = W_N^{t k1} x W_N^{256 j k1}: one gather per thread and 16 uniform (scalar) loads instead of 16 gathers
+    const cd twb = ldc(WN + t * k1);
 #pragma unroll
-  for (int j = 0; j < 16; j++) v[j] = v[j] * ldc(WN + (t + 256 * j) * k1);      // W_N^{n2 k1}  (n2 k1 < N)
+    for (int j = 0; j < 16; j++) v[j] = v[j] * (twb * ldc(WN + 256 * j * k1));
+  }
   fft4096<false>(v, lds64, wa, wb, t);
   double2* dst = Xs + ((long)row * R + k1) * M + t;
 #pragma unroll
@@ -297,6 +306,7 @@ __global__ __launch_bounds__(kBlock, 2) void c128_split_corr_kernel(const double
     for (int k = 0; k < 15; k++) s_tw2[16 * k + t] = pw[k];
   }
   __syncthreads();
+  const cd twb = ldc(WN + t * k1);
   cd xs[16];
   int have = -1;
   for (int p = p0; p < p1; p++) {
@@ -315,11 +325,11 @@ __global__ __launch_bounds__(kBlock, 2) void c128_split_corr_kernel(const double
     if (p > p0) __syncthreads();                                                 // the previous transform's exchange-2 reads are complete
     fft4096<false, true>(y, lds64, wa, wb, t, s_tw2 + (t & 15));
     double2* zr = Z + ((((ul * P + p) * B + b) * R + k1) * (long)M) + t;
-    // W_N^{n2 k1}: re-read per item (L1 / L2 hits) -- resident, its 64 registers push the transform into scratch
-    const double2* twp = WN;
-    asm volatile("" : "+s"(twp));
+    // W_N^{n2 k1}, n2 = t + 256 j, as W_N^{t k1} (one value per thread, resident) x W_N^{256 j k1} (uniform over the workgroup: scalar
+    // loads): a second complex product per output instead of 16 gathers behind the transform (two workgroups per CU hide little of a
+    // dependent round trip); all 16 resident, their 64 registers push the transform into scratch
 #pragma unroll
-    for (int j = 0; j < 16; j++) stc(zr + 256 * j, y[rev16(j)] * ldc(twp + (t + 256 * j) * k1));
+    for (int j = 0; j < 16; j++) stc(zr + 256 * j, y[rev16(j)] * (twb * ldc(WN + 256 * j * k1)));
   }
 }
 
@@ -533,6 +543,113 @@ __global__ __launch_bounds__(kBlock, 2) void c128_r31_reader_kernel(const double
   }
 }
 
+// ---- N = 4096 with several blocks or carriers (GPS L1 / Xona at --time > 1: the reference CLI's own default is --time 80) in complex128 ----
+// The two-kernel form of lds_forward_kernel + lds_correlate_kernel on the complex128 transform: forward spectra once per (epoch, carrier,
+// Doppler bin, block) -- conj(FFT(x nco)), natural order, 64 KB per row --, then one workgroup per (epoch, Doppler bin, item) that holds the
+// item's code spectrum in registers, walks the B rows (C_p conj(X), inverse transform, |.| / N summed over the blocks in registers) and
+// reduces.  Nothing but X crosses HBM twice; the rocFFT pipeline it replaces moves five stage boundaries of 32 N per row and block.
+__global__ __launch_bounds__(kBlock, 2) void c128_4k_forward_kernel(XSrc x, size_t epoch_stride, double2* __restrict__ X, const double* __restrict__ freq,
+                                                                    const double2* __restrict__ tab, const double2* __restrict__ tw, int n, int FD, int B) {
+  using namespace gacq::f64;
+  extern __shared__ __attribute__((aligned(16))) double lds64[];
+  const int t = threadIdx.x;
+  const unsigned row = blockIdx.x;          // ((e*FD + fd)*B + b)
+  const int b = (int)(row % (unsigned)B);
+  const unsigned r2 = row / (unsigned)B;
+  const int fd = (int)(r2 % (unsigned)FD);
+  const long e = r2 / (unsigned)FD;
+  const double f = freq[fd];
+  const XSrc src = x.offset(e * epoch_stride + (size_t)b * n);
+  const cd wa = ldc(tw + t), wb = ldc(tw + 16 * (t & 15));
+  cd v[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const int i = t + 256 * j;
+    const double2 sv = ld_x(src, i);
+    const double2 w = tab[nco_index(f, i)];                     // gnsstools/nco.py:6-10
+    v[j] = cd{sv.x, sv.y} * cd{w.x, w.y};
+  }
+  fft4096<false>(v, lds64, wa, wb, t);
+  double2* dst = X + (long)row * kN + t;
+#pragma unroll
+  for (int j = 0; j < 16; j++) stc(dst + 256 * j, conj(v[rev16(j)]));      // np.conj(fft.fft(b))  acquire-gps-l1.py:32
+}
+
+// grid: 8 x ceil(units / 8) x P; the P workgroups of an (epoch, Doppler bin) unit run on one XCD and share its B rows in that L2
+__global__ __launch_bounds__(kBlock, 2) void c128_4k_correlate_kernel(const double2* __restrict__ X, const double2* __restrict__ C,
+                                                                      const int* __restrict__ items, const int* __restrict__ fset,
+                                                                      const double2* __restrict__ tw, RowRec64* __restrict__ rows, int E, int P, int F,
+                                                                      int D, int B) {
+  using namespace gacq::f64;
+  extern __shared__ __attribute__((aligned(16))) double lds64[];
+  __shared__ double s_peak[kBlock / 64], s_sum[kBlock / 64];
+  __shared__ int s_idx[kBlock / 64];
+  __shared__ cd s_tw2[15 * 16];
+  const int t = threadIdx.x;
+  const unsigned xcd = blockIdx.x & 7u, jx = blockIdx.x >> 3;
+  const int p = (int)(jx % (unsigned)P);
+  const unsigned u = (jx / (unsigned)P) * 8u + xcd;
+  if (u >= (unsigned)E * (unsigned)D) return;
+  const long e = u / (unsigned)D;
+  const int d = (int)(u % (unsigned)D);
+  const cd wa = ldc(tw + t), wb = ldc(tw + 16 * (t & 15));
+  if (t < 16) {
+    cd pw[15];
+    make_powers(pw, conj(wb));                            // pass-2 powers of the inverse transform, as in fused4k_c128_kernel
+#pragma unroll
+    for (int k = 0; k < 15; k++) s_tw2[16 * k + t] = pw[k];
+  }
+  cd c[16];
+  {
+    const double2* cp = C + (long)items[p] * kN + t;
+#pragma unroll
+    for (int j = 0; j < 16; j++) c[j] = ldc(cp + 256 * j);
+  }
+  const double2* xs = X + ((((long)e * F + fset[p]) * D + d) * (long)B) * kN + t;
+  const double inv_n = 1.0 / (double)kN;
+  double q[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) q[k] = 0.0;
+  __syncthreads();
+  for (int b = 0; b < B; b++) {
+    cd v[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) v[j] = ldc(xs + (long)b * kN + 256 * j);
+#pragma unroll
+    for (int j = 0; j < 16; j++) v[j] = c[j] * v[j];                             // C_p * np.conj(fft.fft(b))
+    if (b > 0) __syncthreads();                                                  // the previous transform's exchange-2 reads are complete
+    fft4096<true, true, true>(v, lds64, wa, wb, t, s_tw2 + (t & 15));
+    asm volatile("s_setprio 0" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 16; k++) {                                               // lane t holds lags t + 256 k
+      const cd r = v[rev16(k)];
+      q[k] += sqrt_pos(r.x * r.x + r.y * r.y) * inv_n;                           // np.absolute(ifft(...)), summed over the blocks
+    }
+  }
+  double sum = 0.0, lmax = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) { sum += q[k]; lmax = fmax(lmax, q[k]); }
+  double peak = wave_max_pos_f64(lmax);
+  int idx = 0x7fffffff;
+#pragma unroll
+  for (int k = 15; k >= 0; k--) {                                                // descending: the last assignment is the smallest k
+    const unsigned long long mk = __builtin_amdgcn_ballot_w64(q[k] == peak);
+    if (mk) idx = 256 * k + (t & ~63) + (int)__builtin_ctzll(mk);
+  }
+  sum = wave_add_f64(sum);
+  if ((t & 63) == 0) { s_peak[t >> 6] = peak; s_idx[t >> 6] = idx; s_sum[t >> 6] = sum; }
+  __syncthreads();
+  if (t == 0) {
+    for (int w = 1; w < kBlock / 64; w++) {
+      if (s_peak[w] > peak || (s_peak[w] == peak && s_idx[w] < idx)) { peak = s_peak[w]; idx = s_idx[w]; }
+      sum += s_sum[w];
+    }
+    RowRec64 r;
+    r.peak = peak; r.sum = sum; r.idx = idx; r.pad = 0;
+    rows[(e * P + p) * (long)D + d] = r;
+  }
+}
+
 // W_4096^k in fp64 (sincospi on the exactly reduced argument, device-side)
 __global__ void twiddle4096_64_kernel(double2* __restrict__ w) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -645,7 +762,8 @@ static int split64_search(gacq_sig* sig, XSrc d_x, size_t nsamp, int nepoch, int
     hipLaunchKernelGGL(mix64_kernel, dim3((unsigned)(rows_x * cols)), dim3(kBlock), 0, st, d_x.offset((size_t)e0 * nsamp), nsamp, (double2*)ctx->Y.p,
                        (const double*)ctx->freq.p, tab, n, N, F * D, B, cols);
     GACQ_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(c128_split_forward_kernel<R>, dim3((unsigned)(rows_x * R)), dim3(kBlock), f64::kLdsBytes, st, (const double2*)ctx->Y.p, Xs, WN);
+    hipLaunchKernelGGL(c128_split_forward_kernel<R>, dim3((unsigned)(((rows_x + 7) / 8) * 8 * R)), dim3(kBlock), f64::kLdsBytes, st, (const double2*)ctx->Y.p, Xs, WN,
+                       (unsigned)rows_x);
     stage_end(ctx);
     GACQ_HIP(ctx, hipGetLastError());
     // Z' passes of whole (epoch, Doppler bin) units, P items each: at most 4 GiB a pass, as in the fp32 split engines
@@ -787,6 +905,39 @@ int verify_search(gacq_sig* sig, XSrc d_x, size_t nsamp, int nepoch, int P, int 
     hipLaunchKernelGGL(best_doppler64_kernel, dim3((unsigned)((nep + 63) / 64)), dim3(64), 0, st, (const RowRec64*)rows, d_out, nep, D, N, sig->desc.metric_mode);
     stage_end(ctx);
     GACQ_HIP(ctx, hipGetLastError());
+    return GACQ_OK;
+  }
+  if (N == 4096 && !d_qrow && ctx->opt[GACQ_OPT_FUSED_C128]) {
+    // several blocks or carriers: forward spectra once, then one workgroup per (epoch, Doppler bin, item) over its B rows
+    const double2* tw;
+    if ((rc = twiddle64_4096(ctx, &tw)) != GACQ_OK) return rc;
+    const size_t x_epoch_bytes = sizeof(double2) * (size_t)F * D * B * N;
+    const int Ec = (int)std::max<size_t>(1, std::min<size_t>((size_t)nepoch, ws_budget(ctx) / std::max<size_t>(1, x_epoch_bytes)));
+    if ((rc = ensure(ctx, ctx->X, x_epoch_bytes * Ec)) != GACQ_OK) return rc;
+    if ((rc = ensure(ctx, ctx->rows, sizeof(RowRec64) * (size_t)Ec * P * D)) != GACQ_OK) return rc;
+    GACQ_HIP(ctx, hipFuncSetAttribute((const void*)c128_4k_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, gacq::f64::kLdsBytes));
+    GACQ_HIP(ctx, hipFuncSetAttribute((const void*)c128_4k_correlate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, gacq::f64::kLdsBytes));
+    for (int e0 = 0; e0 < nepoch; e0 += Ec) {
+      const int ne = std::min(Ec, nepoch - e0);
+      RowRec64* rows = (RowRec64*)ctx->rows.p;
+      const long rows_x = (long)ne * F * D * B;
+      stage_begin(ctx, 0);
+      hipLaunchKernelGGL(c128_4k_forward_kernel, dim3((unsigned)rows_x), dim3(kBlock), gacq::f64::kLdsBytes, st, d_x.offset((size_t)e0 * nsamp), nsamp, (double2*)ctx->X.p,
+                         (const double*)ctx->freq.p, tab, tw, n, F * D, B);
+      stage_end(ctx);
+      GACQ_HIP(ctx, hipGetLastError());
+      const long units8 = ((long)ne * D + 7) / 8;
+      stage_begin(ctx, 6);
+      hipLaunchKernelGGL(c128_4k_correlate_kernel, dim3((unsigned)(8 * units8 * P)), dim3(kBlock), gacq::f64::kLdsBytes, st, (const double2*)ctx->X.p,
+                         (const double2*)sig->spectra64, (const int*)ctx->items.p, (const int*)ctx->fset.p, tw, rows, ne, P, F, D, B);
+      stage_end(ctx);
+      GACQ_HIP(ctx, hipGetLastError());
+      const long nep = (long)ne * P;
+      stage_begin(ctx, 5);
+      hipLaunchKernelGGL(best_doppler64_kernel, dim3((unsigned)((nep + 63) / 64)), dim3(64), 0, st, (const RowRec64*)rows, d_out + (size_t)e0 * P, nep, D, N, sig->desc.metric_mode);
+      stage_end(ctx);
+      GACQ_HIP(ctx, hipGetLastError());
+    }
     return GACQ_OK;
   }
   // N = 4 x 4096 / 16 x 4096: the hand-written split form (one Z' round trip, no rocFFT plan); GACQ_OPT_FUSED_C128 = 0 keeps the pipeline

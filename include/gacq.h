@@ -104,7 +104,8 @@ int gacq_use_null_stream(gacq_ctx* ctx);
  * 4 = split engine with the inner transforms on the LDS FFT kernels (N = 65536, 16384),
  * 5 = complex128 engine (any N): every value in fp64 on the device, as the reference computes (numpy complex128); agrees with it
  *     to ~1e-12 and is what a near-tie disagreement of an fp32 engine is bisected against.  N = 4096 with one block and one carrier
- *     runs as ONE fused kernel (fp64 transform resident in LDS); N = 16384 and 65536 (B1I / B2I, GLONASS, E1B / E1C) as the split
+ *     runs as ONE fused kernel (fp64 transform resident in LDS), with several blocks or carriers as a forward + a correlate kernel on the
+ *     same transform; N = 16384 and 65536 (B1I / B2I, GLONASS, E1B / E1C) as the split
  *     form 4 x / 16 x 4096 on the same transform -- forward spectra shared by the items, one Z' round trip of 32 N bytes per row and
  *     block, no rocFFT plan; N = 61380 / 30690 (the 10.23 Mcps scripts, E6, Xona X5) as 31 x M with hand-written fp64 DFT-31 stages
  *     around rocFFT's native length-M double transforms, which keeps the prime 31 out of rocFFT's Bluestein path (all three:

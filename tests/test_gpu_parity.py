@@ -1359,10 +1359,12 @@ def test_fp32_engines_agree_with_the_complex128_engine_on_near_ties(engine):
                                                 ("beidou-b1i", [6, 7, 33], [1000.0, 2000.0, 250.0], 3, 2),               # N = 16384, B = 3, padded
                                                 ("glonass-l1", [-7, 0, 3, 6], [1000.0, 2000.0, 500.0], 2, 1),            # a carrier per item
                                                 ("gps-l5i", [3, 17, 32], [-400.0, 400.0, 200.0], 2, 2),                 # N = 61380 = 31 x 1980, B = 2
-                                                ("galileo-e6b", [1, 50], [0.0, 600.0, 200.0], 3, 1)])                   # N = 30690 = 31 x 990
+                                                ("galileo-e6b", [1, 50], [0.0, 600.0, 200.0], 3, 1),                    # N = 30690 = 31 x 990
+                                                ("gps-l1", [3, 11, 28], [-750.0, 750.0, 250.0], 3, 2)])                 # N = 4096, B = 3: the two-kernel form
 def test_complex128_split_form_equals_the_rocfft_double_pipeline(engine, name, items, ds, ms, E):
     """Engine 5 beyond N = 4096 on hand-written kernels (round 6) against the five-stage pipeline on rocFFT's double-precision transforms it
-    replaces (option fused_c128 = 0): N = 4 x 4096 / 16 x 4096 as the split form -- forward spectra shared by the items, one Z' round trip on
+    replaces (option fused_c128 = 0): N = 4096 with several blocks as forward + correlate kernels on the LDS-resident complex128 transform;
+    N = 4 x 4096 / 16 x 4096 as the split form -- forward spectra shared by the items, one Z' round trip on
     the LDS-resident complex128 transform, no rocFFT plan --; N = 31 x M with fp64 DFT-31 stages around rocFFT's native length-M transforms (no
     Bluestein).  The same locations and metrics to 1e-12 (both are fp64 throughout; only the butterfly order differs) and the magnitude row of
     one search to float32 resolution."""
@@ -1378,7 +1380,7 @@ def test_complex128_split_form_equals_the_rocfft_double_pipeline(engine, name, i
         got = eng.search_batch_dev(sig, xd, items, dop, B)
         torch.cuda.synchronize()
         got = got.cpu().numpy().view(acquire.PEAK_DTYPE)
-        assert eng.fft_plans() == (0 if sig.nfft in (16384, 65536) else 2)          # 31 x M: the length-M forward and inverse plans
+        assert eng.fft_plans() == (0 if sig.nfft in (4096, 16384, 65536) else 2)    # 31 x M: the length-M forward and inverse plans
         row = eng.debug_row(sig, xs[0], items[1], float(dop[1]), B)
         eng.set_option("fused_c128", 0)
         ref = eng.search_batch_dev(sig, xd, items, dop, B)
