@@ -148,7 +148,9 @@ template <bool INV> __device__ __forceinline__ void dft32_finish(v2 (&v)[kP], co
 }
 
 // Wave priorities (s_setprio) at the segment ends of a row.  Two waves share a SIMD: the one that has just issued the LDS accesses
-// that end its segment steps down so that the other's arithmetic runs under the round trip.
+// that end its segment steps down so that the other's arithmetic runs under the round trip.  Ten assignments of the three levels,
+// none included, measured within +-3 % of each other (profiles/r06_16k_radix32_experiments.log, section 7): what the waves wait for
+// is the CU's one LDS pipe, which the four SIMDs' waves reach together, not each other's arithmetic.
 #ifndef GACQ_R32_PA
 #define GACQ_R32_PA 2       // after the cross-wave gather: last DFT32 + magnitudes
 #define GACQ_R32_PB 3       // after the staged row has been read: C * x + two DFT16
