@@ -309,6 +309,7 @@ def condense(o, wall_s):
          "traffic_measured_bytes_per_launch": r.get("traffic"),
          "traffic_measured_in_this_run": bool((r.get("traffic_source") or {}).get("measured_in_this_run")),
          "ms_per_step_by_signal": {pj["signal"]: sum(st["ms_per_step"] for st in pj["stages"].values()) for pj in o["pipeline"]["per_signal"]},
+         "steps_in_flight": o["config"].get("steps_in_flight"), "one_step_in_flight": o["config"].get("one_step_in_flight"),
          "wall_s": wall_s}
     if d["traffic_measured_bytes_per_launch"] and d["compulsory_hbm_bytes_per_launch"]:
         d["traffic_over_compulsory"] = d["traffic_measured_bytes_per_launch"] / d["compulsory_hbm_bytes_per_launch"]
@@ -719,9 +720,13 @@ def main():
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="gacq_set_option tuning switch (e.g. lds_variant=3)")
     ap.add_argument("--distinct-epochs", type=int, default=0, help="N = 4096 signals: distinct seeded epochs per step, tiled to the batch (default: all 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lanes", type=int, default=1,
-                    help="engine contexts / HIP streams the independent steps alternate between (2 fills the correlate kernel's tail, "
-                         "+3.5 %%, but overlapping launches make per-kernel durations meaningless for the roofline line)")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="steps in flight: engine contexts, each on a HIP stream with a hardware queue of its own, that consecutive "
+                         "(independent) steps alternate between.  2 (default): the end of one step -- ragged last round of workgroups, the "
+                         "small launches that close a search -- runs under the next step's kernels, and memory-bound and arithmetic-bound "
+                         "searches of a mixed step overlap; the line carries the one-step-in-flight time measured in the same process "
+                         "(roofline.ab.steps_in_flight).  Kernel durations for the roofline come from the profiling pass, which keeps ONE "
+                         "step in flight: overlapped launches have no meaningful duration of their own")
     ap.add_argument("--no-latency", action="store_true",
                     help="skip the single-epoch host-call latency probe (profiling runs: keeps every launch the bench workload)")
     ap.add_argument("--sustained-s", type=float, default=1.5, help="length of the second, sustained timed region (0 = skip)")
@@ -790,7 +795,6 @@ def main():
             a = argparse.Namespace(**vars(args))
             a.config, a.epochs, a.steps, a.warmup, a.sustained_s, a.preroll_s = k, 0, 5, 1, 1.0, 0.2
             a.no_cpu_baseline = a.no_latency = True
-            a.lanes = 1
             t1 = time.perf_counter()
             try:
                 others.append(condense(run(a, env), time.perf_counter() - t1))
@@ -812,6 +816,8 @@ def main():
             ab["n16384_transform"] = ab_n16384(args, env)
         except Exception as exc:
             ab["n16384_transform"] = {"error": repr(exc)[:300]}
+        if out["config"].get("one_step_in_flight"):
+            ab["steps_in_flight"] = {"one_ms_per_step": out["config"]["one_step_in_flight"]["ms_per_step"], "%d_ms_per_step" % out["config"]["steps_in_flight"]: out["ms_per_step"]}
         ts = out.get("tie_safe") or {}
         if "ms_per_step_with_tie_safe_off" in ts:
             ab["tie_safe_locations"] = {"on_ms_per_step": out["ms_per_step"], "off_ms_per_step": ts["ms_per_step_with_tie_safe_off"]}
@@ -1013,9 +1019,12 @@ def run(args, env):
     # all-gather of step i runs under the kernels of step i+1 (asynchronous collective, merge deferred by one step); with
     # --lanes 2 the steps also alternate between two engine contexts with their own HIP streams and workspaces.  Every step
     # runs all of its kernels, the exchange and the merge inside the timed region.
-    lanes = []
+    lanes, own_queues = [], []
     for _ in range(max(1, args.lanes)):
-        st = torch.cuda.Stream(dev)
+        # a stream with a hardware queue of its own: plain HIP streams are multiplexed over a few queues, and two lanes that land on the
+        # same one would run one after the other (acquire.MaskedStream; tools/exp_lanes_debug.py: the overlap was there or not by luck)
+        own_queues.append(acquire.MaskedStream(local_rank))
+        st = own_queues[-1].torch_stream
         e2 = make_engine()
         with torch.cuda.stream(st):
             lanes.append((st, e2, sharded.ShardedSearch(engine=e2, always_gather=args.force_gather)))
@@ -1043,6 +1052,12 @@ def run(args, env):
         preroll["seconds"] = time.perf_counter() - t0
     run_steps(args.warmup)
     merged, dt = timed(args.steps)
+    one_lane = None
+    if len(lanes) > 1:
+        # the same K steps with ONE step in flight (lane 0 only), same process, right after the timed region: what the second step in
+        # flight is worth (roofline.ab.steps_in_flight) and the step time the profiling pass's kernel durations belong to
+        _, dt_one = make_timed(make_run_steps([((lambda st=lanes[0][0]: torch.cuda.stream(st)), lanes[0][2])], jobs), dev, use_dist)(args.steps)
+        one_lane = {"steps_in_flight": 1, "ms_per_step": dt_one / args.steps * 1e3, "value": cells_step * args.steps / dt_one}
     plain_ratio = None
     if use_dist and world == 1:
         # launched by torch.distributed.run with one rank: the same K steps once more without the barrier / MAX-reduce bracket of the
@@ -1069,6 +1084,10 @@ def run(args, env):
             if dt_sus >= args.sustained_s:
                 break
         sustained = {"steps": k_sus, "seconds": dt_sus, "ms_per_step": dt_sus / k_sus * 1e3, "value": cells_step * k_sus / dt_sus, "clocks": clocks}
+        if one_lane is not None:
+            # the one-step-in-flight comparison over a region of the same length (same clocks regime as `sustained`)
+            _, dt_one_sus = make_timed(make_run_steps([((lambda st=lanes[0][0]: torch.cuda.stream(st)), lanes[0][2])], jobs), dev, use_dist)(k_sus)
+            one_lane["sustained"] = {"steps": k_sus, "seconds": dt_one_sus, "ms_per_step": dt_one_sus / k_sus * 1e3, "value": cells_step * k_sus / dt_one_sus}
 
     # ---- correctness of what was just computed (not timed) ----------------------------------------------------------
     # (a) every rank received `world` shards: one more step with the un-merged exchange buffer kept -- noise alone gives
@@ -1230,7 +1249,7 @@ def run(args, env):
     under_profiler = any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ)       # never nest profilers
     if world == 1 and rank == 0 and not args.no_pmc and not under_profiler and not os.environ.get("GACQ_BENCH_PMC_CHILD"):
         child = ["--gpus", "1", "--config", str(args.config), "--epochs", str(epochs), "--steps", "3", "--warmup", "1", "--engine", str(args.engine),
-                 "--no-cpu-baseline", "--no-latency", "--sustained-s", "0", "--preroll-s", "0", "--no-pmc", "--no-others", "--lanes", str(args.lanes)]
+                 "--no-cpu-baseline", "--no-latency", "--sustained-s", "0", "--preroll-s", "0", "--no-pmc", "--no-others", "--lanes", "1"]
         for kv in args.option:
             child += ["--option", kv]
         if args.no_self_check:
@@ -1348,7 +1367,7 @@ def run(args, env):
                        "cells_per_step": cells_step, "cell_blocks_per_step": cell_blocks_step, "sharding": sharding,
                        "shards_seen_by_every_rank": shards_seen,
                        "engine": {0: "auto", 1: "rocfft", 2: "lds-fft", 3: "split", 4: "split-lds", 5: "complex128"}[args.engine],
-                       "steps_in_flight": len(lanes)},
+                       "steps_in_flight": len(lanes), "one_step_in_flight": one_lane},
             "preroll": preroll,
             "sustained": sustained,
             "roofline": roofline,
@@ -1411,9 +1430,12 @@ def run(args, env):
             out["cpu_baseline"] = None
     else:
         out = None
+    torch.cuda.synchronize(dev)
     for _, e2, _ in lanes:
         e2.close()
     eng.close()
+    for q in own_queues:
+        q.close()
     return out
 
 

@@ -169,6 +169,9 @@ SYMBOLS = {
                                                 c_double_p, c_double_p, c_double_p, ctypes.c_int, c_double_p]),
     "gacq_mix_int8_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]),
     "gacq_stream_probe": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, c_double_p]),
+    "gacq_stream_create_cu_mask": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_uint32), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "gacq_stream_destroy": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p]),
+    "gacq_cu_census": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32)]),
     "gacq_set_profiling": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "gacq_get_stage_time": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_double_p, ctypes.POINTER(ctypes.c_long)]),
     "gacq_reset_stage_times": (ctypes.c_int, [ctypes.c_void_p]),

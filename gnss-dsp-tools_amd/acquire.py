@@ -100,6 +100,47 @@ class AcqSignal:
         return out
 
 
+class MaskedStream:
+    """A HIP stream with a hardware queue of its own (gacq_stream_create_cu_mask), optionally limited to `cus` of the device's compute
+    units: the low `cus` bits of the mask, which the driver deals round-robin over the XCDs (cus / 8 CUs of every XCD); cus = None
+    selects every CU.  Why not a plain stream: the HIP runtime multiplexes plain streams over a few hardware queues (four by default),
+    and two streams that land on the same queue run their kernels one after the other however independent they are; a stream created
+    with a CU mask always gets its own queue, so work on two of them really runs side by side (tools/exp_lanes_debug.py).
+    `.handle` is the hipStream_t for Engine.set_stream; `.torch_stream` wraps it as a torch.cuda.ExternalStream, so torch's allocator
+    and wait_stream() see it."""
+
+    def __init__(self, device, cus=None, total_cus=None):
+        if total_cus is None:
+            total_cus = nat.require_torch().cuda.get_device_properties(int(device)).multi_processor_count       # 256 on MI355X
+        cus = int(total_cus if cus is None else cus)
+        if not 0 < cus <= total_cus:
+            raise ValueError("cus must be in 1..%d" % total_cus)
+        nwords = (total_cus + 31) // 32
+        words = (ctypes.c_uint32 * nwords)(*[((1 << max(0, min(32, cus - 32 * i))) - 1) & 0xffffffff for i in range(nwords)])
+        h = ctypes.c_void_p()
+        nat.check(nat.lib.gacq_stream_create_cu_mask(int(device), words, nwords, ctypes.byref(h)))
+        self.device, self.cus, self.handle = int(device), cus, h.value
+        self._torch_stream = None
+
+    @property
+    def torch_stream(self):
+        if self._torch_stream is None:
+            torch = nat.require_torch()
+            self._torch_stream = torch.cuda.ExternalStream(self.handle, device=torch.device("cuda", self.device))
+        return self._torch_stream
+
+    def close(self):
+        if self.handle:
+            nat.lib.gacq_stream_destroy(self.device, ctypes.c_void_p(self.handle))
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Engine:
     """One acquisition context bound to one GPU (one process per GPU).  Like the gacq_ctx it wraps, an Engine is single-threaded:
     the plan cache, the reusable result buffer and the library's workspaces are per context -- use one Engine per thread."""
@@ -166,6 +207,13 @@ class Engine:
         v = ctypes.c_double()
         nat.check(nat.lib.gacq_stream_probe(self._ctx, {"fill": 0, "read": 1, "copy": 2, "fill_read": 3, "fill_plain": 4, "read_plain": 5, "fill_read_plain": 6}[kind], int(nbytes), int(reps), ctypes.byref(v)), self._ctx)
         return v.value
+
+    def cu_census(self, nworkgroups=4096):
+        """gacq_cu_census: the distinct (xcc, se, sh, cu) places the workgroups of one launch on the context's current stream ran on,
+        as a sorted list of (xcc, se, sh, cu) tuples -- what a CU-masked stream really selects."""
+        w = np.zeros(int(nworkgroups), dtype=np.uint32)
+        nat.check(nat.lib.gacq_cu_census(self._ctx, int(nworkgroups), w.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))), self._ctx)
+        return sorted({(int(v) >> 8, (int(v) >> 5) & 7, (int(v) >> 4) & 1, int(v) & 15) for v in w})
 
     def set_profiling(self, on):
         nat.check(nat.lib.gacq_set_profiling(self._ctx, int(bool(on))), self._ctx)

@@ -104,3 +104,66 @@ extern "C" int gacq_stream_probe(gacq_ctx* ctx, int kind, size_t bytes, int reps
   cleanup();
   return rc;
 }
+
+// ---- streams restricted to a subset of the CUs --------------------------------------------------------------------------------
+// A cold-start search runs signals of two kinds back to back: LDS-resident transforms (N <= 16384; the vector pipes bind them and one
+// workgroup owns a CU's register file) and split transforms with a Z' round trip through HBM (N = 65536, 61380; the memory system binds
+// them).  Launched on two streams they share the chip: the memory-bound kernels hide under the arithmetic of the others.  A CU mask on the
+// memory-bound stream keeps its many small workgroups on a fixed set of CUs, so that they do not keep the large workgroups of the other
+// stream from ever finding an empty CU (ShardedSearch.search_jobs_async, bench.py config 5).
+namespace {
+
+__global__ void cu_census_kernel(unsigned* __restrict__ out, int spin) {
+  unsigned hw, xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  // stay resident for a while, so that the workgroups of one launch spread over every CU the stream may use
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < spin) __builtin_amdgcn_s_sleep(8);
+  // HW_ID (gfx9): cu_id [11:8], sh_id [12], se_id [15:13]; XCC_ID: xcc_id [3:0]
+  if (threadIdx.x == 0) out[blockIdx.x] = ((xcc & 15u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
+}
+
+}  // namespace
+
+extern "C" int gacq_stream_create_cu_mask(int device, const uint32_t* cu_mask, int nwords, void** stream_out) {
+  if (!stream_out) return set_error(nullptr, GACQ_ERR_BAD_ARG, "gacq_stream_create_cu_mask: stream_out is NULL");
+  *stream_out = nullptr;
+  if (!cu_mask || nwords <= 0 || nwords > 32 || device < 0 || device >= gacq_device_count())
+    return set_error(nullptr, GACQ_ERR_BAD_ARG, "gacq_stream_create_cu_mask: device in range, 1..32 mask words");
+  bool any = false;
+  for (int i = 0; i < nwords; i++) any |= cu_mask[i] != 0;
+  if (!any) return set_error(nullptr, GACQ_ERR_BAD_ARG, "gacq_stream_create_cu_mask: empty mask");
+  DeviceGuard guard(device);
+  hipStream_t st = nullptr;
+  if (!guard.ok || hipExtStreamCreateWithCUMask(&st, (uint32_t)nwords, cu_mask) != hipSuccess) {
+    (void)hipGetLastError();
+    return set_error(nullptr, GACQ_ERR_HIP, "gacq_stream_create_cu_mask: hipExtStreamCreateWithCUMask failed on device %d", device);
+  }
+  *stream_out = (void*)st;
+  return GACQ_OK;
+}
+
+extern "C" int gacq_stream_destroy(int device, void* stream) {
+  if (!stream) return GACQ_OK;
+  DeviceGuard guard(device);
+  if (!guard.ok || hipStreamSynchronize((hipStream_t)stream) != hipSuccess || hipStreamDestroy((hipStream_t)stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return set_error(nullptr, GACQ_ERR_HIP, "gacq_stream_destroy: failed on device %d", device);
+  }
+  return GACQ_OK;
+}
+
+extern "C" int gacq_cu_census(gacq_ctx* ctx, int nworkgroups, unsigned* where) {
+  if (!ctx || !where || nworkgroups <= 0 || nworkgroups > (1 << 16))
+    return set_error(ctx, GACQ_ERR_BAD_ARG, "gacq_cu_census: 1 <= nworkgroups <= 65536");
+  GACQ_DEVICE(ctx);
+  unsigned* d = nullptr;
+  if (hipMalloc((void**)&d, sizeof(unsigned) * nworkgroups) != hipSuccess) { (void)hipGetLastError(); return set_error(ctx, GACQ_ERR_HIP, "gacq_cu_census: allocation failed"); }
+  hipLaunchKernelGGL(cu_census_kernel, dim3(nworkgroups), dim3(64), 0, ctx->stream, d, 20000);      // 100 MHz counter: 0.2 ms
+  int rc = GACQ_OK;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(where, d, sizeof(unsigned) * nworkgroups, hipMemcpyDeviceToHost) != hipSuccess || hipGetLastError() != hipSuccess)
+    rc = set_error(ctx, GACQ_ERR_HIP, "gacq_cu_census: launch failed");
+  (void)hipFree(d);
+  return rc;
+}

@@ -9,6 +9,8 @@ code spectra.  The path has exactly ONE exchange step: an all-gather of the per-
 strict '>' so ties resolve to the lowest Doppler bin exactly like the reference's scan
 (acquire-gps-l1.py:36-39).  A plain max all-reduce would lose that tie rule.
 """
+import contextlib
+
 import numpy as np
 
 from . import acquire
@@ -46,6 +48,45 @@ class ShardedSearch:
         self.always_gather = always_gather          # run the collective + merge even for world_size 1 (tests)
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._lanes, self._lane_order = [], "cost"
+
+    def enable_job_lanes(self, n=2, options=None, order="cost", cus=None):
+        """Searches of several signals (search_jobs): run the jobs side by side on `n` contexts with their own HIP streams (this one
+        plus n - 1 more), as the reference runs its searches side by side (Pool(32), acquire-gps-l1.py:105-108).  The large kernels
+        of one job own the device while they run (the N = 16384 transforms hold a CU's whole register file), so this is not about
+        sharing CUs between them: what runs under the next job's kernels is the END of a job -- the ragged last round of a long
+        kernel's workgroups, the small latency-bound launches that close a search (Doppler scan, tie-safe re-evaluation, record
+        writes).  Jobs are queued in descending cost (cells x blocks), job k on lane k mod n, so the longest tails are covered and
+        the cheapest job closes the step.  Results are the same records in the same order.  `cus` limits the extra lanes to that many
+        compute units (experiments: keeping the memory-bound searches on a few CUs next to the others was measured and is slower,
+        profiles/r06_config5_clocks_and_overlap.log)."""
+        if self.engine is None:
+            raise RuntimeError("job lanes: needs an engine (the CPU test stand-in has no streams)")
+        import torch
+        self.close_job_lanes()
+        self._lane_order = order
+        for _ in range(max(0, int(n) - 1)):
+            eng = acquire.Engine(self.engine.device)
+            for k, v in (options or {}).items():
+                eng.set_option(k, int(v))
+            own = acquire.MaskedStream(self.engine.device, cus)   # every CU by default, but a hardware queue of its own (see MaskedStream)
+            self._lanes.append((eng, own.torch_stream, own))
+        return self
+
+    def close_job_lanes(self):
+        import torch
+        for eng, st, own in getattr(self, "_lanes", []):
+            torch.cuda.synchronize(eng.device)
+            eng.close()
+            own.close()
+        self._lanes = []
+
+    @staticmethod
+    def _job_cost(job):
+        name = job["family"][0] if job.get("family") else job["name"]
+        sig = acquire._signals.get(name) if isinstance(name, str) else name
+        nitems = sum(len(i) for i in job["items"]) if job.get("family") else len(job["items"])
+        return float(nitems) * len(job["dopplers"]) * sig.nfft * int(job["blocks"]) * int(job["x"].shape[0])
 
     def partition(self, nd, nitems):
         """SURVEY 8e: cut the Doppler grid while every rank still gets >= 4 bins (forward FFTs are not duplicated);
@@ -134,24 +175,41 @@ class ShardedSearch:
         PendingJobs.wait(): queueing the next step before waiting puts the exchange under the next step's kernels.
         Every job's x must stay alive and unmodified until wait() returns (see search_batch_async)."""
         import torch
-        locals_, bounds, shapes = [], [], []
-        for job in jobs:
+        locals_, bounds, shapes = [None] * len(jobs), [None] * len(jobs), [None] * len(jobs)
+        lanes = getattr(self, "_lanes", []) if (self.local_fn is None and len(jobs) > 1) else []
+        order = list(range(len(jobs)))
+        if lanes:
+            if self._lane_order == "cost":
+                order.sort(key=lambda i: -self._job_cost(jobs[i]))
+            elif not isinstance(self._lane_order, str):
+                order = list(self._lane_order)                   # an explicit queueing order (experiments)
+            cur = torch.cuda.current_stream(jobs[0]["x"].device)
+            for _, st, _ in lanes:
+                st.wait_stream(cur)                              # the samples were produced on the caller's stream
+        for k, ji in enumerate(order):
+            job = jobs[ji]
             dop = np.ascontiguousarray(job["dopplers"], dtype=np.float64)
             b = doppler_bounds(len(dop), self.world)
             lo, hi = b[self.rank], b[self.rank + 1]
-            if self.local_fn is not None:
-                loc = self.local_fn(job["name"], job["x"], job["items"], dop[lo:hi], job["blocks"])
-            elif job.get("family"):
-                # several signals sharing everything but their code tables (E1B + E1C): `family` = signal names, `items` = one
-                # item list per signal; one stacked signal, forward transforms shared
-                self.engine.use_torch_stream(job["x"].device)
-                loc = self.engine.search_family_batch_dev(job["family"], job["x"], job["items"], dop[lo:hi], job["blocks"])
-            else:
-                self.engine.use_torch_stream(job["x"].device)
-                loc = self.engine.search_batch_dev(job["name"], job["x"], job["items"], dop[lo:hi], job["blocks"])
-            locals_.append(loc.contiguous())
-            bounds.append(b)
-            shapes.append(tuple(loc.shape))
+            lane = k % (len(lanes) + 1) if lanes else 0          # lane 0: this context on the caller's stream
+            engine = lanes[lane - 1][0] if lane else self.engine
+            with (torch.cuda.stream(lanes[lane - 1][1]) if lane else contextlib.nullcontext()):
+                if self.local_fn is not None:
+                    loc = self.local_fn(job["name"], job["x"], job["items"], dop[lo:hi], job["blocks"])
+                elif job.get("family"):
+                    # several signals sharing everything but their code tables (E1B + E1C): `family` = signal names, `items` = one
+                    # item list per signal; one stacked signal, forward transforms shared
+                    engine.use_torch_stream(job["x"].device)
+                    loc = engine.search_family_batch_dev(job["family"], job["x"], job["items"], dop[lo:hi], job["blocks"])
+                else:
+                    engine.use_torch_stream(job["x"].device)
+                    loc = engine.search_batch_dev(job["name"], job["x"], job["items"], dop[lo:hi], job["blocks"])
+                loc = loc.contiguous()
+            if lane:
+                loc.record_stream(cur)                           # allocated on the lane's stream, consumed on the caller's
+            locals_[ji], bounds[ji], shapes[ji] = loc, b, tuple(loc.shape)
+        for _, st, _ in lanes:
+            cur.wait_stream(st)                                  # join: the exchange / the caller reads every job's records
         if self._solo():
             return PendingJobs(self, locals_, None, None, shapes, bounds, jobs)
         flat = torch.cat([t.view(-1) for t in locals_])

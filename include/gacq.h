@@ -374,6 +374,18 @@ const char* gacq_stage_name(int stage);
  * (roofline.stream_ceiling), measured in the run that reports it.  Synchronous; allocates and frees its own buffers. */
 int gacq_stream_probe(gacq_ctx* ctx, int kind, size_t bytes, int reps, double* gbytes_per_s);
 
+/* A HIP stream whose kernels run on a subset of the device's compute units (hipExtStreamCreateWithCUMask; bit b of the mask = logical
+ * CU b, which the driver deals round-robin over the XCDs, so the low m bits are m / 8 CUs of every XCD).  For searches of several
+ * signals run side by side (the reference runs its PRNs side by side in a Pool, acquire-gps-l1.py:105-108; a cold start searches
+ * several signals): the contexts of the memory-bound signals (N = 65536, 61380: Z' round trip through HBM) get a masked stream with
+ * gacq_set_stream, the others keep the whole device, and the memory-bound kernels run under the arithmetic of the others
+ * (ShardedSearch.search_jobs_async).  The stream is the caller's: destroy it with gacq_stream_destroy after the contexts that used it. */
+int gacq_stream_create_cu_mask(int device_id, const uint32_t* cu_mask, int nwords, void** hip_stream_out);
+int gacq_stream_destroy(int device_id, void* hip_stream);
+/* Where the workgroups of a launch on the ctx stream land: where[i] = xcc_id << 8 | se_id << 5 | sh_id << 4 | cu_id of workgroup i
+ * (nworkgroups one-wave workgroups that stay resident 0.2 ms each) -- how tests and tools check what a CU mask selects. */
+int gacq_cu_census(gacq_ctx* ctx, int nworkgroups, unsigned* where);
+
 /* Full accumulated magnitude row q[0..N) for one (item, doppler) -- debugging / golden rows. */
 int gacq_debug_row(gacq_sig* sig, const float* x_iq, size_t nsamp, int item, double doppler,
                    double bias_hz, int blocks, float* q_out);

@@ -602,6 +602,13 @@ def test_bench_measures_hbm_traffic_live_with_pmc_child_runs():
     assert nr["longcode_l2cl"]["k_found"] == nr["longcode_l2cl"]["k_injected"] and nr["longcode_glonass_p"]["k_found"] == nr["longcode_glonass_p"]["k_injected"]
     assert 0.0 < nr["tracking_epl"]["us_resident_block"] < nr["tracking_epl"]["us_host_block"] < 500.0
     assert j["tie_safe"]["enabled"] is True and j["tie_safe"]["kept_fp32"] == 0, j["tie_safe"]
+    # round 6: two steps in flight on hardware queues of their own by default; the one-step-in-flight time of the same process is in the
+    # line, and the profiling pass (one step in flight) holds the kernel time against its own step time
+    assert j["config"]["steps_in_flight"] == 2 and j["config"]["one_step_in_flight"]["steps_in_flight"] == 1
+    assert 0.8 < j["config"]["one_step_in_flight"]["ms_per_step"] / j["ms_per_step"] < 1.3, j["config"]["one_step_in_flight"]
+    assert set(j["roofline"]["ab"]["steps_in_flight"]) == {"one_ms_per_step", "2_ms_per_step"}
+    assert j["roofline"]["profiling_pass"]["kernel_time_within_its_own_step"] is True
+    assert all(c["steps_in_flight"] == 2 and c["one_step_in_flight"]["ms_per_step"] > 0 for c in others)
     for c in others:
         if c["bound"] == "hbm":
             sc = c["stream_ceiling"]
@@ -905,6 +912,59 @@ def test_multi_constellation_jobs_single_rank(engine):
         got = sh.results(name, items, m, acquire.doppler_grid(ds))[0]
         assert got == w, name
     engine.set_stream(None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nlanes", [2, 3])
+def test_multi_constellation_jobs_on_job_lanes_equal_the_serial_records(engine, nlanes):
+    """ShardedSearch.enable_job_lanes: the searches of one job list queued on several contexts, each on a stream with a hardware queue of
+    its own -- the records must be the serial ones bit for bit, in the caller's job order, step after step (buffers reused)."""
+    import torch
+    from gnss_dsp_tools_amd import acquire, sharded, signals, synth
+    specs = [("gps-l1", [3, 11, 28], [-2000.0, 2000.0, 250.0], 2), ("galileo-e1b", [5, 24], [-500.0, 500.0, 250.0], 8),
+             ("beidou-b1i", [6, 33], [1000.0, 2000.0, 250.0], 2), ("glonass-l1", [-7, 3], [1000.0, 2000.0, 250.0], 1)]
+    jobs = []
+    for name, items, ds, ms in specs:
+        sig = signals.get(name)
+        B = sig.blocks(ms)
+        x = synth.make_iq(sig, B, 9191, [(items[0], 0.4, 1537.0, 1201)])
+        jobs.append({"name": sig, "x": torch.from_numpy(x[None, :sig.samples_needed(B)].copy()).cuda(), "items": items,
+                     "dopplers": acquire.doppler_grid(ds), "blocks": B})
+    sh = sharded.ShardedSearch(engine=engine)
+    want = [t.cpu().numpy().copy() for t in sh.search_jobs(jobs)]
+    sh.enable_job_lanes(nlanes)
+    try:
+        for _ in range(3):
+            got = sh.search_jobs(jobs)
+            torch.cuda.synchronize()
+            for (name, _, _, _), g_, w in zip(specs, got, want):
+                assert np.array_equal(g_.cpu().numpy(), w), name
+    finally:
+        sh.close_job_lanes()
+        engine.set_stream(None)
+
+
+@pytest.mark.gpu
+def test_masked_stream_selects_the_cus_it_names_and_a_full_mask_the_whole_device(engine):
+    """gacq_stream_create_cu_mask / gacq_cu_census: the low m bits of the mask are m / 8 CUs of every XCD; the full mask (a stream that
+    only wants a hardware queue of its own) reaches every CU."""
+    import torch
+    from gnss_dsp_tools_amd import acquire
+    total = torch.cuda.get_device_properties(0).multi_processor_count
+    try:
+        assert len(engine.cu_census(8192)) == total
+        for cus in (32, total):
+            ms = acquire.MaskedStream(0, None if cus == total else cus)
+            engine.set_stream(ms.handle)
+            places = engine.cu_census(8192)
+            engine.set_stream(None)
+            ms.close()
+            per_xcc = {}
+            for p_ in places:
+                per_xcc[p_[0]] = per_xcc.get(p_[0], 0) + 1
+            assert len(places) == cus and set(per_xcc.values()) == {cus // 8} and len(per_xcc) == 8, (cus, per_xcc)
+    finally:
+        engine.set_stream(None)
 
 
 def test_caller_supplied_chips_equal_builtin_generators():

@@ -194,6 +194,15 @@ def test_new_entry_points_fail_loudly_without_crashing():
     assert lib.gacq_debug_fft_plans(None) == -1
     assert lib.gacq_acquire_int8(None, None, 0, 1.0, 0.0, None, 0, 0, None, 0, None, 0, None, 0, None) == -1
     assert set(nat.OPTIONS.values()) == set(range(len(nat.OPTIONS)))          # GACQ_OPT_* numbering is dense
+    # round 6: streams with a hardware queue of their own / a CU mask
+    sh, mask = ctypes.c_void_p(), (ctypes.c_uint32 * 8)(*([0xffffffff] * 8))
+    assert lib.gacq_stream_create_cu_mask(0, mask, 8, None) == -1
+    assert lib.gacq_stream_create_cu_mask(-1, mask, 8, ctypes.byref(sh)) == -1 and not sh.value
+    assert lib.gacq_stream_create_cu_mask(0, None, 8, ctypes.byref(sh)) == -1 and lib.gacq_stream_create_cu_mask(0, mask, 0, ctypes.byref(sh)) == -1
+    if lib.gacq_device_count() > 0:
+        assert lib.gacq_stream_create_cu_mask(0, (ctypes.c_uint32 * 8)(), 8, ctypes.byref(sh)) == -1 and not sh.value      # empty mask
+    assert lib.gacq_stream_destroy(0, None) == 0
+    assert lib.gacq_cu_census(None, 16, None) == -1
     hdr = open(os.path.join(ROOT, "include", "gacq.h")).read()
     for name, num in nat.OPTIONS.items():
         assert re.search(r"#define GACQ_OPT_%s %d\b" % (name.upper(), num), hdr), name

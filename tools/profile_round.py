@@ -20,7 +20,8 @@ def trace(out, name, cmd):
     r = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "t", "--"] + cmd, cwd="/tmp", env=ENV,
                        capture_output=True, text=True)
     lines = ["# rocprofv3 --kernel-trace --stats -- " + " ".join(os.path.relpath(c, ROOT) if c.startswith(ROOT) else c for c in cmd),
-             "# taken at commit " + os.environ.get("GACQ_EVIDENCE_HEAD", "unknown"), ""]
+             "# taken at commit " + os.environ.get("GACQ_EVIDENCE_HEAD", "unknown"),
+             "# (--lanes 1 = one step in flight, as in bench.py's profiling pass: overlapped launches have no duration of their own)", ""]
     for path in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
         rows = list(csv.DictReader(open(path)))
         lines.append("%-100s %6s %12s %12s %7s %10s %10s" % ("kernel", "calls", "total_us", "avg_us", "%", "min_us", "max_us"))
@@ -56,7 +57,10 @@ def main():
     out = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     os.makedirs(out, exist_ok=True)
     py = sys.executable
-    bench = [py, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-latency", "--no-pmc", "--no-others"]
+    # --lanes 1: ONE step in flight.  The bench's default keeps two (overlapped on two hardware queues); overlapped launches share the
+    # device, so their durations in a trace say nothing about the kernel -- the roofline's kernel time comes from the bench's
+    # one-step-in-flight profiling pass, and that is what these traces must agree with
+    bench = [py, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-latency", "--no-pmc", "--no-others", "--lanes", "1"]
     for cfg in (2, 3, 4, 5):
         trace(out, "config%d" % cfg, bench + ["--config", str(cfg)])
     txt = pmc(out, "config2", bench + ["--steps", "2", "--warmup", "1", "--preroll-s", "0", "--sustained-s", "0"], "fused4k|lds_correlate|lds_forward|best_doppler")
