@@ -1019,12 +1019,16 @@ def run(args, env):
     # all-gather of step i runs under the kernels of step i+1 (asynchronous collective, merge deferred by one step); with
     # --lanes 2 the steps also alternate between two engine contexts with their own HIP streams and workspaces.  Every step
     # runs all of its kernels, the exchange and the merge inside the timed region.
-    lanes, own_queues = [], []
+    lanes, own_queues, lane_queue_note = [], [], "one hardware queue per lane (streams created with a full CU mask)"
     for _ in range(max(1, args.lanes)):
         # a stream with a hardware queue of its own: plain HIP streams are multiplexed over a few queues, and two lanes that land on the
         # same one would run one after the other (acquire.MaskedStream; tools/exp_lanes_debug.py: the overlap was there or not by luck)
-        own_queues.append(acquire.MaskedStream(local_rank))
-        st = own_queues[-1].torch_stream
+        try:
+            own_queues.append(acquire.MaskedStream(local_rank))
+            st = own_queues[-1].torch_stream
+        except Exception as exc:                       # no CU-mask streams on this system: plain streams (the lanes may then share a queue)
+            lane_queue_note = "plain torch streams (gacq_stream_create_cu_mask failed: %s)" % repr(exc)[:160]
+            st = torch.cuda.Stream(dev)
         e2 = make_engine()
         with torch.cuda.stream(st):
             lanes.append((st, e2, sharded.ShardedSearch(engine=e2, always_gather=args.force_gather)))
@@ -1367,7 +1371,7 @@ def run(args, env):
                        "cells_per_step": cells_step, "cell_blocks_per_step": cell_blocks_step, "sharding": sharding,
                        "shards_seen_by_every_rank": shards_seen,
                        "engine": {0: "auto", 1: "rocfft", 2: "lds-fft", 3: "split", 4: "split-lds", 5: "complex128"}[args.engine],
-                       "steps_in_flight": len(lanes), "one_step_in_flight": one_lane},
+                       "steps_in_flight": len(lanes), "one_step_in_flight": one_lane, "lane_queues": lane_queue_note},
             "preroll": preroll,
             "sustained": sustained,
             "roofline": roofline,
