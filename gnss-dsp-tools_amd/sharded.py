@@ -62,7 +62,6 @@ class ShardedSearch:
         profiles/r06_config5_clocks_and_overlap.log)."""
         if self.engine is None:
             raise RuntimeError("job lanes: needs an engine (the CPU test stand-in has no streams)")
-        import torch
         self.close_job_lanes()
         self._lane_order = order
         for _ in range(max(0, int(n) - 1)):
@@ -74,9 +73,8 @@ class ShardedSearch:
         return self
 
     def close_job_lanes(self):
-        import torch
         for eng, st, own in getattr(self, "_lanes", []):
-            torch.cuda.synchronize(eng.device)
+            st.synchronize()
             eng.close()
             own.close()
         self._lanes = []
