@@ -127,6 +127,26 @@ def test_doppler_bounds_cover_grid():
             assert max(b[i + 1] - b[i] for i in range(w)) - min(b[i + 1] - b[i] for i in range(w)) <= 1
 
 
+def test_job_lanes_need_an_engine_and_cost_order_puts_the_longest_search_first():
+    """ShardedSearch.enable_job_lanes is a GPU feature (contexts on streams of their own): the CPU stand-in path refuses it loudly and
+    keeps running its jobs serially; the queueing order is by cells x blocks, the cheapest job closing the step."""
+    import numpy as np
+    import pytest
+    from gnss_dsp_tools_amd import sharded, signals
+    sh = sharded.ShardedSearch(local_fn=lambda *a: None)
+    with pytest.raises(RuntimeError):
+        sh.enable_job_lanes(2)
+    assert sh._lanes == []
+    x1 = np.zeros((1, 8), dtype=np.complex64)
+    jobs = [{"name": "gps-l1", "x": x1, "items": list(range(32)), "dopplers": np.arange(200.0), "blocks": 10},
+            {"name": "galileo-e1b", "x": x1, "items": list(range(50)), "dopplers": np.arange(200.0), "blocks": 1},
+            {"name": "beidou-b1i", "x": x1, "items": list(range(63)), "dopplers": np.arange(200.0), "blocks": 10},
+            {"name": "glonass-l1", "x": x1, "items": list(range(15)), "dopplers": np.arange(200.0), "blocks": 10}]
+    cost = [sharded.ShardedSearch._job_cost(j) for j in jobs]
+    assert sorted(range(4), key=lambda i: -cost[i]) == [2, 1, 3, 0]                 # B1I, E1B, GLONASS, GPS L1
+    assert cost[0] == 32 * 200 * signals.get("gps-l1").nfft * 10
+
+
 def test_merge_tie_rule_lowest_doppler_wins():
     """Equal metrics in two shards: the earlier shard (lower Doppler) must win, like the strict '>' scan."""
     from gnss_dsp_tools_amd import acquire, sharded
